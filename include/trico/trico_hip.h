@@ -1,0 +1,102 @@
+/*
+ * trico_hip.h — thin C-ABI shim between the host C container code (trico_amd/csrc/host/archive.c)
+ * and the hand-written HIP kernels for gfx950 (trico_amd/csrc/hip/).  Plain C types only: no HIP,
+ * torch or C++ types cross this boundary.  This surface has no reference counterpart; each entry
+ * names the reference loops it replaces.
+ *
+ * Pointers named `src`/`dst`/`payloads[]` may be host or HIP device pointers (detected with
+ * hipPointerGetAttributes); host data is staged through the context's device workspace.
+ * All functions return 1 on success and 0 on failure unless stated; on failure
+ * trico_hip_last_error() returns a static description.  Nothing aborts.
+ */
+#ifndef TRICO_TRICO_HIP_H
+#define TRICO_TRICO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__cplusplus)
+extern "C" {
+#endif
+
+#ifndef TRICO_API
+#define TRICO_API __attribute__((visibility("default")))
+#endif
+
+typedef struct trico_hip_ctx trico_hip_ctx;   /* per-archive device workspace (not thread-shared) */
+
+/* ---- device / context ------------------------------------------------------------------- */
+TRICO_API int  trico_hip_available(void);                 /* 1 if a HIP device can be used */
+TRICO_API const char* trico_hip_last_error(void);         /* thread-local, never NULL */
+TRICO_API trico_hip_ctx* trico_hip_ctx_create(void);      /* NULL if no device */
+TRICO_API void trico_hip_ctx_destroy(trico_hip_ctx* ctx);
+TRICO_API void trico_hip_set_stream(void* hip_stream);    /* stream for all later launches of this thread (default: null stream) */
+TRICO_API int  trico_hip_synchronize(void);
+
+/* ---- memory helpers ---------------------------------------------------------------------- */
+TRICO_API int   trico_hip_pointer_is_device(const void* p);
+TRICO_API void* trico_hip_device_alloc(size_t bytes);
+TRICO_API void  trico_hip_device_free(void* p);
+TRICO_API int   trico_hip_copy(void* dst, const void* src, size_t bytes);   /* any direction, complete on return */
+
+/* ---- floating-point streams ---------------------------------------------------------------
+ * Replaces trico_transpose_*_aos_to_soa (transpose_aos_to_soa.c:8-82) fused with
+ * trico_compress / trico_compress_double_precision (fpsc.c:86-210 / 576-800), called per
+ * component with exponents (4,10) for width 4 and (20,20) for width 8 (trico.c:231,396).
+ * `src`: n elements of `arity` interleaved components (arity 1..3), `width` 4 or 8 bytes.
+ * On success sizes[c] is the payload size of component c; payloads stay in the context until
+ * the next encode and are copied out with trico_hip_fetch_payload. */
+TRICO_API int trico_hip_fpc_encode(trico_hip_ctx* ctx, const void* src, uint32_t n, int arity, int width, uint32_t sizes[3]);
+
+/* Inverse: trico_decompress / trico_decompress_double_precision (fpsc.c:212-417 / 803-1164) per
+ * component, then trico_transpose_*_soa_to_aos.  Every payload must announce exactly `n` values.
+ * dst == NULL decodes and discards. */
+TRICO_API int trico_hip_fpc_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[3], const uint32_t sizes[3],
+                                   int arity, int width, uint32_t n, void* dst);
+
+/* ---- integer streams ------------------------------------------------------------------------
+ * Replaces trico_transpose_uint{16,32,64}_aos_to_soa (transpose_aos_to_soa.c:84-147) and one
+ * LZ4_compress_default per byte plane (trico.c:343-368; lz4.c:1271 -> 793-1181), byte-exact with
+ * LZ4 1.9.2.  `width` 1, 2, 4 or 8; width 1 is a single unsplit block (trico.c:630-656). */
+TRICO_API int trico_hip_int_encode(trico_hip_ctx* ctx, const void* src, uint32_t count, int width, uint32_t sizes[8]);
+
+/* Inverse: LZ4_decompress_safe per plane (trico.c:1100-1129) + trico_transpose_*_soa_to_aos. */
+TRICO_API int trico_hip_int_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[8], const uint32_t sizes[8],
+                                   int width, uint32_t count, void* dst);
+
+/* copy payload `c` of the last encode on this context to dst (host or device) */
+TRICO_API int trico_hip_fetch_payload(trico_hip_ctx* ctx, int c, void* dst);
+/* device address of payload `c` of the last encode (valid until the next encode on ctx) */
+TRICO_API const uint8_t* trico_hip_payload_device_pointer(trico_hip_ctx* ctx, int c);
+
+/* ---- device-resident archives ---------------------------------------------------------------
+ * Same handle type and semantics as trico_open_archive_for_writing (trico.c:126-156) but the
+ * archive buffer lives in HBM: trico_get_buffer_pointer then returns a device pointer.  Used when
+ * the .trc bytes are consumed on the GPU (RCCL gather, device-side decode) so nothing crosses PCIe. */
+TRICO_API void* trico_hip_open_archive_for_writing_device(uint64_t initial_buffer_size);
+
+/* ---- kernel timing (bench instrumentation) ---------------------------------------------------
+ * When enabled, every launch of a hot kernel is bracketed by hipEvents on the launch stream and
+ * the durations are accumulated per kernel id (TRICO_HIP_K_*).  Costs a sync per query only. */
+enum trico_hip_kernel_id
+  {
+  TRICO_HIP_K_FPC32_ENCODE = 0,   /* float coder, all passes (AoS load -> payload bytes) */
+  TRICO_HIP_K_FPC64_ENCODE = 1,
+  TRICO_HIP_K_FPC32_DECODE = 2,
+  TRICO_HIP_K_FPC64_DECODE = 3,
+  TRICO_HIP_K_PLANES_SPLIT = 4,
+  TRICO_HIP_K_PLANES_MERGE = 5,
+  TRICO_HIP_K_LZ4_ENCODE   = 6,
+  TRICO_HIP_K_LZ4_DECODE   = 7,
+  TRICO_HIP_K_COUNT        = 8
+  };
+TRICO_API void trico_hip_profile_enable(int on);
+TRICO_API void trico_hip_profile_reset(void);
+/* returns accumulated milliseconds and number of timed spans for kernel id `k` (syncs first) */
+TRICO_API double trico_hip_profile_ms(int k, uint64_t* spans);
+
+#if defined(__cplusplus)
+}
+#endif
+
+#endif /* TRICO_TRICO_HIP_H */

@@ -1,0 +1,176 @@
+"""GPU tier (-m gpu): the HIP path, called through the C-ABI (libtrico.so), against the oracle and
+the committed golden fixtures.  Bit-exact is the bar for everything here (integer/byte work)."""
+import ctypes
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from streams import ALL_ORDER, STREAM_TAG, mesh_streams
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api(native_libs):
+    L = native_libs.lib()
+    assert L.trico_hip_available() == 1, "no HIP device: " + native_libs.last_error()
+    return native_libs
+
+
+def write_archive(api, streams, device=False, initial=1 << 20):
+    a = api.Archive.open_for_writing(initial, device=device)
+    for name, data, count in streams:
+        assert a.write(name, data, count) == 1, (name, api.last_error())
+    b = a.tobytes()
+    a.close()
+    return b
+
+
+def oracle_archive(streams):
+    a = O.OracleArchive()
+    for name, data, count in streams:
+        a.write(name, data, count)
+    b = a.tobytes()
+    a.close()
+    return b
+
+
+def read_back(api, blob, streams):
+    r = api.Archive.open_for_reading(blob)
+    assert r is not None
+    for name, data, count in streams:
+        assert r.get_next_stream_type() == STREAM_TAG[name]
+        if name in ("attributes_float", "attributes_double"):
+            got = r.read_alloc(name, count, data.dtype)
+            assert got is not None, api.last_error()
+        else:
+            got = np.empty_like(data)
+            assert r.read(name, got) == 1, (name, api.last_error())
+        assert got.tobytes() == data.tobytes(), name
+    assert r.get_next_stream_type() == api.trico_empty
+    r.close()
+
+
+@pytest.mark.parametrize("kind", ["grid", "walk", "multi"])
+def test_small_golden_archives(api, gold_dir, kind):
+    want = open(os.path.join(gold_dir, "%s_16x8.trc" % kind), "rb").read()
+    streams = mesh_streams(kind, 16, 8)
+    assert write_archive(api, streams) == want
+    read_back(api, want, streams)
+
+
+def test_allstreams_golden(api, gold_dir, allstreams):
+    want = open(os.path.join(gold_dir, "allstreams.trc"), "rb").read()
+    streams = [(name, allstreams[name], allstreams[name].size // div) for name, div, _ in ALL_ORDER]
+    got = write_archive(api, streams, initial=16)      # tiny initial buffer: exercises growth
+    assert got == want
+    read_back(api, want, streams)
+
+
+def test_kat_through_shim(api, kat):
+    L = api.lib()
+    ctx = L.trico_hip_ctx_create()
+    assert ctx
+    try:
+        for k in kat:
+            if k["n"] == 0:
+                continue
+            if k["kind"] == "fpc":
+                a = np.frombuffer(bytes.fromhex(k["input_hex"]), dtype=k["dtype"]).copy()
+                sizes = (ctypes.c_uint32 * 3)()
+                assert L.trico_hip_fpc_encode(ctx, a.ctypes.data, a.size, 1, a.dtype.itemsize, sizes) == 1
+            else:
+                a = np.frombuffer(bytes.fromhex(k["input_hex"]), dtype=np.uint8).copy()
+                sizes = (ctypes.c_uint32 * 8)()
+                assert L.trico_hip_int_encode(ctx, a.ctypes.data, a.size, 1, sizes) == 1
+            out = np.empty(sizes[0], np.uint8)
+            assert L.trico_hip_fetch_payload(ctx, 0, out.ctypes.data) == 1
+            assert out.tobytes().hex() == k["payload_hex"], k["name"]
+    finally:
+        L.trico_hip_ctx_destroy(ctx)
+
+
+@pytest.mark.parametrize("n", list(range(1, 20)) + [63, 64, 65, 127, 128, 129, 1000, 4097])
+def test_fp_tails_vs_oracle(api, n):
+    rng = np.random.default_rng(100 + n)
+    for dt, wname, rname in ((np.float32, "attributes_float", "vertices"), (np.float64, "attributes_double", "vertices_double")):
+        a = (np.cumsum(rng.integers(-9, 10, 3 * n)) * 0.03125).astype(dt)
+        a[rng.integers(0, 3 * n)] = dt(rng.standard_normal())
+        streams = [(rname, a, n), (wname, a[:n].copy(), n)]
+        got = write_archive(api, streams)
+        assert got == oracle_archive(streams)
+        read_back(api, got, streams)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 12, 13, 14, 15, 16, 17, 255, 4096, 65546, 65547, 65548, 100001])
+def test_int_edges_vs_oracle(api, n):
+    rng = np.random.default_rng(200 + n)
+    a8 = ((np.arange(n) // 5 % 256).astype(np.uint8) ^ (rng.integers(0, 256, n) > 250).astype(np.uint8))
+    a16 = (np.arange(n) % 1000).astype(np.uint16)
+    a32 = rng.integers(0, max(2, n), n, dtype=np.uint32)
+    a64 = np.arange(n, dtype=np.uint64) * 0x10001
+    streams = [("attributes_uint8", a8, n), ("attributes_uint16", a16, n), ("attributes_uint32", a32, n),
+               ("attributes_uint64", a64, n), ("vertex_colors", a32, n)]
+    if n % 3 == 0:
+        streams += [("triangles", a32, n // 3), ("triangles_long", a64, n // 3)]
+    got = write_archive(api, streams)
+    assert got == oracle_archive(streams)
+    read_back(api, got, streams)
+
+
+@pytest.mark.parametrize("kind,W,H", [("grid", 200, 100), ("walk", 200, 100), ("multi", 100, 100)])
+def test_meshes_vs_oracle(api, kind, W, H):
+    streams = mesh_streams(kind, W, H)
+    got = write_archive(api, streams)
+    assert got == oracle_archive(streams)
+    read_back(api, got, streams)
+
+
+def test_double_uv_writer_quirk(api):
+    # trico.c:620-628: the double uv writers emit the FLOAT tags 5/7 and the unscaled count
+    uv = (np.arange(40) / 64.0).astype(np.float64)
+    streams = [("uv_per_vertex_double", uv, 20), ("uv_per_triangle_double", uv, 20)]
+    got = write_archive(api, streams)
+    assert got == oracle_archive(streams)
+    assert got[8] == 5
+    r = api.Archive.open_for_reading(got)
+    out = np.empty(40, np.float32)
+    assert r.read("uv_per_vertex", out) == 0      # a double payload cannot be read by the float reader
+    assert r.read("uv_per_vertex_double", np.empty(40, np.float64)) == 0   # tag is 5, not 6
+    r.close()
+
+
+def test_device_pointers_and_device_archive(api):
+    torch = pytest.importorskip("torch")
+    streams = mesh_streams("grid", 64, 32)
+    want = oracle_archive(streams)
+    dev = [(name, torch.from_numpy(data.view(np.uint8).copy()).cuda(), count) for name, data, count in streams]
+    a = api.Archive.open_for_writing(64, device=True)
+    for name, t, count in dev:
+        assert a.write(name, t, count) == 1, api.last_error()
+    assert api.lib().trico_hip_pointer_is_device(a.get_buffer_pointer()) == 1
+    assert a.tobytes() == want
+    # decode straight from the device-resident archive into device outputs
+    size = a.get_size()
+    r = api.Archive.open_for_reading(a.get_buffer_pointer(), size)
+    assert r is not None
+    for (name, data, count), (_, t, _) in zip(streams, dev):
+        out = torch.zeros_like(t)
+        assert r.read(name, out) == 1, api.last_error()
+        assert torch.equal(out, t)
+    r.close()
+    a.close()
+
+
+def test_corrupt_payload_is_rejected(api, gold_dir):
+    blob = bytearray(open(os.path.join(gold_dir, "grid_16x8.trc"), "rb").read())
+    # vertex stream: tag(1) count(4) nbytes(4) then payload: break the announced value count
+    blob[8 + 1 + 4 + 4 + 4] ^= 0x55
+    r = api.Archive.open_for_reading(bytes(blob))
+    out = np.empty(16 * 8 * 3, np.float32)
+    assert r.read("vertices", out) == 0
+    assert r.get_next_stream_type() == api.trico_vertex_float_stream
+    r.close()

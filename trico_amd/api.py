@@ -1,0 +1,265 @@
+"""ctypes binding of libtrico.so — the C-ABI of include/trico/trico.h and trico_hip.h.
+
+The names, argument meaning and 1/0 error convention are the reference's (trico/trico.h:36-94);
+this module only adds the argtypes.  Data arguments accept numpy arrays (host), torch CUDA tensors
+(device, via data_ptr) or raw integer addresses.  Nothing here computes: every call goes through
+the shared library, and loading fails loudly if the library has not been built.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtrico.so")
+
+_lib = None
+
+# reference: trico/trico.h:11-34
+STREAM_TYPES = [
+    "trico_empty", "trico_vertex_float_stream", "trico_vertex_double_stream",
+    "trico_triangle_uint32_stream", "trico_triangle_uint64_stream",
+    "trico_uv_per_vertex_float_stream", "trico_uv_per_vertex_double_stream",
+    "trico_uv_per_triangle_float_stream", "trico_uv_per_triangle_double_stream",
+    "trico_vertex_normal_float_stream", "trico_vertex_normal_double_stream",
+    "trico_triangle_normal_float_stream", "trico_triangle_normal_double_stream",
+    "trico_vertex_color_stream", "trico_triangle_color_stream",
+    "trico_attribute_float_stream", "trico_attribute_double_stream",
+    "trico_attribute_uint8_stream", "trico_attribute_uint16_stream",
+    "trico_attribute_uint32_stream", "trico_attribute_uint64_stream",
+]
+for _i, _n in enumerate(STREAM_TYPES):
+    globals()[_n] = _i
+
+WRITERS = [
+    "trico_write_vertices", "trico_write_vertices_double", "trico_write_triangles", "trico_write_triangles_long",
+    "trico_write_uv_per_vertex", "trico_write_uv_per_vertex_double", "trico_write_uv_per_triangle",
+    "trico_write_uv_per_triangle_double", "trico_write_vertex_normals", "trico_write_vertex_normals_double",
+    "trico_write_triangle_normals", "trico_write_triangle_normals_double", "trico_write_vertex_colors",
+    "trico_write_triangle_colors", "trico_write_attributes_float", "trico_write_attributes_double",
+    "trico_write_attributes_uint8", "trico_write_attributes_uint16", "trico_write_attributes_uint32",
+    "trico_write_attributes_uint64",
+]
+READERS = [w.replace("trico_write_", "trico_read_") for w in WRITERS]
+PEEKS = [
+    "trico_get_number_of_vertices", "trico_get_number_of_triangles", "trico_get_number_of_uvs",
+    "trico_get_number_of_normals", "trico_get_number_of_colors", "trico_get_number_of_attributes",
+]
+API_SYMBOLS = (
+    ["trico_open_archive_for_writing", "trico_open_archive_for_reading", "trico_close_archive"]
+    + WRITERS + ["trico_get_buffer_pointer", "trico_get_size", "trico_get_version", "trico_get_next_stream_type"]
+    + PEEKS + READERS + ["trico_skip_next_stream"]
+)
+HIP_SYMBOLS = [
+    "trico_hip_available", "trico_hip_last_error", "trico_hip_ctx_create", "trico_hip_ctx_destroy",
+    "trico_hip_set_stream", "trico_hip_synchronize", "trico_hip_pointer_is_device", "trico_hip_device_alloc",
+    "trico_hip_device_free", "trico_hip_copy", "trico_hip_fpc_encode", "trico_hip_fpc_decode",
+    "trico_hip_int_encode", "trico_hip_int_decode", "trico_hip_fetch_payload", "trico_hip_payload_device_pointer",
+    "trico_hip_open_archive_for_writing_device", "trico_hip_profile_enable", "trico_hip_profile_reset",
+    "trico_hip_profile_ms",
+]
+KERNEL_IDS = {
+    "fpc32_encode": 0, "fpc64_encode": 1, "fpc32_decode": 2, "fpc64_decode": 3,
+    "planes_split": 4, "planes_merge": 5, "lz4_encode": 6, "lz4_decode": 7,
+}
+
+
+def lib():
+    """Load libtrico.so (once).  Raises if it is missing: there is no Python/CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libtrico.so not built: run `python -m trico_amd.build` (needs hipcc). "
+            "The trico hot path has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u8p, u32, u64, ci = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
+    L.trico_open_archive_for_writing.restype = vp
+    L.trico_open_archive_for_writing.argtypes = [u64]
+    L.trico_hip_open_archive_for_writing_device.restype = vp
+    L.trico_hip_open_archive_for_writing_device.argtypes = [u64]
+    L.trico_open_archive_for_reading.restype = vp
+    L.trico_open_archive_for_reading.argtypes = [u8p, u64]
+    L.trico_close_archive.restype = None
+    L.trico_close_archive.argtypes = [vp]
+    for w in WRITERS:
+        f = getattr(L, w)
+        f.restype = ci
+        f.argtypes = [vp, vp, u32]
+    for r in READERS:
+        f = getattr(L, r)
+        f.restype = ci
+        f.argtypes = [vp, ctypes.POINTER(ctypes.c_void_p)]
+    L.trico_skip_next_stream.restype = ci
+    L.trico_skip_next_stream.argtypes = [vp]
+    L.trico_get_buffer_pointer.restype = vp
+    L.trico_get_buffer_pointer.argtypes = [vp]
+    L.trico_get_size.restype = u64
+    L.trico_get_size.argtypes = [vp]
+    L.trico_get_version.restype = u32
+    L.trico_get_version.argtypes = [vp]
+    L.trico_get_next_stream_type.restype = ci
+    L.trico_get_next_stream_type.argtypes = [vp]
+    for p in PEEKS:
+        f = getattr(L, p)
+        f.restype = u32
+        f.argtypes = [vp]
+    # shim
+    L.trico_hip_available.restype = ci
+    L.trico_hip_last_error.restype = ctypes.c_char_p
+    L.trico_hip_ctx_create.restype = vp
+    L.trico_hip_ctx_destroy.argtypes = [vp]
+    L.trico_hip_ctx_destroy.restype = None
+    L.trico_hip_set_stream.argtypes = [vp]
+    L.trico_hip_set_stream.restype = None
+    L.trico_hip_synchronize.restype = ci
+    L.trico_hip_pointer_is_device.argtypes = [vp]
+    L.trico_hip_pointer_is_device.restype = ci
+    L.trico_hip_device_alloc.argtypes = [ctypes.c_size_t]
+    L.trico_hip_device_alloc.restype = vp
+    L.trico_hip_device_free.argtypes = [vp]
+    L.trico_hip_device_free.restype = None
+    L.trico_hip_copy.argtypes = [vp, vp, ctypes.c_size_t]
+    L.trico_hip_copy.restype = ci
+    L.trico_hip_fpc_encode.argtypes = [vp, vp, u32, ci, ci, ctypes.POINTER(u32)]
+    L.trico_hip_fpc_encode.restype = ci
+    L.trico_hip_fpc_decode.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u32), ci, ci, u32, vp]
+    L.trico_hip_fpc_decode.restype = ci
+    L.trico_hip_int_encode.argtypes = [vp, vp, u32, ci, ctypes.POINTER(u32)]
+    L.trico_hip_int_encode.restype = ci
+    L.trico_hip_int_decode.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u32), ci, u32, vp]
+    L.trico_hip_int_decode.restype = ci
+    L.trico_hip_fetch_payload.argtypes = [vp, ci, vp]
+    L.trico_hip_fetch_payload.restype = ci
+    L.trico_hip_payload_device_pointer.argtypes = [vp, ci]
+    L.trico_hip_payload_device_pointer.restype = vp
+    L.trico_hip_profile_enable.argtypes = [ci]
+    L.trico_hip_profile_enable.restype = None
+    L.trico_hip_profile_reset.restype = None
+    L.trico_hip_profile_ms.argtypes = [ci, ctypes.POINTER(u64)]
+    L.trico_hip_profile_ms.restype = ctypes.c_double
+    _lib = L
+    return L
+
+
+def ptr(x):
+    """Address of a numpy array, torch tensor, ctypes buffer, bytes object or int."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    if isinstance(x, (bytes, bytearray)):
+        return ctypes.cast(ctypes.c_char_p(bytes(x)), ctypes.c_void_p).value
+    return ctypes.addressof(x)
+
+
+def last_error():
+    return lib().trico_hip_last_error().decode()
+
+
+class Archive:
+    """Thin object wrapper over one archive handle; method names are the C names minus `trico_`."""
+
+    def __init__(self, handle, keepalive=None):
+        if not handle:
+            raise RuntimeError("trico archive could not be opened: " + last_error())
+        self.h = handle
+        self._keep = keepalive
+
+    @classmethod
+    def open_for_writing(cls, initial_buffer_size=1 << 20, device=False):
+        L = lib()
+        if device:
+            return cls(L.trico_hip_open_archive_for_writing_device(initial_buffer_size))
+        return cls(L.trico_open_archive_for_writing(initial_buffer_size))
+
+    @classmethod
+    def open_for_reading(cls, data, size=None):
+        """data: bytes / numpy uint8 array (host) or a torch CUDA uint8 tensor / int address (device)."""
+        L = lib()
+        if isinstance(data, (bytes, bytearray)):
+            data = np.frombuffer(bytes(data), dtype=np.uint8)
+        if size is None:
+            size = data.nbytes if isinstance(data, np.ndarray) else data.numel() * data.element_size()
+        h = L.trico_open_archive_for_reading(ptr(data), size)
+        if not h:
+            return None
+        return cls(h, keepalive=data)
+
+    def close(self):
+        if self.h:
+            lib().trico_close_archive(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # write side
+    def write(self, name, data, count):
+        return getattr(lib(), "trico_write_" + name)(self.h, ptr(data), count)
+
+    def get_size(self):
+        return lib().trico_get_size(self.h)
+
+    def get_buffer_pointer(self):
+        return lib().trico_get_buffer_pointer(self.h)
+
+    def tobytes(self):
+        """Copy of the archive bytes (works for host and device archives)."""
+        L = lib()
+        n = L.trico_get_size(self.h)
+        p = L.trico_get_buffer_pointer(self.h)
+        if L.trico_hip_pointer_is_device(p):
+            buf = (ctypes.c_uint8 * n)()
+            if not L.trico_hip_copy(ctypes.addressof(buf), p, n):
+                raise RuntimeError(last_error())
+            return bytes(buf)
+        return ctypes.string_at(p, n)
+
+    # read side
+    def get_version(self):
+        return lib().trico_get_version(self.h)
+
+    def get_next_stream_type(self):
+        return lib().trico_get_next_stream_type(self.h)
+
+    def get_number_of(self, what):
+        return getattr(lib(), "trico_get_number_of_" + what)(self.h)
+
+    def read(self, name, out):
+        """out: caller-allocated array/tensor, or None to decode-and-discard (NULL)."""
+        f = getattr(lib(), "trico_read_" + name)
+        if out is None:
+            return f(self.h, None)
+        box = ctypes.c_void_p(ptr(out))
+        return f(self.h, ctypes.byref(box))
+
+    def read_alloc(self, name, count, dtype):
+        """trico_read_attributes_float/double: the library mallocs the output; returns a numpy copy."""
+        f = getattr(lib(), "trico_read_" + name)
+        box = ctypes.c_void_p(None)
+        ok = f(self.h, ctypes.byref(box))
+        if not ok:
+            return None
+        arr = np.ctypeslib.as_array(ctypes.cast(box, ctypes.POINTER(ctypes.c_uint8)), shape=(count * np.dtype(dtype).itemsize,)).copy()
+        libc = ctypes.CDLL(None)
+        libc.free.argtypes = [ctypes.c_void_p]
+        libc.free(box)
+        return arr.view(dtype)
+
+    def skip_next_stream(self):
+        return lib().trico_skip_next_stream(self.h)

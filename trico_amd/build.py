@@ -1,0 +1,75 @@
+"""In-tree build of the native libraries (gfx950 only).
+
+    python -m trico_amd.build            # build what is stale
+    python -m trico_amd.build --force
+
+Outputs (git-ignored, but they travel to the GPU box with the gpurun snapshot):
+    trico_amd/lib/libtrico.so            host C container + HIP kernels + C-ABI shim
+    trico_amd/lib/libtrico_meshgen.so    synthetic mesh generators (tests / bench only)
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(HERE, "build")
+INCLUDE = os.path.join(ROOT, "include")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CC = os.environ.get("CC", "gcc")
+ARCH = "gfx950"
+
+HOST_C = ["host/archive.c"]
+HIP_SRC = sorted(f for f in os.listdir(os.path.join(CSRC, "hip")) if f.endswith(".hip"))
+HIP_HDR = sorted(f for f in os.listdir(os.path.join(CSRC, "hip")) if f.endswith(".hpp"))
+
+LIBTRICO = os.path.join(LIBDIR, "libtrico.so")
+LIBMESHGEN = os.path.join(LIBDIR, "libtrico_meshgen.so")
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    headers = [os.path.join(INCLUDE, "trico", h) for h in ("trico.h", "trico_hip.h")]
+    headers += [os.path.join(CSRC, "hip", h) for h in HIP_HDR]
+    objs = []
+    for rel in HOST_C:
+        src = os.path.join(CSRC, rel)
+        obj = os.path.join(OBJDIR, os.path.basename(rel) + ".o")
+        if force or _stale(obj, [src] + headers):
+            _run([CC, "-O2", "-std=c11", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wextra",
+                  "-I" + INCLUDE, "-c", src, "-o", obj])
+        objs.append(obj)
+    for f in HIP_SRC:
+        src = os.path.join(CSRC, "hip", f)
+        obj = os.path.join(OBJDIR, f + ".o")
+        if force or _stale(obj, [src] + headers):
+            _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+                  "-Wall", "-Wno-unused-function", "-I" + INCLUDE, "-I" + os.path.join(CSRC, "hip"),
+                  "-c", src, "-o", obj])
+        objs.append(obj)
+    if force or _stale(LIBTRICO, objs):
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIBTRICO] + objs)
+    mg = os.path.join(CSRC, "tools", "meshgen.c")
+    if force or _stale(LIBMESHGEN, [mg]):
+        _run([CC, "-O2", "-std=c11", "-fPIC", "-fvisibility=hidden", "-shared", mg, "-o", LIBMESHGEN])
+    return LIBTRICO
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,84 @@
+// common.hpp — internal declarations shared by the HIP translation units (gfx950 only).
+// Nothing here crosses the C-ABI; see include/trico/trico_hip.h for the exported surface.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "trico/trico_hip.h"
+
+namespace trico {
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error(const char* msg);
+bool hip_ok(hipError_t e, const char* what);
+#define TRICO_HIP_TRY(expr) do { if (!::trico::hip_ok((expr), #expr)) return 0; } while (0)
+
+hipStream_t current_stream();
+
+// ---- growable device workspace --------------------------------------------------------------
+struct DevBuf
+  {
+  uint8_t* p = nullptr;
+  size_t cap = 0;
+  bool reserve(size_t bytes);   // grow-only, contents NOT preserved
+  void release();
+  };
+
+} // namespace trico
+
+// Per-archive workspace.  One context must not be used from two threads at once (same rule as
+// the reference's archive handle, SURVEY.md §8(b) "threading").
+struct trico_hip_ctx
+  {
+  trico::DevBuf in;        // staged host input / staged host payloads
+  trico::DevBuf out;       // encoded payloads (component c at out.p + c * out_stride) / staged decode output
+  trico::DevBuf tmp;       // planes, SoA intermediates, predictor tables
+  trico::DevBuf aux;       // small: sizes, status words, segment summaries
+  size_t out_stride = 0;
+  uint32_t out_sizes[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  int out_count = 0;
+  uint32_t* h_pinned = nullptr;   // 64 words of pinned host memory for size/status read-back
+  };
+
+namespace trico {
+
+// ---- profiling spans ---------------------------------------------------------------------------
+struct ProfSpan
+  {
+  int k;
+  bool active;
+  hipEvent_t e0, e1;
+  explicit ProfSpan(int kernel_id);
+  ~ProfSpan();
+  };
+
+// ---- payload size bounds -------------------------------------------------------------------------
+inline size_t fpc_bound(uint32_t n, int width)
+  {
+  const size_t g = (width == 4) ? 8 : 2, hdr = (width == 4) ? 3 : 1;
+  return 5 + (size_t)width * n + hdr * (((size_t)n + g - 1) / g + 1) + g;
+  }
+inline size_t lz4_bound(uint32_t n) { return (size_t)n + n / 255 + 16; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- kernel launchers (k_*.hip) ----------------------------------------------------------------
+// All launch on current_stream(); device pointers only.  `status` is a device word that kernels
+// set non-zero on malformed input.
+
+// serial reference-order kernels (k_serial.hip): one workgroup per component stream / plane.
+int launch_fpc_encode_serial(const void* d_src, uint32_t n, int arity, int width, uint8_t* d_out, size_t out_stride,
+                             uint32_t* d_sizes, uint64_t* d_tables);
+int launch_fpc_decode_serial(const uint8_t* const d_payloads[3], const uint32_t sizes[3], int arity, int width,
+                             uint32_t n, void* d_dst, uint64_t* d_tables, uint32_t* d_status);
+int launch_lz4_encode_serial(const uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, int nplanes, uint8_t* d_out,
+                             size_t out_stride, uint32_t* d_sizes);
+int launch_lz4_decode_serial(const uint8_t* const d_payloads[8], const uint32_t sizes[8], int nplanes,
+                             uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, uint32_t* d_status);
+
+// byte-plane split / merge (k_planes.hip)
+int launch_planes_split(const void* d_src, uint32_t count, int width, uint8_t* d_planes, size_t plane_stride);
+int launch_planes_merge(const uint8_t* d_planes, size_t plane_stride, uint32_t count, int width, void* d_dst);
+
+} // namespace trico

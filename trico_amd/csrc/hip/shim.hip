@@ -1,0 +1,525 @@
+// shim.hip — the extern "C" surface of include/trico/trico_hip.h: device/context management,
+// host<->device staging and dispatch to the gfx950 kernels.  No compute happens on the host.
+#include "common.hpp"
+
+#include <new>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace trico {
+
+static thread_local char g_err[256] = "";
+static thread_local hipStream_t g_stream = nullptr;
+
+void set_error(const char* msg)
+  {
+  snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "");
+  }
+
+bool hip_ok(hipError_t e, const char* what)
+  {
+  if (e == hipSuccess)
+    return true;
+  snprintf(g_err, sizeof(g_err), "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+  (void)hipGetLastError();
+  return false;
+  }
+
+hipStream_t current_stream() { return g_stream; }
+
+bool DevBuf::reserve(size_t bytes)
+  {
+  if (bytes <= cap)
+    return true;
+  release();
+  const size_t want = align_up(bytes + bytes / 8, 4096);
+  void* np = nullptr;
+  if (!hip_ok(hipMalloc(&np, want), "hipMalloc(workspace)"))
+    return false;
+  p = (uint8_t*)np;
+  cap = want;
+  return true;
+  }
+
+void DevBuf::release()
+  {
+  if (p)
+    (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+  }
+
+// ---- profiling ---------------------------------------------------------------------------------
+struct ProfRec { hipEvent_t e0, e1; int k; };
+static bool g_prof_on = false;
+static ProfRec* g_prof = nullptr;
+static size_t g_prof_n = 0, g_prof_cap = 0;
+static double g_prof_ms[TRICO_HIP_K_COUNT];
+static uint64_t g_prof_spans[TRICO_HIP_K_COUNT];
+
+static void prof_drain()
+  {
+  for (size_t i = 0; i < g_prof_n; ++i)
+    {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_prof[i].e1) == hipSuccess && hipEventElapsedTime(&ms, g_prof[i].e0, g_prof[i].e1) == hipSuccess)
+      {
+      g_prof_ms[g_prof[i].k] += ms;
+      g_prof_spans[g_prof[i].k] += 1;
+      }
+    (void)hipEventDestroy(g_prof[i].e0);
+    (void)hipEventDestroy(g_prof[i].e1);
+    }
+  g_prof_n = 0;
+  }
+
+ProfSpan::ProfSpan(int kernel_id) : k(kernel_id), active(false)
+  {
+  if (!g_prof_on)
+    return;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+    return;
+  active = true;
+  (void)hipEventRecord(e0, current_stream());
+  }
+
+ProfSpan::~ProfSpan()
+  {
+  if (!active)
+    return;
+  (void)hipEventRecord(e1, current_stream());
+  if (g_prof_n == g_prof_cap)
+    {
+    const size_t nc = g_prof_cap ? g_prof_cap * 2 : 256;
+    ProfRec* np = (ProfRec*)realloc(g_prof, nc * sizeof(ProfRec));
+    if (!np)
+      return;
+    g_prof = np;
+    g_prof_cap = nc;
+    }
+  g_prof[g_prof_n++] = ProfRec{ e0, e1, k };
+  }
+
+static int g_device_state = 0;   // 0 unknown, 1 ok, -1 none
+
+static bool device_ready()
+  {
+  if (g_device_state == 0)
+    {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+      {
+      (void)hipGetLastError();
+      g_device_state = -1;
+      }
+    else
+      g_device_state = 1;
+    }
+  if (g_device_state < 0)
+    set_error("no HIP device available: the trico hot path has no CPU fallback");
+  return g_device_state > 0;
+  }
+
+// stage `bytes` from src (host or device) so that kernels can read it; returns a device pointer
+static const void* stage_in(DevBuf& buf, const void* src, size_t bytes, size_t offset = 0)
+  {
+  if (trico_hip_pointer_is_device(src))
+    return src;
+  if (!hip_ok(hipMemcpyAsync(buf.p + offset, src, bytes, hipMemcpyHostToDevice, current_stream()), "H2D stage"))
+    return nullptr;
+  return buf.p + offset;
+  }
+
+static int read_back_words(trico_hip_ctx* ctx, const uint32_t* d_words, int count, uint32_t* host)
+  {
+  TRICO_HIP_TRY(hipMemcpyAsync(ctx->h_pinned, d_words, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, current_stream()));
+  TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
+  memcpy(host, ctx->h_pinned, sizeof(uint32_t) * count);
+  return 1;
+  }
+
+} // namespace trico
+
+using namespace trico;
+
+extern "C" {
+
+int trico_hip_available(void) { return device_ready() ? 1 : 0; }
+
+const char* trico_hip_last_error(void) { return g_err; }
+
+trico_hip_ctx* trico_hip_ctx_create(void)
+  {
+  if (!device_ready())
+    return nullptr;
+  trico_hip_ctx* ctx = new (std::nothrow) trico_hip_ctx();
+  if (!ctx)
+    return nullptr;
+  void* hp = nullptr;
+  if (!hip_ok(hipHostMalloc(&hp, 64 * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc") ||
+      !ctx->aux.reserve(1 << 16))
+    {
+    if (hp) (void)hipHostFree(hp);
+    delete ctx;
+    return nullptr;
+    }
+  ctx->h_pinned = (uint32_t*)hp;
+  return ctx;
+  }
+
+void trico_hip_ctx_destroy(trico_hip_ctx* ctx)
+  {
+  if (!ctx)
+    return;
+  (void)hipStreamSynchronize(current_stream());
+  ctx->in.release();
+  ctx->out.release();
+  ctx->tmp.release();
+  ctx->aux.release();
+  if (ctx->h_pinned)
+    (void)hipHostFree(ctx->h_pinned);
+  delete ctx;
+  }
+
+void trico_hip_set_stream(void* hip_stream) { g_stream = (hipStream_t)hip_stream; }
+
+int trico_hip_synchronize(void)
+  {
+  if (!device_ready())
+    return 0;
+  TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
+  return 1;
+  }
+
+int trico_hip_pointer_is_device(const void* p)
+  {
+  if (!p || g_device_state < 0)
+    return 0;
+  if (!device_ready())
+    return 0;
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess)
+    {
+    (void)hipGetLastError();
+    return 0;
+    }
+  return attr.type == hipMemoryTypeDevice ? 1 : 0;
+  }
+
+void* trico_hip_device_alloc(size_t bytes)
+  {
+  if (!device_ready())
+    return nullptr;
+  void* p = nullptr;
+  if (!hip_ok(hipMalloc(&p, bytes ? bytes : 1), "hipMalloc"))
+    return nullptr;
+  return p;
+  }
+
+void trico_hip_device_free(void* p)
+  {
+  if (p)
+    (void)hipFree(p);
+  }
+
+int trico_hip_copy(void* dst, const void* src, size_t bytes)
+  {
+  if (bytes == 0)
+    return 1;
+  if (!device_ready())
+    return 0;
+  TRICO_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, current_stream()));
+  TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
+  return 1;
+  }
+
+// ---- floating point -----------------------------------------------------------------------------
+
+int trico_hip_fpc_encode(trico_hip_ctx* ctx, const void* src, uint32_t n, int arity, int width, uint32_t sizes[3])
+  {
+  if (!ctx || !device_ready())
+    return 0;
+  if (arity < 1 || arity > 3 || (width != 4 && width != 8) || (n != 0 && !src))
+    {
+    set_error("trico_hip_fpc_encode: bad arguments");
+    return 0;
+    }
+  const size_t in_bytes = (size_t)n * arity * width;
+  const size_t stride = align_up(fpc_bound(n, width), 256);
+  if (!ctx->in.reserve(in_bytes + 16) || !ctx->out.reserve(stride * arity))
+    return 0;
+  ctx->out_stride = stride;
+  ctx->out_count = 0;
+  const void* d_src = n ? stage_in(ctx->in, src, in_bytes) : ctx->in.p;
+  if (!d_src)
+    return 0;
+  uint32_t* d_sizes = (uint32_t*)ctx->aux.p;
+  {
+  ProfSpan span(width == 4 ? TRICO_HIP_K_FPC32_ENCODE : TRICO_HIP_K_FPC64_ENCODE);
+  uint64_t* d_tables = nullptr;
+  if (width == 8)
+    {
+    // two 2^20-entry u64 tables per component (fpsc.c:592-593), zeroed per call
+    const size_t tb = (size_t)arity * 2 * ((size_t)1 << 20) * 8;
+    if (!ctx->tmp.reserve(tb))
+      return 0;
+    TRICO_HIP_TRY(hipMemsetAsync(ctx->tmp.p, 0, tb, current_stream()));
+    d_tables = (uint64_t*)ctx->tmp.p;
+    }
+  if (!launch_fpc_encode_serial(d_src, n, arity, width, ctx->out.p, stride, d_sizes, d_tables))
+    return 0;
+  }
+  if (!read_back_words(ctx, d_sizes, arity, ctx->out_sizes))
+    return 0;
+  ctx->out_count = arity;
+  for (int c = 0; c < arity; ++c)
+    sizes[c] = ctx->out_sizes[c];
+  return 1;
+  }
+
+int trico_hip_fpc_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[3], const uint32_t sizes[3],
+                         int arity, int width, uint32_t n, void* dst)
+  {
+  if (!ctx || !device_ready())
+    return 0;
+  if (arity < 1 || arity > 3 || (width != 4 && width != 8))
+    {
+    set_error("trico_hip_fpc_decode: bad arguments");
+    return 0;
+    }
+  if (!dst)
+    return 1;
+  // stage host payloads back to back (256-byte aligned) in ctx->in
+  size_t total = 0, offs[3] = { 0, 0, 0 };
+  for (int c = 0; c < arity; ++c)
+    {
+    if (sizes[c] < 5 || !payloads[c])
+      {
+      set_error("trico_hip_fpc_decode: payload too short");
+      return 0;
+      }
+    offs[c] = total;
+    total += align_up((size_t)sizes[c] + 16, 256);
+    }
+  const uint8_t* d_pay[3] = { nullptr, nullptr, nullptr };
+  bool any_host = false;
+  for (int c = 0; c < arity; ++c)
+    any_host |= !trico_hip_pointer_is_device(payloads[c]);
+  if (any_host && !ctx->in.reserve(total))
+    return 0;
+  for (int c = 0; c < arity; ++c)
+    {
+    d_pay[c] = (const uint8_t*)stage_in(ctx->in, payloads[c], sizes[c], offs[c]);
+    if (!d_pay[c])
+      return 0;
+    }
+  const size_t out_bytes = (size_t)n * arity * width;
+  const bool dst_dev = trico_hip_pointer_is_device(dst) != 0;
+  void* d_dst = dst;
+  if (!dst_dev)
+    {
+    if (!ctx->out.reserve(out_bytes + 16))
+      return 0;
+    ctx->out_count = 0;
+    d_dst = ctx->out.p;
+    }
+  uint32_t* d_status = (uint32_t*)ctx->aux.p;
+  TRICO_HIP_TRY(hipMemsetAsync(d_status, 0, 64, current_stream()));
+  {
+  ProfSpan span(width == 4 ? TRICO_HIP_K_FPC32_DECODE : TRICO_HIP_K_FPC64_DECODE);
+  uint64_t* d_tables = nullptr;
+  if (width == 8)
+    {
+    // table sizes come from the payload's hash_info byte; the archive API always writes (20,20).
+    const size_t tb = (size_t)arity * 2 * ((size_t)1 << 20) * 8;
+    if (!ctx->tmp.reserve(tb))
+      return 0;
+    TRICO_HIP_TRY(hipMemsetAsync(ctx->tmp.p, 0, tb, current_stream()));
+    d_tables = (uint64_t*)ctx->tmp.p;
+    }
+  if (!launch_fpc_decode_serial(d_pay, sizes, arity, width, n, d_dst, d_tables, d_status))
+    return 0;
+  }
+  uint32_t status = 0;
+  if (!read_back_words(ctx, d_status, 1, &status))
+    return 0;
+  if (status != 0)
+    {
+    set_error("trico_hip_fpc_decode: malformed payload");
+    return 0;
+    }
+  if (!dst_dev && out_bytes)
+    {
+    TRICO_HIP_TRY(hipMemcpyAsync(dst, d_dst, out_bytes, hipMemcpyDeviceToHost, current_stream()));
+    TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
+    }
+  return 1;
+  }
+
+// ---- integers -----------------------------------------------------------------------------------
+
+int trico_hip_int_encode(trico_hip_ctx* ctx, const void* src, uint32_t count, int width, uint32_t sizes[8])
+  {
+  if (!ctx || !device_ready())
+    return 0;
+  if ((width != 1 && width != 2 && width != 4 && width != 8) || (count != 0 && !src) || count > 0x7E000000u)
+    {
+    set_error("trico_hip_int_encode: bad arguments");
+    return 0;
+    }
+  const size_t in_bytes = (size_t)count * width;
+  const size_t stride = align_up(lz4_bound(count), 256);
+  const size_t plane_stride = align_up((size_t)count + 16, 256);
+  if (!ctx->in.reserve(in_bytes + 16) || !ctx->out.reserve(stride * width) || !ctx->tmp.reserve(plane_stride * width))
+    return 0;
+  ctx->out_stride = stride;
+  ctx->out_count = 0;
+  const void* d_src = count ? stage_in(ctx->in, src, in_bytes) : ctx->in.p;
+  if (!d_src)
+    return 0;
+  const uint8_t* d_planes = (const uint8_t*)d_src;
+  if (width > 1)
+    {
+    ProfSpan span(TRICO_HIP_K_PLANES_SPLIT);
+    if (!launch_planes_split(d_src, count, width, ctx->tmp.p, plane_stride))
+      return 0;
+    d_planes = ctx->tmp.p;
+    }
+  uint32_t* d_sizes = (uint32_t*)ctx->aux.p;
+  {
+  ProfSpan span(TRICO_HIP_K_LZ4_ENCODE);
+  if (!launch_lz4_encode_serial(d_planes, plane_stride, count, width, ctx->out.p, stride, d_sizes))
+    return 0;
+  }
+  if (!read_back_words(ctx, d_sizes, width, ctx->out_sizes))
+    return 0;
+  ctx->out_count = width;
+  for (int c = 0; c < width; ++c)
+    sizes[c] = ctx->out_sizes[c];
+  return 1;
+  }
+
+int trico_hip_int_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[8], const uint32_t sizes[8],
+                         int width, uint32_t count, void* dst)
+  {
+  if (!ctx || !device_ready())
+    return 0;
+  if (width != 1 && width != 2 && width != 4 && width != 8)
+    {
+    set_error("trico_hip_int_decode: bad arguments");
+    return 0;
+    }
+  if (!dst)
+    return 1;
+  size_t total = 0, offs[8];
+  bool any_host = false;
+  for (int c = 0; c < width; ++c)
+    {
+    if (sizes[c] < 1 || !payloads[c])
+      {
+      set_error("trico_hip_int_decode: empty payload");
+      return 0;
+      }
+    offs[c] = total;
+    total += align_up((size_t)sizes[c] + 16, 256);
+    any_host |= !trico_hip_pointer_is_device(payloads[c]);
+    }
+  if (any_host && !ctx->in.reserve(total))
+    return 0;
+  const uint8_t* d_pay[8];
+  for (int c = 0; c < width; ++c)
+    {
+    d_pay[c] = (const uint8_t*)stage_in(ctx->in, payloads[c], sizes[c], offs[c]);
+    if (!d_pay[c])
+      return 0;
+    }
+  const size_t out_bytes = (size_t)count * width;
+  const bool dst_dev = trico_hip_pointer_is_device(dst) != 0;
+  void* d_dst = dst;
+  if (!dst_dev)
+    {
+    if (!ctx->out.reserve(out_bytes + 16))
+      return 0;
+    ctx->out_count = 0;
+    d_dst = ctx->out.p;
+    }
+  uint8_t* d_planes = (uint8_t*)d_dst;
+  const size_t plane_stride = align_up((size_t)count + 16, 256);
+  if (width > 1)
+    {
+    if (!ctx->tmp.reserve(plane_stride * width))
+      return 0;
+    d_planes = ctx->tmp.p;
+    }
+  uint32_t* d_status = (uint32_t*)ctx->aux.p;
+  TRICO_HIP_TRY(hipMemsetAsync(d_status, 0, 64, current_stream()));
+  {
+  ProfSpan span(TRICO_HIP_K_LZ4_DECODE);
+  if (!launch_lz4_decode_serial(d_pay, sizes, width, d_planes, plane_stride, count, d_status))
+    return 0;
+  }
+  if (width > 1)
+    {
+    ProfSpan span(TRICO_HIP_K_PLANES_MERGE);
+    if (!launch_planes_merge(d_planes, plane_stride, count, width, d_dst))
+      return 0;
+    }
+  uint32_t status = 0;
+  if (!read_back_words(ctx, d_status, 1, &status))
+    return 0;
+  if (status != 0)
+    {
+    set_error("trico_hip_int_decode: malformed LZ4 block");
+    return 0;
+    }
+  if (!dst_dev && out_bytes)
+    {
+    TRICO_HIP_TRY(hipMemcpyAsync(dst, d_dst, out_bytes, hipMemcpyDeviceToHost, current_stream()));
+    TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
+    }
+  return 1;
+  }
+
+int trico_hip_fetch_payload(trico_hip_ctx* ctx, int c, void* dst)
+  {
+  if (!ctx || c < 0 || c >= ctx->out_count)
+    {
+    set_error("trico_hip_fetch_payload: no such payload");
+    return 0;
+    }
+  return trico_hip_copy(dst, ctx->out.p + (size_t)c * ctx->out_stride, ctx->out_sizes[c]);
+  }
+
+const uint8_t* trico_hip_payload_device_pointer(trico_hip_ctx* ctx, int c)
+  {
+  if (!ctx || c < 0 || c >= ctx->out_count)
+    return nullptr;
+  return ctx->out.p + (size_t)c * ctx->out_stride;
+  }
+
+// ---- profiling ----------------------------------------------------------------------------------
+
+void trico_hip_profile_enable(int on) { g_prof_on = on != 0; }
+
+void trico_hip_profile_reset(void)
+  {
+  prof_drain();
+  for (int k = 0; k < TRICO_HIP_K_COUNT; ++k)
+    {
+    g_prof_ms[k] = 0.0;
+    g_prof_spans[k] = 0;
+    }
+  }
+
+double trico_hip_profile_ms(int k, uint64_t* spans)
+  {
+  if (k < 0 || k >= TRICO_HIP_K_COUNT)
+    return 0.0;
+  prof_drain();
+  if (spans)
+    *spans = g_prof_spans[k];
+  return g_prof_ms[k];
+  }
+
+} // extern "C"

@@ -1,0 +1,555 @@
+/*
+ * archive.c — host side of the drop-in boundary: the .trc container (framing, archive handle,
+ * peeks, skip) behind the reference's 54-function C API, in plain C11.
+ *
+ * Reference behaviour restated (not copied) from trico/trico.c:
+ *   archive handle + append/read primitives  trico.c:12-88
+ *   header "Trco" + version                  trico.c:90-124
+ *   open/close/accessors                     trico.c:126-213
+ *   stream writers                           trico.c:215-858
+ *   count peeks                              trico.c:860-941
+ *   stream readers + skip                    trico.c:943-1698
+ * The reference's ~40 hand-unrolled writers/readers collapse here into four generic routines
+ * (fp / integer x write / read); all compression work is delegated to the HIP shim
+ * (include/trico/trico_hip.h).  There is no CPU compression path in this library.
+ *
+ * Deliberate divergences from the reference (SURVEY.md §8 "quirks"):
+ *   - buffer growth is geometric instead of exact-fit (same bytes, fewer reallocs);
+ *   - a failing writer writes nothing, a failing reader consumes nothing;
+ *   - compressed payloads are decoded in place from the borrowed archive bytes (no malloc+memcpy);
+ *   - trico_read_attributes_uint8 writes into *attrib (the reference's (char*)attrib is a bug);
+ *   - double uv readers accept tags 6/8 per the enum while the writers emit 5/7 like the reference;
+ *   - the next-stream tag is read into a byte, integers are little-endian by construction.
+ */
+#include "trico/trico.h"
+#include "trico/trico_hip.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+struct trico_archive
+  {
+  /* write side */
+  uint8_t* buffer;
+  uint64_t buffer_size;
+  uint64_t used;
+  int buffer_on_device;
+  /* read side (borrowed) */
+  const uint8_t* data;
+  uint64_t data_size;
+  uint64_t pos;
+  int data_on_device;
+
+  uint32_t version;
+  uint8_t next_stream_type;
+  int writable;
+  trico_hip_ctx* ctx;   /* created on first use */
+  };
+
+#define TRICO_MAGIC 0x6f637254u   /* "Trco", trico.c:94 */
+
+static trico_hip_ctx* arch_ctx(struct trico_archive* a)
+  {
+  if (!a->ctx)
+    a->ctx = trico_hip_ctx_create();
+  return a->ctx;
+  }
+
+/* ---- write primitives (trico.c:26-63) ---------------------------------------------------- */
+
+static int reserve(struct trico_archive* a, uint64_t extra)
+  {
+  if (!a->writable)
+    return 0;
+  if (a->buffer_size - a->used >= extra)
+    return 1;
+  uint64_t want = a->used + extra;
+  uint64_t cap = a->buffer_size + a->buffer_size / 2;
+  if (cap < want)
+    cap = want;
+  if (a->buffer_on_device)
+    {
+    uint8_t* nb = (uint8_t*)trico_hip_device_alloc(cap);
+    if (!nb)
+      return 0;
+    if (a->used && !trico_hip_copy(nb, a->buffer, a->used))
+      {
+      trico_hip_device_free(nb);
+      return 0;
+      }
+    trico_hip_device_free(a->buffer);
+    a->buffer = nb;
+    }
+  else
+    {
+    uint8_t* nb = (uint8_t*)realloc(a->buffer, cap ? cap : 1);
+    if (!nb)
+      return 0;
+    a->buffer = nb;
+    }
+  a->buffer_size = cap;
+  return 1;
+  }
+
+/* append small host-resident fields; space must have been reserved */
+static int put_host(struct trico_archive* a, const void* p, uint64_t n)
+  {
+  if (a->buffer_on_device)
+    {
+    if (!trico_hip_copy(a->buffer + a->used, p, n))
+      return 0;
+    }
+  else
+    memcpy(a->buffer + a->used, p, n);
+  a->used += n;
+  return 1;
+  }
+
+static void store_le32(uint8_t* p, uint32_t v)
+  {
+  p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
+  }
+
+static uint32_t load_le32(const uint8_t* p)
+  {
+  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+  }
+
+/* ---- read primitives (trico.c:65-124) ---------------------------------------------------- */
+
+static int peek_bytes(struct trico_archive* a, void* dst, uint64_t n)
+  {
+  if (a->writable)
+    return 0;
+  if (a->pos + n > a->data_size)
+    return 0;
+  if (a->data_on_device)
+    return trico_hip_copy(dst, a->data + a->pos, n);
+  memcpy(dst, a->data + a->pos, n);
+  return 1;
+  }
+
+static int read_u32(struct trico_archive* a, uint32_t* v)
+  {
+  uint8_t b[4];
+  if (!peek_bytes(a, b, 4))
+    return 0;
+  a->pos += 4;
+  *v = load_le32(b);
+  return 1;
+  }
+
+static void read_next_stream_type(struct trico_archive* a)
+  {
+  uint8_t t = 0;
+  if (a->pos < a->data_size && peek_bytes(a, &t, 1))
+    {
+    a->pos += 1;
+    a->next_stream_type = t;
+    }
+  else
+    a->next_stream_type = (uint8_t)trico_empty;
+  }
+
+/* ---- open / close / accessors ------------------------------------------------------------ */
+
+static struct trico_archive* new_archive(void)
+  {
+  return (struct trico_archive*)calloc(1, sizeof(struct trico_archive));
+  }
+
+static void* open_for_writing(uint64_t initial_buffer_size, int on_device)
+  {
+  struct trico_archive* a = new_archive();
+  if (!a)
+    return NULL;
+  a->writable = 1;
+  a->buffer_on_device = on_device;
+  if (on_device)
+    a->buffer = (uint8_t*)trico_hip_device_alloc(initial_buffer_size ? initial_buffer_size : 8);
+  else
+    a->buffer = (uint8_t*)malloc(initial_buffer_size ? initial_buffer_size : 1);
+  if (!a->buffer)
+    {
+    free(a);
+    return NULL;
+    }
+  a->buffer_size = initial_buffer_size ? initial_buffer_size : (on_device ? 8 : 1);
+  uint8_t hdr[8];
+  store_le32(hdr, TRICO_MAGIC);
+  store_le32(hdr + 4, a->version);
+  if (!reserve(a, 8) || !put_host(a, hdr, 8))
+    {
+    trico_close_archive(a);
+    return NULL;
+    }
+  return a;
+  }
+
+void* trico_open_archive_for_writing(uint64_t initial_buffer_size)
+  {
+  return open_for_writing(initial_buffer_size, 0);
+  }
+
+void* trico_hip_open_archive_for_writing_device(uint64_t initial_buffer_size)
+  {
+  if (!trico_hip_available())
+    return NULL;
+  return open_for_writing(initial_buffer_size, 1);
+  }
+
+void* trico_open_archive_for_reading(const uint8_t* data, uint64_t data_size)
+  {
+  struct trico_archive* a = new_archive();
+  if (!a)
+    return NULL;
+  a->data = data;
+  a->data_size = data_size;
+  a->data_on_device = (data != NULL && data_size != 0) ? trico_hip_pointer_is_device(data) : 0;
+  uint8_t hdr[8];
+  if (data == NULL || !peek_bytes(a, hdr, 8) || load_le32(hdr) != TRICO_MAGIC)
+    {
+    free(a);
+    return NULL;
+    }
+  a->pos = 8;
+  a->version = load_le32(hdr + 4);
+  read_next_stream_type(a);
+  return a;
+  }
+
+void trico_close_archive(void* archive)
+  {
+  struct trico_archive* a = (struct trico_archive*)archive;
+  if (!a)
+    return;
+  if (a->buffer)
+    {
+    if (a->buffer_on_device)
+      trico_hip_device_free(a->buffer);
+    else
+      free(a->buffer);
+    }
+  if (a->ctx)
+    trico_hip_ctx_destroy(a->ctx);
+  free(a);
+  }
+
+uint8_t* trico_get_buffer_pointer(void* archive)
+  {
+  return ((struct trico_archive*)archive)->buffer;
+  }
+
+uint64_t trico_get_size(void* archive)
+  {
+  return ((struct trico_archive*)archive)->used;
+  }
+
+uint32_t trico_get_version(void* archive)
+  {
+  return ((struct trico_archive*)archive)->version;
+  }
+
+enum trico_stream_type trico_get_next_stream_type(void* archive)
+  {
+  return (enum trico_stream_type)((struct trico_archive*)archive)->next_stream_type;
+  }
+
+/* ---- generic stream writers ---------------------------------------------------------------
+ * stream := u8 type, u32 count, then per component: u32 nbytes, payload  (trico.c:215-262 etc.) */
+
+static int append_stream(struct trico_archive* a, enum trico_stream_type st, uint32_t count_field,
+                         int ncomp, const uint32_t* sizes)
+  {
+  uint64_t total = 5;
+  for (int c = 0; c < ncomp; ++c)
+    total += 4 + (uint64_t)sizes[c];
+  if (!reserve(a, total))
+    return 0;
+  const uint64_t rollback = a->used;
+  uint8_t head[5];
+  head[0] = (uint8_t)st;
+  store_le32(head + 1, count_field);
+  if (!put_host(a, head, 5))
+    {
+    a->used = rollback;
+    return 0;
+    }
+  for (int c = 0; c < ncomp; ++c)
+    {
+    uint8_t nb[4];
+    store_le32(nb, sizes[c]);
+    if (!put_host(a, nb, 4) || !trico_hip_fetch_payload(a->ctx, c, a->buffer + a->used))
+      {
+      a->used = rollback;
+      return 0;
+      }
+    a->used += sizes[c];
+    }
+  return 1;
+  }
+
+static int write_fp_stream(void* archive, enum trico_stream_type st, uint32_t count_field,
+                           const void* data, uint32_t n, int arity, int width)
+  {
+  struct trico_archive* a = (struct trico_archive*)archive;
+  if (!a || !a->writable || !arch_ctx(a))
+    return 0;
+  uint32_t sizes[3] = { 0, 0, 0 };
+  if (!trico_hip_fpc_encode(a->ctx, data, n, arity, width, sizes))
+    return 0;
+  return append_stream(a, st, count_field, arity, sizes);
+  }
+
+static int write_int_stream(void* archive, enum trico_stream_type st, uint32_t count_field,
+                            const void* data, uint32_t n, int width)
+  {
+  struct trico_archive* a = (struct trico_archive*)archive;
+  if (!a || !a->writable || !arch_ctx(a))
+    return 0;
+  uint32_t sizes[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  if (!trico_hip_int_encode(a->ctx, data, n, width, sizes))
+    return 0;
+  return append_stream(a, st, count_field, width, sizes);
+  }
+
+/* vec3 float / double (trico.c:215-277, 380-442) */
+int trico_write_vertices(void* a, const float* v, uint32_t n)
+  { return write_fp_stream(a, trico_vertex_float_stream, n, v, n, 3, 4); }
+int trico_write_vertex_normals(void* a, const float* v, uint32_t n)
+  { return write_fp_stream(a, trico_vertex_normal_float_stream, n, v, n, 3, 4); }
+int trico_write_triangle_normals(void* a, const float* v, uint32_t n)
+  { return write_fp_stream(a, trico_triangle_normal_float_stream, n, v, n, 3, 4); }
+int trico_write_vertices_double(void* a, const double* v, uint32_t n)
+  { return write_fp_stream(a, trico_vertex_double_stream, n, v, n, 3, 8); }
+int trico_write_vertex_normals_double(void* a, const double* v, uint32_t n)
+  { return write_fp_stream(a, trico_vertex_normal_double_stream, n, v, n, 3, 8); }
+int trico_write_triangle_normals_double(void* a, const double* v, uint32_t n)
+  { return write_fp_stream(a, trico_triangle_normal_double_stream, n, v, n, 3, 8); }
+
+/* vec2 (trico.c:534-628).  per-triangle float stores 3*nr positions (trico.c:579); the double
+ * variants carry the FLOAT tags 5/7 and the unscaled count, exactly like trico.c:620-628. */
+int trico_write_uv_per_vertex(void* a, const float* uv, uint32_t n)
+  { return write_fp_stream(a, trico_uv_per_vertex_float_stream, n, uv, n, 2, 4); }
+int trico_write_uv_per_triangle(void* a, const float* uv, uint32_t n)
+  { return write_fp_stream(a, trico_uv_per_triangle_float_stream, n * 3u, uv, n * 3u, 2, 4); }
+int trico_write_uv_per_vertex_double(void* a, const double* uv, uint32_t n)
+  { return write_fp_stream(a, trico_uv_per_vertex_float_stream, n, uv, n, 2, 8); }
+int trico_write_uv_per_triangle_double(void* a, const double* uv, uint32_t n)
+  { return write_fp_stream(a, trico_uv_per_triangle_float_stream, n, uv, n, 2, 8); }
+
+/* scalar attributes (trico.c:279-321) */
+int trico_write_attributes_float(void* a, const float* p, uint32_t n)
+  { return write_fp_stream(a, trico_attribute_float_stream, n, p, n, 1, 4); }
+int trico_write_attributes_double(void* a, const double* p, uint32_t n)
+  { return write_fp_stream(a, trico_attribute_double_stream, n, p, n, 1, 8); }
+
+/* index / integer streams (trico.c:323-378, 444-532, 630-858): planes hold 3*count bytes for
+ * triangles, count bytes for colors/attributes. */
+int trico_write_triangles(void* a, const uint32_t* t, uint32_t n)
+  { return write_int_stream(a, trico_triangle_uint32_stream, n, t, n * 3u, 4); }
+int trico_write_triangles_long(void* a, const uint64_t* t, uint32_t n)
+  { return write_int_stream(a, trico_triangle_uint64_stream, n, t, n * 3u, 8); }
+int trico_write_vertex_colors(void* a, const uint32_t* c, uint32_t n)
+  { return write_int_stream(a, trico_vertex_color_stream, n, c, n, 4); }
+int trico_write_triangle_colors(void* a, const uint32_t* c, uint32_t n)
+  { return write_int_stream(a, trico_triangle_color_stream, n, c, n, 4); }
+int trico_write_attributes_uint8(void* a, const uint8_t* p, uint32_t n)
+  { return write_int_stream(a, trico_attribute_uint8_stream, n, p, n, 1); }
+int trico_write_attributes_uint16(void* a, const uint16_t* p, uint32_t n)
+  { return write_int_stream(a, trico_attribute_uint16_stream, n, p, n, 2); }
+int trico_write_attributes_uint32(void* a, const uint32_t* p, uint32_t n)
+  { return write_int_stream(a, trico_attribute_uint32_stream, n, p, n, 4); }
+int trico_write_attributes_uint64(void* a, const uint64_t* p, uint32_t n)
+  { return write_int_stream(a, trico_attribute_uint64_stream, n, p, n, 8); }
+
+/* ---- count peeks (trico.c:860-941) --------------------------------------------------------- */
+
+static uint32_t peek_count(void* archive, uint32_t type_mask)
+  {
+  struct trico_archive* a = (struct trico_archive*)archive;
+  if (!a || a->writable || a->next_stream_type > 20 || !((type_mask >> a->next_stream_type) & 1u))
+    return 0;
+  uint8_t b[4];
+  if (!peek_bytes(a, b, 4))
+    return 0;
+  return load_le32(b);
+  }
+
+#define TM(t) (1u << (t))
+
+uint32_t trico_get_number_of_vertices(void* a)
+  { return peek_count(a, TM(trico_vertex_float_stream) | TM(trico_vertex_double_stream)); }
+uint32_t trico_get_number_of_triangles(void* a)
+  { return peek_count(a, TM(trico_triangle_uint32_stream) | TM(trico_triangle_uint64_stream)); }
+uint32_t trico_get_number_of_uvs(void* a)
+  { return peek_count(a, TM(trico_uv_per_vertex_float_stream) | TM(trico_uv_per_vertex_double_stream) |
+                         TM(trico_uv_per_triangle_float_stream) | TM(trico_uv_per_triangle_double_stream)); }
+uint32_t trico_get_number_of_normals(void* a)
+  { return peek_count(a, TM(trico_vertex_normal_float_stream) | TM(trico_vertex_normal_double_stream) |
+                         TM(trico_triangle_normal_float_stream) | TM(trico_triangle_normal_double_stream)); }
+uint32_t trico_get_number_of_colors(void* a)
+  { return peek_count(a, TM(trico_vertex_color_stream) | TM(trico_triangle_color_stream)); }
+uint32_t trico_get_number_of_attributes(void* a)
+  { return peek_count(a, TM(trico_attribute_float_stream) | TM(trico_attribute_double_stream) |
+                         TM(trico_attribute_uint8_stream) | TM(trico_attribute_uint16_stream) |
+                         TM(trico_attribute_uint32_stream) | TM(trico_attribute_uint64_stream)); }
+
+/* ---- generic stream readers (trico.c:943-1668) -------------------------------------------- */
+
+/* Parses count + ncomp (nbytes, payload) frames at the cursor without consuming them. */
+static int parse_frames(struct trico_archive* a, int ncomp, uint32_t* count, const uint8_t** payloads,
+                        uint32_t* sizes, uint64_t* end_pos)
+  {
+  const uint64_t start = a->pos;
+  int ok = read_u32(a, count);
+  for (int c = 0; ok && c < ncomp; ++c)
+    {
+    ok = read_u32(a, &sizes[c]);
+    if (ok && a->pos + sizes[c] > a->data_size)
+      ok = 0;
+    if (ok)
+      {
+      payloads[c] = a->data + a->pos;
+      a->pos += sizes[c];
+      }
+    }
+  *end_pos = a->pos;
+  a->pos = start;
+  return ok;
+  }
+
+/* lib_alloc: the library mallocs *dst (trico_read_attributes_float/double, trico.c:1377,1408) */
+static int read_fp_stream(void* archive, enum trico_stream_type st, void** dst, int arity, int width, int lib_alloc)
+  {
+  struct trico_archive* a = (struct trico_archive*)archive;
+  if (!a || a->writable || a->next_stream_type != (uint8_t)st)
+    return 0;
+  uint32_t count = 0, sizes[3] = { 0, 0, 0 };
+  const uint8_t* payloads[3] = { NULL, NULL, NULL };
+  uint64_t end_pos = 0;
+  if (!parse_frames(a, arity, &count, payloads, sizes, &end_pos))
+    return 0;
+  if (dst != NULL)
+    {
+    if (!arch_ctx(a))
+      return 0;
+    void* out = *dst;
+    if (lib_alloc)
+      {
+      out = malloc((size_t)count * (size_t)width + 1);
+      if (!out)
+        return 0;
+      }
+    if (!trico_hip_fpc_decode(a->ctx, payloads, sizes, arity, width, count, out))
+      {
+      if (lib_alloc)
+        free(out);
+      return 0;
+      }
+    if (lib_alloc)
+      *dst = out;
+    }
+  a->pos = end_pos;
+  read_next_stream_type(a);
+  return 1;
+  }
+
+static int read_int_stream(void* archive, enum trico_stream_type st, void** dst, int width, uint32_t per_count)
+  {
+  struct trico_archive* a = (struct trico_archive*)archive;
+  if (!a || a->writable || a->next_stream_type != (uint8_t)st)
+    return 0;
+  uint32_t count = 0, sizes[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  const uint8_t* payloads[8] = { NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL };
+  uint64_t end_pos = 0;
+  if (!parse_frames(a, width, &count, payloads, sizes, &end_pos))
+    return 0;
+  if ((uint64_t)count * per_count > 0xffffffffull)
+    return 0;
+  if (dst != NULL)
+    {
+    if (!arch_ctx(a))
+      return 0;
+    if (!trico_hip_int_decode(a->ctx, payloads, sizes, width, count * per_count, *dst))
+      return 0;
+    }
+  a->pos = end_pos;
+  read_next_stream_type(a);
+  return 1;
+  }
+
+int trico_read_vertices(void* a, float** v)
+  { return read_fp_stream(a, trico_vertex_float_stream, (void**)v, 3, 4, 0); }
+int trico_read_vertex_normals(void* a, float** v)
+  { return read_fp_stream(a, trico_vertex_normal_float_stream, (void**)v, 3, 4, 0); }
+int trico_read_triangle_normals(void* a, float** v)
+  { return read_fp_stream(a, trico_triangle_normal_float_stream, (void**)v, 3, 4, 0); }
+int trico_read_vertices_double(void* a, double** v)
+  { return read_fp_stream(a, trico_vertex_double_stream, (void**)v, 3, 8, 0); }
+int trico_read_vertex_normals_double(void* a, double** v)
+  { return read_fp_stream(a, trico_vertex_normal_double_stream, (void**)v, 3, 8, 0); }
+int trico_read_triangle_normals_double(void* a, double** v)
+  { return read_fp_stream(a, trico_triangle_normal_double_stream, (void**)v, 3, 8, 0); }
+int trico_read_uv_per_vertex(void* a, float** uv)
+  { return read_fp_stream(a, trico_uv_per_vertex_float_stream, (void**)uv, 2, 4, 0); }
+int trico_read_uv_per_triangle(void* a, float** uv)
+  { return read_fp_stream(a, trico_uv_per_triangle_float_stream, (void**)uv, 2, 4, 0); }
+int trico_read_uv_per_vertex_double(void* a, double** uv)
+  { return read_fp_stream(a, trico_uv_per_vertex_double_stream, (void**)uv, 2, 8, 0); }
+int trico_read_uv_per_triangle_double(void* a, double** uv)
+  { return read_fp_stream(a, trico_uv_per_triangle_double_stream, (void**)uv, 2, 8, 0); }
+int trico_read_attributes_float(void* a, float** p)
+  { return read_fp_stream(a, trico_attribute_float_stream, (void**)p, 1, 4, 1); }
+int trico_read_attributes_double(void* a, double** p)
+  { return read_fp_stream(a, trico_attribute_double_stream, (void**)p, 1, 8, 1); }
+
+int trico_read_triangles(void* a, uint32_t** t)
+  { return read_int_stream(a, trico_triangle_uint32_stream, (void**)t, 4, 3); }
+int trico_read_triangles_long(void* a, uint64_t** t)
+  { return read_int_stream(a, trico_triangle_uint64_stream, (void**)t, 8, 3); }
+int trico_read_vertex_colors(void* a, uint32_t** c)
+  { return read_int_stream(a, trico_vertex_color_stream, (void**)c, 4, 1); }
+int trico_read_triangle_colors(void* a, uint32_t** c)
+  { return read_int_stream(a, trico_triangle_color_stream, (void**)c, 4, 1); }
+int trico_read_attributes_uint8(void* a, uint8_t** p)
+  { return read_int_stream(a, trico_attribute_uint8_stream, (void**)p, 1, 1); }
+int trico_read_attributes_uint16(void* a, uint16_t** p)
+  { return read_int_stream(a, trico_attribute_uint16_stream, (void**)p, 2, 1); }
+int trico_read_attributes_uint32(void* a, uint32_t** p)
+  { return read_int_stream(a, trico_attribute_uint32_stream, (void**)p, 4, 1); }
+int trico_read_attributes_uint64(void* a, uint64_t** p)
+  { return read_int_stream(a, trico_attribute_uint64_stream, (void**)p, 8, 1); }
+
+/* trico.c:1670-1698 */
+int trico_skip_next_stream(void* archive)
+  {
+  struct trico_archive* a = (struct trico_archive*)archive;
+  if (!a || a->writable)
+    return 0;
+  switch ((enum trico_stream_type)a->next_stream_type)
+    {
+    case trico_empty: return 1;
+    case trico_vertex_float_stream: return trico_read_vertices(a, NULL);
+    case trico_vertex_double_stream: return trico_read_vertices_double(a, NULL);
+    case trico_triangle_uint32_stream: return trico_read_triangles(a, NULL);
+    case trico_triangle_uint64_stream: return trico_read_triangles_long(a, NULL);
+    case trico_uv_per_vertex_float_stream: return trico_read_uv_per_vertex(a, NULL);
+    case trico_uv_per_vertex_double_stream: return trico_read_uv_per_vertex_double(a, NULL);
+    case trico_uv_per_triangle_float_stream: return trico_read_uv_per_triangle(a, NULL);
+    case trico_uv_per_triangle_double_stream: return trico_read_uv_per_triangle_double(a, NULL);
+    case trico_vertex_normal_float_stream: return trico_read_vertex_normals(a, NULL);
+    case trico_vertex_normal_double_stream: return trico_read_vertex_normals_double(a, NULL);
+    case trico_triangle_normal_float_stream: return trico_read_triangle_normals(a, NULL);
+    case trico_triangle_normal_double_stream: return trico_read_triangle_normals_double(a, NULL);
+    case trico_vertex_color_stream: return trico_read_vertex_colors(a, NULL);
+    case trico_triangle_color_stream: return trico_read_triangle_colors(a, NULL);
+    case trico_attribute_float_stream: return trico_read_attributes_float(a, NULL);
+    case trico_attribute_double_stream: return trico_read_attributes_double(a, NULL);
+    case trico_attribute_uint8_stream: return trico_read_attributes_uint8(a, NULL);
+    case trico_attribute_uint16_stream: return trico_read_attributes_uint16(a, NULL);
+    case trico_attribute_uint32_stream: return trico_read_attributes_uint32(a, NULL);
+    case trico_attribute_uint64_stream: return trico_read_attributes_uint64(a, NULL);
+    }
+  return 0;
+  }
