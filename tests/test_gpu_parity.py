@@ -174,3 +174,44 @@ def test_corrupt_payload_is_rejected(api, gold_dir):
     assert r.read("vertices", out) == 0
     assert r.get_next_stream_type() == api.trico_vertex_float_stream
     r.close()
+
+
+def _fp32_data(kind, n, rng):
+    if kind == "smooth":
+        return (np.cumsum(rng.integers(-3, 4, n)) * 0.125).astype(np.float32)
+    if kind == "noisy":
+        return (np.cumsum(rng.integers(-128, 128, n)) / 1024.0).astype(np.float32)
+    if kind == "randbits":       # every class/key collides all the time, all residual lengths
+        return rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    if kind == "steps":          # long constant runs with jumps: code 0 runs + class changes
+        return np.repeat(rng.standard_normal(n // 97 + 1).astype(np.float32), 97)[:n].copy()
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("n", [1023, 1024, 1025, 2049, 4160, 65537, 250001, 1000003])
+@pytest.mark.parametrize("kind", ["smooth", "noisy", "randbits", "steps"])
+def test_fp32_segmented_encoder_vs_oracle(api, n, kind):
+    """Segment/step boundaries of the throughput encoder (k_fpc32_encode.hip) for arity 1, 2 and 3."""
+    rng = np.random.default_rng(n * 7 + len(kind))
+    a3 = _fp32_data(kind, 3 * n, rng)
+    streams = [("vertices", a3, n), ("uv_per_vertex", a3[: 2 * n].copy(), n), ("attributes_float", a3[:n].copy(), n)]
+    got = write_archive(api, streams)
+    assert got == oracle_archive(streams)
+    if n <= 70000:
+        read_back(api, got, streams)
+
+
+@pytest.mark.parametrize("kind", ["grid", "walk"])
+def test_config1_vertices(api, kind, hashes):
+    """BASELINE config 1 vertex stream (1M float vertices): payload sizes must match the reference's."""
+    streams = mesh_streams(kind, 1000, 1000)[:1]
+    got = write_archive(api, streams)
+    assert got == oracle_archive(streams)
+    want_sizes = hashes["%s_1000x1000" % kind]["streams"][0][2]
+    import struct
+    pos, sizes = 8 + 5, []
+    for _ in range(3):
+        nb = struct.unpack_from("<I", got, pos)[0]
+        sizes.append(nb)
+        pos += 4 + nb
+    assert sizes == want_sizes

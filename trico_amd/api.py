@@ -73,8 +73,15 @@ def lib():
         raise RuntimeError(
             "libtrico.so not built: run `python -m trico_amd.build` (needs hipcc). "
             "The trico hot path has no CPU fallback.")
+    # One HIP runtime per process: torch wheels bundle their own libamdhip64.so.7.  Importing torch
+    # first makes the dynamic linker resolve libtrico.so's DT_NEEDED against that already-loaded
+    # copy (same soname), so torch tensors and libtrico share one runtime / one KFD connection.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
-    vp, u8p, u32, u64, ci = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
+    vp, u8p, u32, u64, ci =ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
     L.trico_open_archive_for_writing.restype = vp
     L.trico_open_archive_for_writing.argtypes = [u64]
     L.trico_hip_open_archive_for_writing_device.restype = vp

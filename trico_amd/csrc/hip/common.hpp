@@ -77,6 +77,12 @@ int launch_lz4_encode_serial(const uint8_t* d_planes, size_t plane_stride, uint3
 int launch_lz4_decode_serial(const uint8_t* const d_payloads[8], const uint32_t sizes[8], int nplanes,
                              uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, uint32_t* d_status);
 
+// throughput float encoder (k_fpc32_encode.hip): segmented 2-sweep scheme, see the file header
+size_t fpc32_encode_workspace(uint32_t n, int arity, uint32_t* L_out, uint32_t* S_out);
+int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
+                        uint8_t* d_ws, size_t ws_bytes);
+bool force_serial();   // TRICO_HIP_SERIAL=1: route everything through the reference-order kernels (A/B debugging)
+
 // byte-plane split / merge (k_planes.hip)
 int launch_planes_split(const void* d_src, uint32_t count, int width, uint8_t* d_planes, size_t plane_stride);
 int launch_planes_merge(const uint8_t* d_planes, size_t plane_stride, uint32_t count, int width, void* d_dst);

@@ -28,6 +28,17 @@ bool hip_ok(hipError_t e, const char* what)
 
 hipStream_t current_stream() { return g_stream; }
 
+bool force_serial()
+  {
+  static int v = -1;
+  if (v < 0)
+    {
+    const char* e = getenv("TRICO_HIP_SERIAL");
+    v = (e && e[0] == '1') ? 1 : 0;
+    }
+  return v == 1;
+  }
+
 bool DevBuf::reserve(size_t bytes)
   {
   if (bytes <= cap)
@@ -267,7 +278,16 @@ int trico_hip_fpc_encode(trico_hip_ctx* ctx, const void* src, uint32_t n, int ar
     TRICO_HIP_TRY(hipMemsetAsync(ctx->tmp.p, 0, tb, current_stream()));
     d_tables = (uint64_t*)ctx->tmp.p;
     }
-  if (!launch_fpc_encode_serial(d_src, n, arity, width, ctx->out.p, stride, d_sizes, d_tables))
+  if (width == 4 && !force_serial())
+    {
+    uint32_t L, S;
+    const size_t ws = fpc32_encode_workspace(n, arity, &L, &S);
+    if (!ctx->tmp.reserve(ws))
+      return 0;
+    if (!launch_fpc32_encode(d_src, n, arity, ctx->out.p, stride, d_sizes, ctx->tmp.p, ctx->tmp.cap))
+      return 0;
+    }
+  else if (!launch_fpc_encode_serial(d_src, n, arity, width, ctx->out.p, stride, d_sizes, d_tables))
     return 0;
   }
   if (!read_back_words(ctx, d_sizes, arity, ctx->out_sizes))
