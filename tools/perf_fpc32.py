@@ -1,0 +1,36 @@
+"""Micro-benchmark of the float-vertex encoder on device-resident input (not the driver bench)."""
+import ctypes
+import sys
+import time
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from trico_amd import api, meshgen
+
+kind = sys.argv[1] if len(sys.argv) > 1 else "grid"
+W, H = (10000, 5000) if len(sys.argv) < 4 else (int(sys.argv[2]), int(sys.argv[3]))
+L = api.lib()
+v, _ = (meshgen.grid if kind == "grid" else meshgen.walk)(W, H, triangles=False)
+n = W * H
+d = torch.from_numpy(v).cuda()
+ctx = L.trico_hip_ctx_create()
+sizes = (ctypes.c_uint32 * 3)()
+L.trico_hip_profile_enable(1)
+for it in range(6):
+    if it == 1:
+        L.trico_hip_profile_reset()
+    t0 = time.perf_counter()
+    assert L.trico_hip_fpc_encode(ctx, d.data_ptr(), n, 3, 4, sizes) == 1, api.last_error()
+    L.trico_hip_synchronize()
+    t1 = time.perf_counter()
+    print("iter", it, "wall ms %.3f" % ((t1 - t0) * 1e3), list(sizes), flush=True)
+spans = ctypes.c_uint64(0)
+ms = L.trico_hip_profile_ms(0, ctypes.byref(spans))
+per = ms / spans.value
+raw = n * 12
+comp = sum(sizes)
+print("kernel span avg %.3f ms; raw %.1f MB comp %.1f MB; input GB/s %.1f; algorithmic GB/s %.1f (%.1f%% of 8 TB/s)" % (
+    per, raw / 1e6, comp / 1e6, raw / per / 1e6, (raw + comp) / per / 1e6, (raw + comp) / per / 1e6 / 8000 * 100))
+L.trico_hip_ctx_destroy(ctx)

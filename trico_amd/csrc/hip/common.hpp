@@ -78,10 +78,20 @@ int launch_lz4_decode_serial(const uint8_t* const d_payloads[8], const uint32_t 
                              uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, uint32_t* d_status);
 
 // throughput float encoder (k_fpc32_encode.hip): segmented 2-sweep scheme, see the file header
-size_t fpc32_encode_workspace(uint32_t n, int arity, uint32_t* L_out, uint32_t* S_out);
+size_t fpc32_encode_workspace(uint32_t n, int arity);
 int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
                         uint8_t* d_ws, size_t ws_bytes);
 bool force_serial();   // TRICO_HIP_SERIAL=1: route everything through the reference-order kernels (A/B debugging)
+
+// latency-optimised float decoder (k_fpc32_decode.hip): one wave per component stream
+int launch_fpc32_decode(const uint8_t* const d_payloads[3], const uint32_t sizes[3], int arity, uint32_t n, void* d_dst,
+                        uint32_t* d_status);
+
+// wave-cooperative LZ4 (k_lz4.hip): one wave per plane, wide match counting / copies
+int launch_lz4_encode_wave(const uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, int nplanes, uint8_t* d_out,
+                           size_t out_stride, uint32_t* d_sizes);
+int launch_lz4_decode_wave(const uint8_t* const d_payloads[8], const uint32_t sizes[8], int nplanes,
+                           uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, uint32_t* d_status);
 
 // byte-plane split / merge (k_planes.hip)
 int launch_planes_split(const void* d_src, uint32_t count, int width, uint8_t* d_planes, size_t plane_stride);

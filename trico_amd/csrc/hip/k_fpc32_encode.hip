@@ -5,44 +5,54 @@
 //
 // Why this can be parallel and still bit-exact: the FCM hash of value
 // i is a pure function of v[i-1] (top 4 bits) and the DFCM hash a pure function of v[i-3..i-1], so
-// each value belongs to a *class* known from the input alone, and the reference's table read for
+// every value belongs to a *class* known from the input alone, and the reference's table read for
 // value i returns the payload (value / stride) of the latest earlier value of the same class, or 0.
 //
-// Structure: each component stream is cut into S contiguous segments of L values (L % 64 == 0).
-// One wave owns one (segment, component) and sweeps it 64 values per step with its own 16+1024
-// entry table in LDS, exactly like the reference's tables but written once per class per step:
-//   * inside a step the "latest earlier value of my class" is found with ballots over the distinct
-//     classes present (1-3 iterations on smooth data), the payload moves by ds_bpermute;
-//   * across steps it comes from the wave-private LDS table.
-// What a segment cannot know is the table content at its start.  Pass A therefore sweeps with an
-// empty table, records the few values whose class had not occurred yet in the segment (at most one
-// per class) and the segment's end-of-segment table; B1 turns the per-segment tables into incoming
-// tables with a last-writer scan across segments; B2 corrects the byte counts of the recorded values;
-// B3 prefix-sums segment sizes; pass C sweeps again with the exact incoming table and packs bytes.
+// Structure: each component stream is cut into S contiguous segments of L values (L % 64 == 0);
+// one wave owns one (segment, component) and walks it 64 values per step.
+//   sweep A  (k_fpc32_index):  classes only.  The run-end lane of every class run does an LDS
+//            ds_max of its value index into a 16+1024 entry table -> "last writer index per class"
+//            of the segment.  ~25 VALU instructions per step.
+//   scan     (k_fpc32_scan_*): prefix-max over segments per class = the table every segment starts
+//            with, as value indices (0 = never written = the reference's zeroed table).
+//   sweep C  (k_fpc32_code):   loads the incoming table (payloads gathered from the input by index),
+//            then per step: the latest earlier value of my class is the previous lane inside a run
+//            of equal classes; run starts look at the wave-private LDS table; several runs of one
+//            class inside a step are detected with a lane-id table and fixed up with ballots.
+//            Codes, residual lengths, wave prefix sums (mbcnt), 3-byte group headers (DPP or-reduce),
+//            bytes staged in an LDS ring and flushed as aligned dwords into the segment's slot.
+//   offsets  (k_fpc32_offsets): exclusive scan of the segment byte counts per component.
+//   gather   (k_fpc32_gather): slot -> final position (this is the copy the reference does with
+//            memcpy into the archive, trico.c:57-63; it can target the archive buffer directly).
 //
-// HBM traffic: 2 x raw input (pass A + C) + payload bytes + ~6 % table traffic.  No MFMA: this is
-// integer bit-twiddling bounded by HBM bandwidth; algorithmic bytes per value = 4 + payload share.
+// HBM traffic: 2 x raw input + 2 x payload bytes + ~5 % table traffic.  No MFMA: integer
+// bit-twiddling bounded by HBM bandwidth; algorithmic bytes per value = 4 + its payload share.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace trico {
 
 namespace {
 
 constexpr int TAB = 1040;      // 16 FCM entries followed by 1024 DFCM entries
-constexpr int SEENW = 33;      // presence bits for TAB classes
-constexpr int LDSW_A = TAB + 48;   // per-wave LDS words in pass A (table + seen bits, padded)
-constexpr int ROW = 1088;      // words per (segment, component) row in the global tables
-constexpr int UCAP = 1040;     // a class can be unresolved at most once per segment
+constexpr int ROW = 1040;      // words per (segment, component) row in the global index tables
 constexpr int CH = 32;         // segments per chunk in the cross-segment scan
-constexpr int RING = 1024;     // bytes of per-wave output staging ring in pass C
-constexpr int LDSW_C = TAB + RING / 4;
-
-struct UEntry { uint32_t v, a, meta, pk; };   // meta: k1 | (k2 << 4) | need1 << 16 | need2 << 17
+constexpr int RING = 1024;     // bytes of per-wave output staging ring
+constexpr int LIDW = 272;      // words of the lane-id table (1040 bytes, padded)
+constexpr int LDSW_A = TAB;                        // per-wave LDS words, sweep A
+constexpr int LDSW_C = TAB + RING / 4 + LIDW;      // per-wave LDS words, sweep C
+constexpr int PF = 8;          // steps (of 64 values) whose loads are kept in flight per wave
 
 __device__ __forceinline__ uint32_t dpp_shr1(uint32_t carry, uint32_t v)
   {
   // lane l <- lane l-1, lane 0 <- carry   (DPP wave_shr:1)
   return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)v, 0x138, 0xf, 0xf, false);
+  }
+
+__device__ __forceinline__ uint32_t dpp_shl1(uint32_t carry, uint32_t v)
+  {
+  // lane l <- lane l+1, lane 63 <- carry   (DPP wave_shl:1)
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)v, 0x130, 0xf, 0xf, false);
   }
 
 __device__ __forceinline__ uint32_t popc_below(uint64_t mask)
@@ -65,29 +75,19 @@ __device__ __forceinline__ uint32_t pick(uint32_t x1, uint32_t x2, uint32_t& len
   return use2 ? 4u + n2 : n1;
   }
 
-// For every active lane: src = nearest lower active lane with the same key (-1 if none) and
-// last = no higher active lane has this key.  Inactive lanes carry key 0xffffffff.
-__device__ __forceinline__ void wave_pred(uint32_t key, uint64_t actmask, uint64_t lt, int lane, int& src, bool& last)
+struct Carry { uint32_t m1, m2, m3; };
+
+// loads PF steps of this wave's component starting at value index i0 (0 beyond i_end)
+__device__ __forceinline__ void load_block(uint32_t (&r)[PF], const uint32_t* __restrict__ src, uint32_t i0, uint32_t i_end,
+                                           int arity, int c, int lane)
   {
-  src = -1;
-  last = false;
-  uint64_t todo = actmask;
-  while (todo)
+#pragma unroll
+  for (int pu = 0; pu < PF; ++pu)
     {
-    const int leader = __builtin_ctzll(todo);
-    const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
-    const uint64_t m = __ballot(key == k);
-    if (key == k)
-      {
-      const uint64_t lower = m & lt;
-      src = lower ? 63 - __builtin_clzll(lower) : -1;
-      last = (m >> lane) == 1ull;
-      }
-    todo &= ~m;
+    const uint32_t i = i0 + 64u * pu + lane;
+    r[pu] = (i0 < i_end && i < i_end) ? src[(size_t)i * arity + c] : 0u;
     }
   }
-
-struct Carry { uint32_t m1, m2, m3; };
 
 __device__ __forceinline__ Carry load_carry(const uint32_t* __restrict__ src, uint32_t i_begin, int arity, int c)
   {
@@ -98,13 +98,12 @@ __device__ __forceinline__ Carry load_carry(const uint32_t* __restrict__ src, ui
   return k;
   }
 
-// classes and stride of the 64 values of a step
-__device__ __forceinline__ void classes(uint32_t v, const Carry& cy, bool act, uint32_t& a, uint32_t& s, uint32_t& k1, uint32_t& k2)
+// classes of the 64 values of a step: k1 in [0,16) (FCM), k2 in [16,1040) (DFCM); a = v[i-1], b = v[i-2]
+__device__ __forceinline__ void classes(uint32_t v, const Carry& cy, bool act, uint32_t& a, uint32_t& b, uint32_t& k1, uint32_t& k2)
   {
-  a = dpp_shr1(cy.m1, v);                    // v[i-1]
-  const uint32_t b = dpp_shr1(cy.m2, a);     // v[i-2]
+  a = dpp_shr1(cy.m1, v);
+  b = dpp_shr1(cy.m2, a);
   const uint32_t d = dpp_shr1(cy.m3, b);     // v[i-3]
-  s = v - a;                                 // stride of value i
   const uint32_t s1 = a - b, s2 = b - d;     // strides of values i-1, i-2
   k1 = a >> 28;                                                    // fpsc.c:76-79 with e1 = 4
   k2 = 16u + ((((s2 >> 22) & 31u) << 5) ^ (s1 >> 22));            // fpsc.c:81-84 with e2 = 10
@@ -112,95 +111,62 @@ __device__ __forceinline__ void classes(uint32_t v, const Carry& cy, bool act, u
     k1 = k2 = 0xffffffffu;
   }
 
-// ---- pass A ------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(192) k_fpc32_pass_a(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t L, uint32_t S,
-                                                      uint32_t* __restrict__ summ, uint32_t* __restrict__ segbytes,
-                                                      uint32_t* __restrict__ ucount, UEntry* __restrict__ ulist)
+__device__ __forceinline__ void next_carry(Carry& cy, uint32_t v)
+  {
+  cy.m1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+  cy.m2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 62);
+  cy.m3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 61);
+  }
+
+// ---- sweep A: last writer index (+1) per class of every segment ---------------------------------------
+__global__ void __launch_bounds__(192) k_fpc32_index(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t L,
+                                                     uint32_t* __restrict__ summ)
   {
   extern __shared__ uint32_t lds[];
   const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t g = blockIdx.x;
   uint32_t* T = lds + c * LDSW_A;
-  uint32_t* seen = T + TAB;
-  for (int i = lane; i < LDSW_A; i += 64)
+  for (int i = lane; i < TAB; i += 64)
     T[i] = 0u;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  const uint64_t lt = (1ull << lane) - 1ull;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   const uint32_t i_begin = g * L;
   const uint32_t i_end = (n - i_begin < L) ? n : i_begin + L;
   Carry cy = load_carry(src, i_begin, arity, c);
-  uint32_t bytes = 0, ucnt = 0;
-  UEntry* ul = ulist + ((size_t)g * arity + c) * UCAP;
-  for (uint32_t i0 = i_begin; i0 < i_end; i0 += 64u)
+  uint32_t cur[PF], nxt[PF];
+  load_block(cur, src, i_begin, i_end, arity, c, lane);
+  for (uint32_t ib = i_begin; ib < i_end; ib += 64u * PF)
     {
-    const uint32_t i = i0 + lane;
-    const bool act = i < i_end;
-    const uint32_t v = act ? src[(size_t)i * arity + c] : 0u;
-    uint32_t a, s, k1, k2;
-    classes(v, cy, act, a, s, k1, k2);
-    const uint64_t actmask = __ballot(act);
-    int src1, src2;
-    bool last1, last2;
-    wave_pred(k1, actmask, lt, lane, src1, last1);
-    wave_pred(k2, actmask, lt, lane, src2, last2);
-    uint32_t p1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src1 << 2, (int)v);
-    uint32_t p2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src2 << 2, (int)s);
-    bool need1 = false, need2 = false;
-    if (act && src1 < 0)
+    load_block(nxt, src, ib + 64u * PF, i_end, arity, c, lane);
+#pragma unroll
+    for (int pu = 0; pu < PF; ++pu)
       {
-      need1 = ((seen[k1 >> 5] >> (k1 & 31u)) & 1u) == 0u;
-      p1 = need1 ? 0u : T[k1];
+      const uint32_t i0 = ib + 64u * pu;
+      if (i0 >= i_end)
+        break;
+      const uint32_t i = i0 + lane;
+      const bool act = i < i_end;
+      const uint32_t v = cur[pu];
+      uint32_t a, b, k1, k2;
+      classes(v, cy, act, a, b, k1, k2);
+      // only the last lane of a run of equal classes can be the class's last writer in this step
+      const uint32_t kn1 = dpp_shl1(0xfffffffeu, k1), kn2 = dpp_shl1(0xfffffffeu, k2);
+      if (act && k1 != kn1) atomicMax(&T[k1], i + 1u);
+      if (act && k2 != kn2) atomicMax(&T[k2], i + 1u);
+      next_carry(cy, v);
       }
-    if (act && src2 < 0)
-      {
-      need2 = ((seen[k2 >> 5] >> (k2 & 31u)) & 1u) == 0u;
-      p2 = need2 ? 0u : T[k2];
-      }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (last1) { T[k1] = v; atomicOr(&seen[k1 >> 5], 1u << (k1 & 31u)); }
-    if (last2) { T[k2] = s; atomicOr(&seen[k2 >> 5], 1u << (k2 & 31u)); }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    uint32_t len, x;
-    pick(v ^ p1, v ^ (a + p2), len, x);
-    if (!act)
-      len = (i < ((n + 7u) & ~7u) && i_end == n) ? 1u : 0u;     // tail padding slots (fpsc.c:196-204)
-    const uint32_t cnt = (i_end - i0 < 64u) ? i_end - i0 : 64u;
-    bytes += 3u * ((cnt + 7u) >> 3);
-    bytes += (uint32_t)__popcll(__ballot(len & 1u)) + 2u * (uint32_t)__popcll(__ballot(len & 2u)) + 4u * (uint32_t)__popcll(__ballot(len & 4u));
-    const bool u = need1 || need2;
-    const uint64_t um = __ballot(u);
-    if (um)
-      {
-      if (u)
-        {
-        UEntry e;
-        e.v = v;
-        e.a = a;
-        e.meta = k1 | ((k2 - 16u) << 4) | (need1 ? 1u << 16 : 0u) | (need2 ? 1u << 17 : 0u);
-        e.pk = need1 ? p2 : p1;
-        ul[ucnt + popc_below(um)] = e;
-        }
-      ucnt += (uint32_t)__popcll(um);
-      }
-    cy.m1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-    cy.m2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 62);
-    cy.m3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 61);
+#pragma unroll
+    for (int pu = 0; pu < PF; ++pu)
+      cur[pu] = nxt[pu];
     }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   uint32_t* row = summ + ((size_t)g * arity + c) * ROW;
-  for (int i = lane; i < TAB + SEENW; i += 64)
+  for (int i = lane; i < TAB; i += 64)
     row[i] = T[i];
-  if (lane == 0)
-    {
-    segbytes[(size_t)c * S + g] = bytes;
-    ucount[(size_t)g * arity + c] = ucnt;
-    }
   }
 
-// ---- B1: incoming table of segment g = payload of the last earlier segment that wrote the class ----
-// B1a: per chunk of CH segments, last written payload per class.  B1b: rewrite each chunk with the carry.
-__global__ void __launch_bounds__(256) k_fpc32_b1a(const uint32_t* __restrict__ summ, uint32_t S, int arity,
-                                                   uint32_t* __restrict__ chval, uint32_t* __restrict__ chseen)
+// ---- scan: incoming index table of segment g = max over earlier segments -----------------------------
+__global__ void __launch_bounds__(256) k_fpc32_scan_a(const uint32_t* __restrict__ summ, uint32_t S, int arity,
+                                                      uint32_t* __restrict__ chmax)
   {
   const uint32_t col = blockIdx.x * 256u + threadIdx.x;      // (component, class)
   const uint32_t ncol = (uint32_t)arity * TAB;
@@ -208,23 +174,14 @@ __global__ void __launch_bounds__(256) k_fpc32_b1a(const uint32_t* __restrict__ 
     return;
   const uint32_t c = col / TAB, k = col % TAB;
   const uint32_t g0 = blockIdx.y * CH, g1 = (g0 + CH < S) ? g0 + CH : S;
-  uint32_t val = 0, has = 0;
+  uint32_t m = 0;
   for (uint32_t g = g0; g < g1; ++g)
-    {
-    const uint32_t* row = summ + ((size_t)g * arity + c) * ROW;
-    if ((row[TAB + (k >> 5)] >> (k & 31u)) & 1u)
-      {
-      val = row[k];
-      has = 1u;
-      }
-    }
-  chval[(size_t)blockIdx.y * ncol + col] = val;
-  chseen[(size_t)blockIdx.y * ncol + col] = has;
+    m = max(m, summ[((size_t)g * arity + c) * ROW + k]);
+  chmax[(size_t)blockIdx.y * ncol + col] = m;
   }
 
-__global__ void __launch_bounds__(256) k_fpc32_b1b(const uint32_t* __restrict__ summ, uint32_t S, int arity,
-                                                   const uint32_t* __restrict__ chval, const uint32_t* __restrict__ chseen,
-                                                   uint32_t* __restrict__ inc)
+__global__ void __launch_bounds__(256) k_fpc32_scan_b(const uint32_t* __restrict__ summ, uint32_t S, int arity,
+                                                      const uint32_t* __restrict__ chmax, uint32_t* __restrict__ inc)
   {
   const uint32_t col = blockIdx.x * 256u + threadIdx.x;
   const uint32_t ncol = (uint32_t)arity * TAB;
@@ -232,57 +189,213 @@ __global__ void __launch_bounds__(256) k_fpc32_b1b(const uint32_t* __restrict__ 
     return;
   const uint32_t c = col / TAB, k = col % TAB;
   uint32_t carry = 0;
-  for (int j = (int)blockIdx.y - 1; j >= 0; --j)
-    if (chseen[(size_t)j * ncol + col])
-      {
-      carry = chval[(size_t)j * ncol + col];
-      break;
-      }
+  for (uint32_t j = 0; j < blockIdx.y; ++j)
+    carry = max(carry, chmax[(size_t)j * ncol + col]);
   const uint32_t g0 = blockIdx.y * CH, g1 = (g0 + CH < S) ? g0 + CH : S;
   for (uint32_t g = g0; g < g1; ++g)
     {
-    const size_t r = ((size_t)g * arity + c) * ROW;
-    inc[r + k] = carry;
-    if ((summ[r + TAB + (k >> 5)] >> (k & 31u)) & 1u)
-      carry = summ[r + k];
+    const size_t r = ((size_t)g * arity + c) * ROW + k;
+    inc[r] = carry;
+    carry = max(carry, summ[r]);
     }
   }
 
-// ---- B2: exact byte count of the values pass A could not resolve ------------------------------------
-__global__ void __launch_bounds__(64) k_fpc32_b2(const uint32_t* __restrict__ inc, int arity, uint32_t S,
-                                                 const uint32_t* __restrict__ ucount, const UEntry* __restrict__ ulist,
-                                                 uint32_t* __restrict__ segbytes)
+// ---- sweep C -------------------------------------------------------------------------------------------
+
+// Who wrote my class last, inside this step?  Lanes form runs of equal class.  Inside a run it is the
+// previous lane.  A run START normally has no earlier lane of its class in the step (-> LDS table);
+// if the class has several runs in this step, the nearest lower run END of that class is the answer.
+// Detection: every run end stores its lane id at LID[class]; every start/end reads it back and
+// compares with the end lane of its own run: a mismatch anywhere means the class has >= 2 runs, and
+// those classes are resolved exactly with ballots (one loop iteration per such class).
+//   src  : lane holding the latest earlier value of my class inside this step, -1 if none
+//   last : I am the last value of my class in this step (I own the table write)
+__device__ __forceinline__ void wave_pred(uint32_t key, bool act, uint8_t* __restrict__ LID, uint64_t lt, int lane,
+                                          bool& start, int& src, bool& last)
   {
-  const uint32_t gc = blockIdx.x;                 // g * arity + c
-  const uint32_t g = gc / arity, c = gc % arity;
-  const uint32_t cnt = ucount[gc];
-  if (cnt == 0)
-    return;
-  const uint32_t* row = inc + (size_t)gc * ROW;
-  const UEntry* ul = ulist + (size_t)gc * UCAP;
-  int delta = 0;
-  for (uint32_t e = threadIdx.x; e < cnt; e += 64u)
+  const uint32_t kp = dpp_shr1(0xfffffffeu, key);
+  const uint32_t kn = dpp_shl1(0xfffffffeu, key);
+  start = act && key != kp;
+  const bool end = act && key != kn;
+  const uint64_t E = __ballot(end);
+  const uint64_t up = E & ~lt;                        // run ends at or above my lane
+  const uint32_t my_end = (uint32_t)__builtin_ctzll(up | (1ull << 63));
+  if (end)
+    LID[key] = (uint8_t)lane;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  uint32_t w = my_end;
+  if (start || end)
+    w = LID[key];
+  src = start ? -1 : lane - 1;
+  last = end;
+  uint64_t todo = __ballot(act && w != my_end);
+  while (todo)                                        // classes with several runs in this step (rare)
     {
-    const UEntry u = ul[e];
-    const uint32_t k1 = u.meta & 15u, k2 = 16u + ((u.meta >> 4) & 1023u);
-    const bool need1 = (u.meta >> 16) & 1u, need2 = (u.meta >> 17) & 1u;
-    const uint32_t p1 = need1 ? row[k1] : u.pk;
-    const uint32_t p2 = need2 ? row[k2] : u.pk;
-    const uint32_t q1 = need1 ? 0u : u.pk, q2 = need2 ? 0u : u.pk;     // what pass A assumed
-    uint32_t lt, la, x;
-    pick(u.v ^ p1, u.v ^ (u.a + p2), lt, x);
-    pick(u.v ^ q1, u.v ^ (u.a + q2), la, x);
-    delta += (int)lt - (int)la;
+    const int leader = __builtin_ctzll(todo);
+    const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+    const bool mine = key == kk;
+    const uint64_t mE = __ballot(mine && end);
+    if (mine)
+      {
+      const uint64_t lower = mE & lt;
+      if (start)
+        src = lower ? 63 - __builtin_clzll(lower) : -1;
+      last = end && (mE >> lane) == 1ull;
+      }
+    todo &= ~__ballot(mine);
     }
-  for (int o = 32; o > 0; o >>= 1)
-    delta += __shfl_xor(delta, o);
-  if (threadIdx.x == 0 && delta != 0)
-    segbytes[(size_t)c * S + g] = (uint32_t)((int)segbytes[(size_t)c * S + g] + delta);
   }
 
-// ---- B3: exclusive scan of segment sizes per component (one workgroup per component) ----------------
-__global__ void __launch_bounds__(1024) k_fpc32_b3(const uint32_t* __restrict__ segbytes, uint32_t S, uint32_t* __restrict__ segoff,
-                                                   uint32_t* __restrict__ sizes)
+// store the bytes of ring word `w` (byte offset off inside the slot, multiple of 4) that lie below hi
+__device__ __forceinline__ void store_span(uint8_t* __restrict__ gbase, uint32_t off, uint32_t w, uint32_t hi)
+  {
+  if (off + 4u <= hi)
+    *(uint32_t*)(gbase + off) = w;
+  else
+    for (uint32_t bb = 0; bb < 4u; ++bb)
+      if (off + bb < hi)
+        gbase[off + bb] = (uint8_t)(w >> (8u * bb));
+  }
+
+__global__ void __launch_bounds__(192) k_fpc32_code(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t L, uint32_t S,
+                                                    const uint32_t* __restrict__ inc, uint8_t* __restrict__ slots, size_t slot_stride,
+                                                    uint32_t segcap, uint32_t* __restrict__ segbytes)
+  {
+  extern __shared__ uint32_t lds[];
+  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t g = blockIdx.x;
+  uint32_t* T = lds + c * LDSW_C;
+  uint32_t* ringw = T + TAB;
+  uint8_t* ring = (uint8_t*)ringw;
+  uint8_t* LID = (uint8_t*)(T + TAB + RING / 4);
+  // incoming table: payload of the last writer of every class before this segment (0 if none)
+  const uint32_t* row = inc + ((size_t)g * arity + c) * ROW;
+  for (int k = lane; k < TAB; k += 64)
+    {
+    const uint32_t idx = row[k];
+    uint32_t pay = 0;
+    if (idx)
+      {
+      const uint32_t vi = src[(size_t)(idx - 1u) * arity + c];
+      const uint32_t vp = idx >= 2u ? src[(size_t)(idx - 2u) * arity + c] : 0u;
+      pay = k < 16 ? vi : vi - vp;
+      }
+    T[k] = pay;
+    }
+  const uint64_t lt = (1ull << lane) - 1ull;
+  const uint32_t i_begin = g * L;
+  const uint32_t i_end = (n - i_begin < L) ? n : i_begin + L;
+  const uint32_t n8 = (n + 7u) & ~7u;
+  uint8_t* gbase = slots + (size_t)c * slot_stride + (size_t)g * segcap;
+  uint32_t pos = 0, flushed = 0;
+  if (g == 0)
+    {
+    if (lane == 0)
+      {
+      ring[0] = 0x25;                       // (4/2) << 4 | (10/2), fpsc.c:120
+      ring[1] = (uint8_t)(n >> 24); ring[2] = (uint8_t)(n >> 16); ring[3] = (uint8_t)(n >> 8); ring[4] = (uint8_t)n;
+      }
+    pos = 5u;
+    }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  Carry cy = load_carry(src, i_begin, arity, c);
+  uint32_t cur[PF], nxt[PF];
+  load_block(cur, src, i_begin, i_end, arity, c, lane);
+  for (uint32_t ib = i_begin; ib < i_end; ib += 64u * PF)
+    {
+    load_block(nxt, src, ib + 64u * PF, i_end, arity, c, lane);
+#pragma unroll
+    for (int pu = 0; pu < PF; ++pu)
+      {
+      const uint32_t i0 = ib + 64u * pu;
+      if (i0 >= i_end)
+        break;
+      const uint32_t i = i0 + lane;
+      const bool act = i < i_end;
+      const uint32_t v = cur[pu];
+      uint32_t a, b, k1, k2;
+      classes(v, cy, act, a, b, k1, k2);
+      const uint32_t s = v - a;
+      int src1, src2;
+      bool st1, st2, last1, last2;
+      wave_pred(k1, act, LID, lt, lane, st1, src1, last1);
+      wave_pred(k2, act, LID, lt, lane, st2, src2, last2);
+      uint32_t p1 = a, p2 = a - b;           // inside a run: previous lane's value / stride
+      const bool t1 = st1 && src1 < 0, t2 = st2 && src2 < 0;      // first of my class in this step
+      uint32_t tv1 = 0, tv2 = 0;
+      if (t1) tv1 = T[k1];
+      if (t2) tv2 = T[k2];
+      if (__ballot((st1 && src1 >= 0) || (st2 && src2 >= 0)))
+        {
+        const uint32_t q1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src1 << 2, (int)v);
+        const uint32_t q2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src2 << 2, (int)s);
+        if (st1) p1 = q1;
+        if (st2) p2 = q2;
+        }
+      if (t1) p1 = tv1;
+      if (t2) p2 = tv2;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (last1) T[k1] = v;
+      if (last2) T[k2] = s;
+      uint32_t len, x;
+      uint32_t code = pick(v ^ p1, v ^ (a + p2), len, x);
+      const bool slot = act || (i_end == n && i < n8);          // value or tail padding slot (fpsc.c:196-204)
+      if (!act)
+        {
+        code = slot ? 1u : 0u;
+        len = slot ? 1u : 0u;
+        x = 0u;
+        }
+      // byte layout of the step: [hdr g0][residuals 0..7][hdr g1][residuals 8..15]...
+      const uint64_t b0 = __ballot(len & 1u), b1 = __ballot(len & 2u), b2 = __ballot(len & 4u);
+      const uint32_t pre = popc_below(b0) + 2u * popc_below(b1) + 4u * popc_below(b2);
+      uint32_t bc = code << (3u * (lane & 7u));
+      bc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bc, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+      bc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bc, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+      bc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bc, 0x141, 0xf, 0xf, true);    // row_half_mirror
+      const uint32_t grp = lane >> 3;
+      const uint32_t rpos = pos + 3u * (grp + 1u) + pre;
+      if (len > 0u) ring[(rpos) & (RING - 1)] = (uint8_t)(x >> (8u * (len - 1u)));
+      if (len > 1u) ring[(rpos + 1u) & (RING - 1)] = (uint8_t)(x >> (8u * (len - 2u)));
+      if (len > 2u) ring[(rpos + 2u) & (RING - 1)] = (uint8_t)(x >> (8u * (len - 3u)));
+      if (len > 3u) ring[(rpos + 3u) & (RING - 1)] = (uint8_t)x;
+      if (slot && (lane & 7) == 0)
+        {
+        const uint32_t hpos = pos + 3u * grp + pre;
+        ring[hpos & (RING - 1)] = (uint8_t)(bc >> 16);
+        ring[(hpos + 1u) & (RING - 1)] = (uint8_t)(bc >> 8);
+        ring[(hpos + 2u) & (RING - 1)] = (uint8_t)bc;
+        }
+      const uint32_t nslots = (uint32_t)__popcll(__ballot(slot));
+      pos += 3u * (nslots >> 3) + (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      while (pos - flushed >= 256u)
+        {
+        const uint32_t off = flushed + 4u * lane;
+        *(uint32_t*)(gbase + off) = ringw[(off & (RING - 1)) >> 2];
+        flushed += 256u;
+        }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      next_carry(cy, v);
+      }
+#pragma unroll
+    for (int pu = 0; pu < PF; ++pu)
+      cur[pu] = nxt[pu];
+    }
+  while (flushed < pos)
+    {
+    const uint32_t off = flushed + 4u * lane;
+    if (off < pos)
+      store_span(gbase, off, ringw[(off & (RING - 1)) >> 2], pos);
+    flushed += 256u;
+    }
+  if (lane == 0)
+    segbytes[(size_t)c * S + g] = pos;
+  }
+
+// ---- offsets: exclusive scan of segment sizes per component (one workgroup per component) -------------
+__global__ void __launch_bounds__(1024) k_fpc32_offsets(const uint32_t* __restrict__ segbytes, uint32_t S, uint32_t* __restrict__ segoff,
+                                                        uint32_t* __restrict__ sizes)
   {
   __shared__ uint32_t part[1024];
   const uint32_t c = blockIdx.x;
@@ -300,162 +413,93 @@ __global__ void __launch_bounds__(1024) k_fpc32_b3(const uint32_t* __restrict__ 
     part[threadIdx.x] += add;
     __syncthreads();
     }
-  uint32_t run = 5u + part[threadIdx.x] - sum;       // 5 = stream header (fpsc.c:120-126)
+  uint32_t run = part[threadIdx.x] - sum;
   for (uint32_t g = g0; g < g1; ++g)
     {
     segoff[(size_t)c * S + g] = run;
     run += segbytes[(size_t)c * S + g];
     }
   if (threadIdx.x == 1023u)
-    sizes[c] = 5u + part[1023];
+    sizes[c] = part[1023];
   }
 
-// ---- pass C -------------------------------------------------------------------------------------------
-// store the bytes of ring word `w` (relative byte offset off, multiple of 4) that lie in [lo, hi)
-__device__ __forceinline__ void store_span(uint8_t* __restrict__ gbase, uint32_t off, uint32_t w, uint32_t lo, uint32_t hi)
-  {
-  if (off >= lo && off + 4u <= hi)
-    *(uint32_t*)(gbase + off) = w;
-  else
-    {
-    for (uint32_t b = 0; b < 4u; ++b)
-      if (off + b >= lo && off + b < hi)
-        gbase[off + b] = (uint8_t)(w >> (8u * b));
-    }
-  }
-
-__global__ void __launch_bounds__(192) k_fpc32_pass_c(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t L, uint32_t S,
-                                                      const uint32_t* __restrict__ inc, const uint32_t* __restrict__ segoff,
+// ---- gather: segment slots -> contiguous payload -------------------------------------------------------
+// grid (S, arity); each workgroup moves one segment.  Destination dwords are written aligned; the source
+// is read as aligned dwords and re-aligned with v_alignbyte.
+__global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap, uint32_t S,
+                                                      const uint32_t* __restrict__ segbytes, const uint32_t* __restrict__ segoff,
                                                       uint8_t* __restrict__ out, size_t out_stride)
   {
-  extern __shared__ uint32_t lds[];
-  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t g = blockIdx.x;
-  uint32_t* T = lds + c * LDSW_C;
-  uint32_t* ringw = T + TAB;
-  uint8_t* ring = (uint8_t*)ringw;
-  const uint32_t* row = inc + ((size_t)g * arity + c) * ROW;
-  for (int i = lane; i < TAB; i += 64)
-    T[i] = row[i];
-  const uint64_t lt = (1ull << lane) - 1ull;
-  const uint32_t i_begin = g * L;
-  const uint32_t i_end = (n - i_begin < L) ? n : i_begin + L;
-  const uint32_t n8 = (n + 7u) & ~7u;
-  // output window: ring byte r <-> global byte (A & ~3) + r
-  const uint32_t A = (g == 0) ? 0u : segoff[(size_t)c * S + g];
-  uint8_t* gbase = out + (size_t)c * out_stride + (A & ~3u);
-  const uint32_t own_lo = A & 3u;
-  uint32_t pos = own_lo, flushed = 0;
-  if (g == 0)
+  const uint32_t g = blockIdx.x, c = blockIdx.y;
+  const uint32_t len = segbytes[(size_t)c * S + g];
+  const uint8_t* s = slots + (size_t)c * slot_stride + (size_t)g * segcap;       // 4-byte aligned
+  uint8_t* d = out + (size_t)c * out_stride + segoff[(size_t)c * S + g];
+  const uint32_t head = (uint32_t)((4u - ((uintptr_t)d & 3u)) & 3u);              // bytes until d is aligned
+  const uint32_t h = head < len ? head : len;
+  if (threadIdx.x < h)
+    d[threadIdx.x] = s[threadIdx.x];
+  const uint32_t body = (len - h) >> 2;                                           // aligned destination dwords
+  uint32_t* dd = (uint32_t*)(d + h);
+  const uint32_t* ss = (const uint32_t*)s;
+  // destination dword t holds source bytes h + 4t .. h + 4t + 3  (h < 4)
+  for (uint32_t t = threadIdx.x; t < body; t += 256u)
     {
-    if (lane == 0)
-      {
-      ring[0] = 0x25;                       // (4/2) << 4 | (10/2)
-      ring[1] = (uint8_t)(n >> 24); ring[2] = (uint8_t)(n >> 16); ring[3] = (uint8_t)(n >> 8); ring[4] = (uint8_t)n;
-      }
-    pos = 5u;
+    const uint32_t lo = ss[t], hi = ss[t + 1u];
+    dd[t] = h ? __builtin_amdgcn_alignbyte(hi, lo, h) : lo;
     }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  Carry cy = load_carry(src, i_begin, arity, c);
-  for (uint32_t i0 = i_begin; i0 < i_end; i0 += 64u)
-    {
-    const uint32_t i = i0 + lane;
-    const bool act = i < i_end;
-    const uint32_t v = act ? src[(size_t)i * arity + c] : 0u;
-    uint32_t a, s, k1, k2;
-    classes(v, cy, act, a, s, k1, k2);
-    const uint64_t actmask = __ballot(act);
-    int src1, src2;
-    bool last1, last2;
-    wave_pred(k1, actmask, lt, lane, src1, last1);
-    wave_pred(k2, actmask, lt, lane, src2, last2);
-    uint32_t p1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src1 << 2, (int)v);
-    uint32_t p2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src2 << 2, (int)s);
-    if (act && src1 < 0) p1 = T[k1];
-    if (act && src2 < 0) p2 = T[k2];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (last1) T[k1] = v;
-    if (last2) T[k2] = s;
-    uint32_t len, x;
-    uint32_t code = pick(v ^ p1, v ^ (a + p2), len, x);
-    const bool slot = act || (i_end == n && i < n8);          // value or tail padding slot
-    if (!act)
-      {
-      code = slot ? 1u : 0u;
-      len = slot ? 1u : 0u;
-      x = 0u;
-      }
-    // byte offsets inside the step: [hdr g0][res 0..7][hdr g1][res 8..15]...
-    const uint32_t pre = popc_below(__ballot(len & 1u)) + 2u * popc_below(__ballot(len & 2u)) + 4u * popc_below(__ballot(len & 4u));
-    uint32_t bc = code << (3u * (lane & 7u));
-    bc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bc, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
-    bc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bc, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
-    bc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bc, 0x141, 0xf, 0xf, true);    // row_half_mirror
-    const uint32_t grp = lane >> 3;
-    const uint32_t rpos = pos + 3u * (grp + 1u) + pre;
-    if (len > 0u) ring[(rpos) & (RING - 1)] = (uint8_t)(x >> (8u * (len - 1u)));
-    if (len > 1u) ring[(rpos + 1u) & (RING - 1)] = (uint8_t)(x >> (8u * (len - 2u)));
-    if (len > 2u) ring[(rpos + 2u) & (RING - 1)] = (uint8_t)(x >> (8u * (len - 3u)));
-    if (len > 3u) ring[(rpos + 3u) & (RING - 1)] = (uint8_t)x;
-    if (slot && (lane & 7) == 0)
-      {
-      const uint32_t hpos = pos + 3u * grp + pre;
-      ring[hpos & (RING - 1)] = (uint8_t)(bc >> 16);
-      ring[(hpos + 1u) & (RING - 1)] = (uint8_t)(bc >> 8);
-      ring[(hpos + 2u) & (RING - 1)] = (uint8_t)bc;
-      }
-    const uint32_t nslots = (uint32_t)__popcll(__ballot(slot));
-    pos += 3u * (nslots >> 3);
-    pos += (uint32_t)__popcll(__ballot(len & 1u)) + 2u * (uint32_t)__popcll(__ballot(len & 2u)) + 4u * (uint32_t)__popcll(__ballot(len & 4u));
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    while (pos - flushed >= 256u)
-      {
-      const uint32_t off = flushed + 4u * lane;
-      store_span(gbase, off, ringw[(off & (RING - 1)) >> 2], own_lo, 0xffffffffu);
-      flushed += 256u;
-      }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    cy.m1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-    cy.m2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 62);
-    cy.m3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 61);
-    }
-  while (flushed < pos)
-    {
-    const uint32_t off = flushed + 4u * lane;
-    if (off < pos)
-      store_span(gbase, off, ringw[(off & (RING - 1)) >> 2], own_lo, pos);
-    flushed += 256u;
-    }
+  const uint32_t done = h + 4u * body;
+  if (threadIdx.x < len - done)
+    d[done + threadIdx.x] = s[done + threadIdx.x];
   }
 
 // n == 0: undefined in the reference; defined as header + one full pad group
 __global__ void k_fpc32_empty(uint8_t* out, size_t out_stride, uint32_t* sizes)
   {
   uint8_t* o = out + (size_t)blockIdx.x * out_stride;
-  const uint8_t b[16] = { 0x25, 0, 0, 0, 0, 0x24, 0x92, 0x49, 0, 0, 0, 0, 0, 0, 0, 0 };
-  for (int i = 0; i < 16; ++i) o[i] = b[i];
+  const uint8_t bts[16] = { 0x25, 0, 0, 0, 0, 0x24, 0x92, 0x49, 0, 0, 0, 0, 0, 0, 0, 0 };
+  for (int i = 0; i < 16; ++i) o[i] = bts[i];
   sizes[blockIdx.x] = 16;
+  }
+
+struct Plan { uint32_t L, S, segcap, nch; size_t rows, slot_stride, off_summ, off_inc, off_chmax, off_segbytes, off_segoff, off_slots, total; };
+
+Plan make_plan(uint32_t n, int arity)
+  {
+  static int waves = 0;
+  if (!waves)
+    {
+    const char* e = getenv("TRICO_FPC32_WAVES");      // tuning knob: waves per sweep
+    waves = e ? atoi(e) : 6144;
+    if (waves < 3) waves = 3;
+    }
+  Plan p;
+  const uint32_t target = (uint32_t)waves / (uint32_t)arity;
+  uint64_t L = ((uint64_t)n + target - 1) / target;
+  L = (L + 63) / 64 * 64;
+  if (L < 1024) L = 1024;
+  p.L = (uint32_t)L;
+  p.S = (uint32_t)(((uint64_t)n + L - 1) / L);
+  if (p.S == 0) p.S = 1;
+  p.segcap = (uint32_t)align_up(5 + 4 * (size_t)L + 3 * ((size_t)L / 8) + 16 + 280, 256);
+  p.nch = (p.S + CH - 1) / CH;
+  p.rows = (size_t)p.S * arity;
+  p.slot_stride = (size_t)p.S * p.segcap;
+  size_t o = 0;
+  p.off_summ = o;      o += align_up(p.rows * ROW * 4, 256);
+  p.off_inc = o;       o += align_up(p.rows * ROW * 4, 256);
+  p.off_chmax = o;     o += align_up((size_t)p.nch * arity * TAB * 4, 256);
+  p.off_segbytes = o;  o += align_up(p.rows * 4, 256);
+  p.off_segoff = o;    o += align_up(p.rows * 4, 256);
+  p.off_slots = o;     o += p.slot_stride * arity;
+  p.total = o + 256;
+  return p;
   }
 
 } // namespace
 
-size_t fpc32_encode_workspace(uint32_t n, int arity, uint32_t* L_out, uint32_t* S_out)
+size_t fpc32_encode_workspace(uint32_t n, int arity)
   {
-  const uint32_t target = 3840u / (uint32_t)arity;
-  uint64_t L = ((uint64_t)n + target - 1) / target;
-  L = (L + 63) / 64 * 64;
-  if (L < 1024) L = 1024;
-  const uint32_t S = (uint32_t)(((uint64_t)n + L - 1) / L);
-  *L_out = (uint32_t)L;
-  *S_out = S ? S : 1;
-  const size_t rows = (size_t)(*S_out) * arity;
-  const size_t nch = ((size_t)(*S_out) + CH - 1) / CH;
-  size_t bytes = 0;
-  bytes += rows * ROW * 4 * 2;                    // summ, inc
-  bytes += nch * arity * TAB * 4 * 2;             // chval, chseen
-  bytes += rows * 4 * 3;                          // segbytes, segoff, ucount
-  bytes += rows * UCAP * sizeof(UEntry);          // ulist
-  return bytes + 4096;
+  return make_plan(n, arity).total;
   }
 
 int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
@@ -467,36 +511,29 @@ int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
     hipLaunchKernelGGL(k_fpc32_empty, dim3(arity), dim3(1), 0, st, d_out, out_stride, d_sizes);
     return hip_ok(hipGetLastError(), "k_fpc32_empty") ? 1 : 0;
     }
-  uint32_t L, S;
-  const size_t need = fpc32_encode_workspace(n, arity, &L, &S);
-  if (need > ws_bytes)
+  const Plan p = make_plan(n, arity);
+  if (p.total > ws_bytes)
     {
     set_error("fpc32 encode: workspace too small");
     return 0;
     }
-  const size_t rows = (size_t)S * arity;
-  const uint32_t nch = (S + CH - 1) / CH;
-  uint8_t* w = d_ws;
-  uint32_t* summ = (uint32_t*)w;      w += rows * ROW * 4;
-  uint32_t* inc = (uint32_t*)w;       w += rows * ROW * 4;
-  uint32_t* chval = (uint32_t*)w;     w += (size_t)nch * arity * TAB * 4;
-  uint32_t* chseen = (uint32_t*)w;    w += (size_t)nch * arity * TAB * 4;
-  uint32_t* segbytes = (uint32_t*)w;  w += rows * 4;
-  uint32_t* segoff = (uint32_t*)w;    w += rows * 4;
-  uint32_t* ucount = (uint32_t*)w;    w += rows * 4;
-  w = (uint8_t*)(((uintptr_t)w + 15) & ~(uintptr_t)15);
-  UEntry* ulist = (UEntry*)w;
+  uint32_t* summ = (uint32_t*)(d_ws + p.off_summ);
+  uint32_t* inc = (uint32_t*)(d_ws + p.off_inc);
+  uint32_t* chmax = (uint32_t*)(d_ws + p.off_chmax);
+  uint32_t* segbytes = (uint32_t*)(d_ws + p.off_segbytes);
+  uint32_t* segoff = (uint32_t*)(d_ws + p.off_segoff);
+  uint8_t* slots = d_ws + p.off_slots;
   const uint32_t* src = (const uint32_t*)d_src;
   const unsigned threads = 64u * (unsigned)arity;
-  hipLaunchKernelGGL(k_fpc32_pass_a, dim3(S), dim3(threads), (size_t)arity * LDSW_A * 4, st,
-                     src, n, arity, L, S, summ, segbytes, ucount, ulist);
+  hipLaunchKernelGGL(k_fpc32_index, dim3(p.S), dim3(threads), (size_t)arity * LDSW_A * 4, st, src, n, arity, p.L, summ);
   const unsigned colblocks = ((unsigned)arity * TAB + 255u) / 256u;
-  hipLaunchKernelGGL(k_fpc32_b1a, dim3(colblocks, nch), dim3(256), 0, st, summ, S, arity, chval, chseen);
-  hipLaunchKernelGGL(k_fpc32_b1b, dim3(colblocks, nch), dim3(256), 0, st, summ, S, arity, chval, chseen, inc);
-  hipLaunchKernelGGL(k_fpc32_b2, dim3((unsigned)rows), dim3(64), 0, st, inc, arity, S, ucount, ulist, segbytes);
-  hipLaunchKernelGGL(k_fpc32_b3, dim3(arity), dim3(1024), 0, st, segbytes, S, segoff, d_sizes);
-  hipLaunchKernelGGL(k_fpc32_pass_c, dim3(S), dim3(threads), (size_t)arity * LDSW_C * 4, st,
-                     src, n, arity, L, S, inc, segoff, d_out, out_stride);
+  hipLaunchKernelGGL(k_fpc32_scan_a, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax);
+  hipLaunchKernelGGL(k_fpc32_scan_b, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax, inc);
+  hipLaunchKernelGGL(k_fpc32_code, dim3(p.S), dim3(threads), (size_t)arity * LDSW_C * 4, st,
+                     src, n, arity, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes);
+  hipLaunchKernelGGL(k_fpc32_offsets, dim3(arity), dim3(1024), 0, st, segbytes, p.S, segoff, d_sizes);
+  hipLaunchKernelGGL(k_fpc32_gather, dim3(p.S, arity), dim3(256), 0, st, slots, p.slot_stride, p.segcap, p.S, segbytes, segoff,
+                     d_out, out_stride);
   return hip_ok(hipGetLastError(), "fpc32 encode kernels") ? 1 : 0;
   }
 

@@ -280,8 +280,7 @@ int trico_hip_fpc_encode(trico_hip_ctx* ctx, const void* src, uint32_t n, int ar
     }
   if (width == 4 && !force_serial())
     {
-    uint32_t L, S;
-    const size_t ws = fpc32_encode_workspace(n, arity, &L, &S);
+    const size_t ws = fpc32_encode_workspace(n, arity);
     if (!ctx->tmp.reserve(ws))
       return 0;
     if (!launch_fpc32_encode(d_src, n, arity, ctx->out.p, stride, d_sizes, ctx->tmp.p, ctx->tmp.cap))
@@ -358,7 +357,12 @@ int trico_hip_fpc_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[3], c
     TRICO_HIP_TRY(hipMemsetAsync(ctx->tmp.p, 0, tb, current_stream()));
     d_tables = (uint64_t*)ctx->tmp.p;
     }
-  if (!launch_fpc_decode_serial(d_pay, sizes, arity, width, n, d_dst, d_tables, d_status))
+  if (width == 4 && !force_serial())
+    {
+    if (!launch_fpc32_decode(d_pay, sizes, arity, n, d_dst, d_status))
+      return 0;
+    }
+  else if (!launch_fpc_decode_serial(d_pay, sizes, arity, width, n, d_dst, d_tables, d_status))
     return 0;
   }
   uint32_t status = 0;
@@ -409,7 +413,8 @@ int trico_hip_int_encode(trico_hip_ctx* ctx, const void* src, uint32_t count, in
   uint32_t* d_sizes = (uint32_t*)ctx->aux.p;
   {
   ProfSpan span(TRICO_HIP_K_LZ4_ENCODE);
-  if (!launch_lz4_encode_serial(d_planes, plane_stride, count, width, ctx->out.p, stride, d_sizes))
+  if (!(force_serial() ? launch_lz4_encode_serial(d_planes, plane_stride, count, width, ctx->out.p, stride, d_sizes)
+                       : launch_lz4_encode_wave(d_planes, plane_stride, count, width, ctx->out.p, stride, d_sizes)))
     return 0;
   }
   if (!read_back_words(ctx, d_sizes, width, ctx->out_sizes))
@@ -476,7 +481,8 @@ int trico_hip_int_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[8], c
   TRICO_HIP_TRY(hipMemsetAsync(d_status, 0, 64, current_stream()));
   {
   ProfSpan span(TRICO_HIP_K_LZ4_DECODE);
-  if (!launch_lz4_decode_serial(d_pay, sizes, width, d_planes, plane_stride, count, d_status))
+  if (!(force_serial() ? launch_lz4_decode_serial(d_pay, sizes, width, d_planes, plane_stride, count, d_status)
+                       : launch_lz4_decode_wave(d_pay, sizes, width, d_planes, plane_stride, count, d_status)))
     return 0;
   }
   if (width > 1)
