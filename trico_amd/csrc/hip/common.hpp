@@ -81,7 +81,8 @@ int launch_lz4_decode_serial(const uint8_t* const d_payloads[8], const uint32_t 
 size_t fpc32_encode_workspace(uint32_t n, int arity);
 int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
                         uint8_t* d_ws, size_t ws_bytes);
-bool force_serial();   // TRICO_HIP_SERIAL=1: route everything through the reference-order kernels (A/B debugging)
+bool force_serial();              // TRICO_HIP_SERIAL: see shim.hip
+bool force_serial_stage(int bit);
 
 // latency-optimised float decoder (k_fpc32_decode.hip): one wave per component stream
 int launch_fpc32_decode(const uint8_t* const d_payloads[3], const uint32_t sizes[3], int arity, uint32_t n, void* d_dst,

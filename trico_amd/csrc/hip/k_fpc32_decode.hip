@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(64) k_fpc32_decode(DecodeArgs args, int arity,
         if (ck > 4u)
           p = p2 + T2[h2];                                 // decoder keeps value + stride (fpsc.c:323)
         const uint32_t v = x ^ p;
-        T1 = (uint32_t)__builtin_amdgcn_writelane((int)v, (int)h1, (int)T1);
+        T1 = ((uint32_t)lane == h1) ? v : T1;             // v_writelane semantics via compare + select
         h1 = ((h1 << e1) ^ (v >> sh1)) & m1;
         p1 = (uint32_t)__builtin_amdgcn_readlane((int)T1, (int)h1);
         const uint32_t s = v - last;
@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(64) k_fpc32_decode(DecodeArgs args, int arity,
         h2 = ((h2 << e2h) ^ (s >> sh2)) & m2;
         p2 = v;
         last = v;
-        outv = (uint32_t)__builtin_amdgcn_writelane((int)v, (int)((i + k) & 63u), (int)outv);
+        outv = ((uint32_t)lane == ((i + k) & 63u)) ? v : outv;
         }
       }
     if (((i + 8u) & 63u) == 0u || i + 8u >= n)

@@ -239,7 +239,7 @@ __device__ __forceinline__ void wave_match_copy(uint8_t* __restrict__ dst, uint3
     for (uint32_t i = 0; i < first; i += 64u)
       {
       if (i + lane < first)
-        dst[i + lane] = dst[i + lane - off];
+        dst[i + lane] = period[i + lane];        // (not dst[i + lane - off]: that index wraps as uint32)
       __builtin_amdgcn_s_waitcnt(0);
       }
     }

@@ -28,16 +28,21 @@ bool hip_ok(hipError_t e, const char* what)
 
 hipStream_t current_stream() { return g_stream; }
 
-bool force_serial()
+// TRICO_HIP_SERIAL: bit mask routing a stage through the reference-order kernels of k_serial.hip
+// (A/B debugging): 1 = float encode, 2 = float decode, 4 = LZ4 encode, 8 = LZ4 decode; "1" alone = all.
+static int serial_mask()
   {
   static int v = -1;
   if (v < 0)
     {
     const char* e = getenv("TRICO_HIP_SERIAL");
-    v = (e && e[0] == '1') ? 1 : 0;
+    v = e ? atoi(e) : 0;
+    if (v == 1) v = 15;
     }
-  return v == 1;
+  return v;
   }
+bool force_serial() { return serial_mask() == 15; }
+bool force_serial_stage(int bit) { return (serial_mask() & bit) != 0; }
 
 bool DevBuf::reserve(size_t bytes)
   {
@@ -278,7 +283,7 @@ int trico_hip_fpc_encode(trico_hip_ctx* ctx, const void* src, uint32_t n, int ar
     TRICO_HIP_TRY(hipMemsetAsync(ctx->tmp.p, 0, tb, current_stream()));
     d_tables = (uint64_t*)ctx->tmp.p;
     }
-  if (width == 4 && !force_serial())
+  if (width == 4 && !force_serial_stage(1))
     {
     const size_t ws = fpc32_encode_workspace(n, arity);
     if (!ctx->tmp.reserve(ws))
@@ -357,7 +362,7 @@ int trico_hip_fpc_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[3], c
     TRICO_HIP_TRY(hipMemsetAsync(ctx->tmp.p, 0, tb, current_stream()));
     d_tables = (uint64_t*)ctx->tmp.p;
     }
-  if (width == 4 && !force_serial())
+  if (width == 4 && !force_serial_stage(2))
     {
     if (!launch_fpc32_decode(d_pay, sizes, arity, n, d_dst, d_status))
       return 0;
@@ -413,7 +418,7 @@ int trico_hip_int_encode(trico_hip_ctx* ctx, const void* src, uint32_t count, in
   uint32_t* d_sizes = (uint32_t*)ctx->aux.p;
   {
   ProfSpan span(TRICO_HIP_K_LZ4_ENCODE);
-  if (!(force_serial() ? launch_lz4_encode_serial(d_planes, plane_stride, count, width, ctx->out.p, stride, d_sizes)
+  if (!(force_serial_stage(4) ? launch_lz4_encode_serial(d_planes, plane_stride, count, width, ctx->out.p, stride, d_sizes)
                        : launch_lz4_encode_wave(d_planes, plane_stride, count, width, ctx->out.p, stride, d_sizes)))
     return 0;
   }
@@ -481,7 +486,7 @@ int trico_hip_int_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[8], c
   TRICO_HIP_TRY(hipMemsetAsync(d_status, 0, 64, current_stream()));
   {
   ProfSpan span(TRICO_HIP_K_LZ4_DECODE);
-  if (!(force_serial() ? launch_lz4_decode_serial(d_pay, sizes, width, d_planes, plane_stride, count, d_status)
+  if (!(force_serial_stage(8) ? launch_lz4_decode_serial(d_pay, sizes, width, d_planes, plane_stride, count, d_status)
                        : launch_lz4_decode_wave(d_pay, sizes, width, d_planes, plane_stride, count, d_status)))
     return 0;
   }
