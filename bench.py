@@ -1,0 +1,261 @@
+"""bench.py — driver benchmark: Trico encode -> decode round trip on device-resident synthetic meshes.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One step = one pass of the hot path over one mesh per GPU: raw arrays resident in HBM ->
+trico_write_vertices + trico_write_triangles into a device-resident .trc archive -> (N > 1: RCCL gather
+of the archives to rank 0 over xGMI) -> trico_open_archive_for_reading + trico_read_* back into HBM.
+Workload = BASELINE.json configs[1]: grid(10000,5000) = 50M float xyz vertices + 100M uint32 triangles
+(1.8e9 raw bytes) per GPU; with N GPUs every rank codes its own mesh (configs[3], seeds 0x12345678+rank),
+so scaling is weak.  Before timing, the archive is checked against the reference's sha256
+(tests/golden/hashes.json) and the decoded arrays against the input (bit-exact).
+
+value = raw input bytes of all ranks / wall time of (encode + gather + decode), GB/s.
+roofline  = the float-vertex encoder (north_star's target kernel): algorithmic bytes (raw vertex bytes
+            + their payload bytes) / average device time of its launch sequence, vs 8 TB/s HBM3E.
+cpu_baseline = the reference itself (oracle/_ref, built from /root/reference) when that library is
+            present, else the oracle port, 1 thread, on a bounded sample of the same generator.
+"""
+import argparse
+import ctypes
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mesh", default="grid", choices=["grid", "walk"])
+    ap.add_argument("--W", type=int, default=10000)
+    ap.add_argument("--H", type=int, default=5000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="10000x1250")
+    return ap.parse_args()
+
+
+def cpu_baseline(mesh, sample):
+    """Times the CPU path (1 thread) on a bounded sample: encode + decode through the reference's API."""
+    from oracle import oracle as O
+    from trico_amd import meshgen
+    W, H = (int(x) for x in sample.split("x"))
+    v, t = (meshgen.grid if mesh == "grid" else meshgen.walk)(W, H)
+    nv, nt = W * H, 2 * W * H
+    raw = v.nbytes + t.nbytes
+    if O.have_ref():
+        L = O.ref()
+        kind = "reference"
+        t0 = time.perf_counter()
+        a = L.trico_open_archive_for_writing(1 << 20)
+        L.trico_write_vertices(a, v.ctypes.data, nv)
+        L.trico_write_triangles(a, t.ctypes.data, nt)
+        t1 = time.perf_counter()
+        size = L.trico_get_size(a)
+        blob = ctypes.string_at(L.trico_get_buffer_pointer(a), size)
+        L.trico_close_archive(a)
+        buf = np.frombuffer(blob, np.uint8)
+        v2, t2 = np.empty_like(v), np.empty_like(t)
+        t2s = time.perf_counter()
+        r = L.trico_open_archive_for_reading(buf.ctypes.data, size)
+        pv, pt = ctypes.c_void_p(v2.ctypes.data), ctypes.c_void_p(t2.ctypes.data)
+        L.trico_read_vertices(r, ctypes.byref(pv))
+        L.trico_read_triangles(r, ctypes.byref(pt))
+        t3 = time.perf_counter()
+        L.trico_close_archive(r)
+        assert v2.tobytes() == v.tobytes() and t2.tobytes() == t.tobytes()
+        enc, dec = t1 - t0, t3 - t2s
+    else:
+        kind = "port"
+        t0 = time.perf_counter()
+        a = O.OracleArchive()
+        a.write("vertices", v, nv)
+        a.write("triangles", t, nt)
+        t1 = time.perf_counter()
+        blob = a.tobytes()
+        a.close()
+        # decode leg of the port: per-payload decoders
+        import struct
+        pos = 8 + 5
+        t2s = time.perf_counter()
+        for _ in range(3):
+            nb = struct.unpack_from("<I", blob, pos)[0]
+            O.fpc_decode(blob[pos + 4: pos + 4 + nb], np.float32)
+            pos += 4 + nb
+        pos += 5
+        for _ in range(4):
+            nb = struct.unpack_from("<I", blob, pos)[0]
+            O.lz4_decompress(blob[pos + 4: pos + 4 + nb], 3 * nt)
+            pos += 4 + nb
+        t3 = time.perf_counter()
+        enc, dec = t1 - t0, t3 - t2s
+    return {"value": round(raw / (enc + dec) / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
+            "sample": "%s(%d,%d): %d float vertices + %d u32 triangles, %.0f MB raw; encode %.2f s, decode %.2f s"
+                      % (mesh, W, H, nv, nt, raw / 1e6, enc, dec),
+            "encode_GBps": round(raw / enc / 1e9, 4), "decode_GBps": round(raw / dec / 1e9, 4)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from trico_amd import api, meshgen
+    from trico_amd.parallel import gather_archives
+    L = api.lib()
+    if not L.trico_hip_available():
+        raise SystemExit("bench.py: no HIP device: " + api.last_error())
+
+    W, H = args.W, args.H
+    nv, nt = W * H, 2 * W * H
+    seed = (meshgen.GRID_SEED if args.mesh == "grid" else meshgen.WALK_SEED) + rank
+    gen = meshgen.grid if args.mesh == "grid" else meshgen.walk
+    v, t = gen(W, H, seed)
+    d_v = torch.from_numpy(v).to(dev)
+    d_t = torch.from_numpy(t.view(np.int32)).to(dev)
+    d_v2 = torch.empty_like(d_v)
+    d_t2 = torch.empty_like(d_t)
+    raw_bytes = v.nbytes + t.nbytes
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    state = {}
+
+    def step(check=False):
+        te0 = time.perf_counter()
+        a = api.Archive.open_for_writing(1 << 20, device=True)
+        assert a.write("vertices", d_v, nv) == 1, api.last_error()
+        assert a.write("triangles", d_t, nt) == 1, api.last_error()
+        torch.cuda.synchronize()
+        te1 = time.perf_counter()
+        size = a.get_size()
+        if dist is not None:
+            gathered = gather_archives(dist, a.get_buffer_pointer(), size, dev, dst=0)
+            torch.cuda.synchronize()
+            state["gathered_bytes"] = gathered
+        tg1 = time.perf_counter()
+        r = api.Archive.open_for_reading(a.get_buffer_pointer(), size)
+        assert r is not None
+        assert r.read("vertices", d_v2) == 1, api.last_error()
+        assert r.read("triangles", d_t2) == 1, api.last_error()
+        torch.cuda.synchronize()
+        td1 = time.perf_counter()
+        if check:
+            blob = a.tobytes()
+            state["archive_bytes"] = len(blob)
+            state["sha256"] = hashlib.sha256(blob).hexdigest()
+            state["roundtrip_ok"] = bool(torch.equal(d_v2.view(torch.int32), d_v.view(torch.int32)) and torch.equal(d_t2, d_t))
+            # vertex payload bytes for the roofline's algorithmic byte count
+            import struct
+            pos, vp = 8 + 5, 0
+            for _ in range(3):
+                nb = struct.unpack_from("<I", blob, pos)[0]
+                vp += nb
+                pos += 4 + nb
+            state["vertex_payload_bytes"] = vp
+        r.close()
+        a.close()
+        return te1 - te0, tg1 - te1, td1 - tg1
+
+    # correctness gate + warmup (untimed)
+    step(check=True)
+    for _ in range(max(0, args.warmup - 1)):
+        step()
+    golden = None
+    hp = os.path.join(ROOT, "tests", "golden", "hashes.json")
+    if os.path.exists(hp):
+        key = "%s_%dx%d" % (args.mesh, W, H) + ("" if rank == 0 else "_seed%08x" % seed)
+        golden = json.load(open(hp)).get(key)
+    parity = "unchecked (no golden for this size)"
+    if golden is not None:
+        if golden["sha256"] != state["sha256"]:
+            raise SystemExit("bench.py: archive sha256 differs from the reference's golden on rank %d" % rank)
+        parity = "sha256 == reference golden"
+    if not state["roundtrip_ok"]:
+        raise SystemExit("bench.py: decoded arrays differ from the input on rank %d" % rank)
+
+    L.trico_hip_profile_enable(1)
+    L.trico_hip_profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    enc = gat = dec = 0.0
+    for _ in range(args.steps):
+        e, g, d = step()
+        enc += e
+        gat += g
+        dec += d
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = torch.tensor([t1 - t0, enc, gat, dec], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = elapsed.tolist()
+
+    spans = ctypes.c_uint64(0)
+    kms = {}
+    for name, kid in api.KERNEL_IDS.items():
+        ms = L.trico_hip_profile_ms(kid, ctypes.byref(spans))
+        if spans.value:
+            kms[name] = {"avg_ms": round(ms / spans.value, 4), "launches": int(spans.value)}
+    L.trico_hip_profile_enable(0)
+
+    if rank == 0:
+        total_raw = raw_bytes * world
+        step_s = elapsed[0] / args.steps
+        fe = kms.get("fpc32_encode", {"avg_ms": float("nan")})
+        alg_bytes = v.nbytes + state["vertex_payload_bytes"]
+        achieved = alg_bytes / (fe["avg_ms"] * 1e-3) / 1e9
+        out = {
+            "metric": "encode+decode GB/s (input bytes)",
+            "value": round(total_raw / step_s / 1e9, 4),
+            "unit": "GB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(step_s * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "%s(%d,%d): %d float xyz vertices + %d uint32 triangles per GPU (BASELINE configs[1]%s), "
+                                   "device-resident raw arrays -> .trc archive in HBM -> decoded arrays in HBM"
+                                   % (args.mesh, W, H, nv, nt, "" if world == 1 else "; one mesh per GPU, RCCL gather of archives to rank 0 (configs[3])"),
+                       "raw_bytes_per_gpu": raw_bytes, "archive_bytes_rank0": state["archive_bytes"], "parity": parity,
+                       "parallelism": "1 process per GPU, %d independent meshes" % world},
+            "encode_GBps": round(total_raw / (elapsed[1] / args.steps) / 1e9, 4),
+            "decode_GBps": round(total_raw / (elapsed[3] / args.steps) / 1e9, 4),
+            "gather_ms": round(elapsed[2] / args.steps * 1e3, 3),
+            "roofline": {"kernel": "float-vertex encoder (k_fpc32_index + scan + k_fpc32_code + offsets + gather)",
+                         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fe["avg_ms"]},
+            "kernels": kms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.mesh, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
