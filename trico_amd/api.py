@@ -56,7 +56,7 @@ HIP_SYMBOLS = [
     "trico_hip_device_free", "trico_hip_copy", "trico_hip_fpc_encode", "trico_hip_fpc_decode",
     "trico_hip_int_encode", "trico_hip_int_decode", "trico_hip_fetch_payload", "trico_hip_payload_device_pointer",
     "trico_hip_open_archive_for_writing_device", "trico_hip_profile_enable", "trico_hip_profile_reset",
-    "trico_hip_profile_ms",
+    "trico_hip_profile_ms", "trico_hip_last_stats",
 ]
 KERNEL_IDS = {
     "fpc32_encode": 0, "fpc64_encode": 1, "fpc32_decode": 2, "fpc64_decode": 3,
@@ -141,6 +141,8 @@ def lib():
     L.trico_hip_fetch_payload.restype = ci
     L.trico_hip_payload_device_pointer.argtypes = [vp, ci]
     L.trico_hip_payload_device_pointer.restype = vp
+    L.trico_hip_last_stats.argtypes = [ctypes.POINTER(u32)]
+    L.trico_hip_last_stats.restype = None
     L.trico_hip_profile_enable.argtypes = [ci]
     L.trico_hip_profile_enable.restype = None
     L.trico_hip_profile_reset.restype = None

@@ -36,8 +36,10 @@ struct trico_hip_ctx
   trico::DevBuf out;       // encoded payloads (component c at out.p + c * out_stride) / staged decode output
   trico::DevBuf tmp;       // planes, SoA intermediates, predictor tables
   trico::DevBuf aux;       // small: sizes, status words, segment summaries
+  trico::DevBuf ws;        // large kernel workspaces (chunked LZ4 descriptors / tables)
   size_t out_stride = 0;
   uint32_t out_sizes[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  uint32_t out_sizes_raw[24] = { 0 };
   int out_count = 0;
   uint32_t* h_pinned = nullptr;   // 64 words of pinned host memory for size/status read-back
   };
@@ -93,6 +95,12 @@ int launch_lz4_encode_wave(const uint8_t* d_planes, size_t plane_stride, uint32_
                            size_t out_stride, uint32_t* d_sizes);
 int launch_lz4_decode_wave(const uint8_t* const d_payloads[8], const uint32_t sizes[8], int nplanes,
                            uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, uint32_t* d_status);
+
+// chunk-speculative exact LZ4 compressor for large planes (k_lz4_chunked.hip)
+uint32_t lz4_chunked_threshold();
+size_t lz4_chunked_workspace(uint32_t n, int nplanes, size_t plane_stride);
+int launch_lz4_encode_chunked(const uint8_t* d_planes, size_t plane_stride, uint32_t n, int nplanes, uint8_t* d_out, size_t out_stride,
+                              uint32_t* d_sizes, uint8_t* d_ws, size_t ws_bytes, uint32_t* d_status);
 
 // byte-plane split / merge (k_planes.hip)
 int launch_planes_split(const void* d_src, uint32_t count, int width, uint8_t* d_planes, size_t plane_stride);

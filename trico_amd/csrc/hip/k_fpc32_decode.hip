@@ -25,6 +25,7 @@ namespace {
 
 constexpr int WINW = 2048;             // staging window, dwords (8 KiB)
 constexpr int WIN_LOW = 64;            // refill when fewer than this many bytes remain (a group needs <= 35)
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 
 struct DecodeArgs
   {
@@ -38,7 +39,6 @@ __global__ void __launch_bounds__(64) k_fpc32_decode(DecodeArgs args, int arity,
                                                      uint32_t* __restrict__ status)
   {
   __shared__ uint32_t win[WINW + 4];
-  __shared__ uint32_t T2[1024];
   const int lane = threadIdx.x;
   const int c = blockIdx.x;
   const uint8_t* in = args.pay[c];
@@ -55,8 +55,8 @@ __global__ void __launch_bounds__(64) k_fpc32_decode(DecodeArgs args, int arity,
     if (lane == 0) atomicOr(status, 2u);
     return;
     }
-  for (int i = lane; i < 1024; i += 64)
-    T2[i] = 0u;
+  // DFCM table (up to 1024 entries) in 16 VGPRs: entry e lives in register e & 15, lane e >> 4
+  u32x16 T2 = (u32x16)(0u);
   const uint32_t m1 = (1u << e1) - 1u, m2 = (1u << e2) - 1u, sh1 = 32u - e1, sh2 = 32u - e2, e2h = e2 >> 1;
   // window over the payload, in units of aligned dwords of the underlying buffer
   const uint32_t al = (uint32_t)((uintptr_t)in & 3u);
@@ -123,13 +123,16 @@ __global__ void __launch_bounds__(64) k_fpc32_decode(DecodeArgs args, int arity,
         const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)xr, (int)k);
         uint32_t p = p1;
         if (ck > 4u)
-          p = p2 + T2[h2];                                 // decoder keeps value + stride (fpsc.c:323)
+          p = p2 + (uint32_t)__builtin_amdgcn_readlane((int)T2[h2 & 15u], (int)(h2 >> 4));   // value + stride (fpsc.c:323)
         const uint32_t v = x ^ p;
         T1 = ((uint32_t)lane == h1) ? v : T1;             // v_writelane semantics via compare + select
         h1 = ((h1 << e1) ^ (v >> sh1)) & m1;
         p1 = (uint32_t)__builtin_amdgcn_readlane((int)T1, (int)h1);
         const uint32_t s = v - last;
-        T2[h2] = s;
+        {
+        const uint32_t r = h2 & 15u;
+        T2[r] = ((uint32_t)lane == (h2 >> 4)) ? s : T2[r];
+        }
         h2 = ((h2 << e2h) ^ (s >> sh2)) & m2;
         p2 = v;
         last = v;

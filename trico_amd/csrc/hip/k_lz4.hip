@@ -1,13 +1,17 @@
-// k_lz4.hip — wave-cooperative LZ4 block compressor / decompressor, one wave per byte plane.
+// k_lz4.hip — LZ4 block compressor / decompressor, one 1024-thread workgroup per byte plane.
 //
 // Compressor: byte-exact with LZ4 1.9.2's LZ4_compress_default as Trico calls it (trico.c:343-368 ->
 // lz4.c:1271 -> 1184 -> LZ4_compress_generic lz4.c:793-1181, notLimited, byU16 below 65547 input
 // bytes else byU32, noDict, acceleration 1).  The greedy parse is one dependent chain per plane (the
-// table content depends on the whole parse history), so the control flow is wave-uniform and only the
-// data-parallel parts are spread over the 64 lanes: match-length counting (LZ4_count, lz4.c:539-563)
-// compares 512 bytes per iteration, literal runs are copied 64 x 16 bytes per iteration.  The hash
-// table (16 KiB) lives in LDS.  Decompressor: LZ4_decompress_safe semantics (lz4.c:1657-2072) with
-// wide literal copies and wide (period-aware) match copies.
+// hash-table content depends on the whole parse history), so wave 0 runs the control flow
+// wave-uniformly with the 16 KiB table in LDS; a lone wave issues one instruction per ~5-9 cycles on
+// gfx950 (tools/ubench/issue.hip), so everything data-parallel is taken off that wave:
+//   * short match counts / literal copies are done by wave 0's 64 lanes (512 B / 1 KiB per iteration);
+//   * long ones (>= BULK_MIN bytes) are posted as a job to the 15 helper waves parked on a barrier and
+//     done by all 1024 threads, 64 KiB per iteration (LZ4_count, lz4.c:539-563, is a first-mismatch
+//     search: per-wave ballot + LDS atomicMin).
+// Decompressor: LZ4_decompress_safe semantics (lz4.c:1657-2072) with the same job scheme for literal
+// copies and for (period-aware, doubling) match copies.
 //
 // Roofline: HBM-bound only on long matches / long literal runs; otherwise latency-bound on the
 // dependent chain.  Algorithmic bytes per plane byte: 1 read + its share of the block written.
@@ -17,6 +21,9 @@ namespace trico {
 
 namespace {
 
+constexpr int WG = 1024;
+constexpr uint32_t BULK_MIN = 8192;      // bytes from which a count/copy is worth two barriers
+
 struct __attribute__((packed, aligned(1))) u32u { uint32_t v; };
 struct __attribute__((packed, aligned(1))) u64u { uint64_t v; };
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -24,15 +31,138 @@ struct __attribute__((packed, aligned(1))) u128u { u32x4 v; };
 
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return ((const u32u*)p)->v; }
 __device__ __forceinline__ uint64_t ld64(const uint8_t* p) { return ((const u64u*)p)->v; }
+__device__ __forceinline__ u32x4 ld128(const uint8_t* p) { return ((const u128u*)p)->v; }
+__device__ __forceinline__ void st128(uint8_t* p, u32x4 v) { ((u128u*)p)->v = v; }
 
 // wave-uniform value from lane 0 (keeps scalar state in SGPRs)
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
-// number of equal bytes of src[a..] and src[b..], at most `limit` (wave-cooperative LZ4_count)
-__device__ __forceinline__ uint32_t wave_count(const uint8_t* __restrict__ src, uint32_t a, uint32_t b, uint32_t limit, int lane)
+// ---- jobs for the whole workgroup ---------------------------------------------------------------------
+enum { JOB_EXIT = 0, JOB_COUNT = 1, JOB_COPY = 2 };
+struct Job
+  {
+  uint32_t kind;
+  uint32_t n;               // bytes to count / copy
+  const uint8_t* a;         // count: first stream;  copy: source
+  const uint8_t* b;         // count: second stream; copy: destination (cast)
+  uint32_t result;          // count: number of equal bytes
+  };
+
+// all WG threads: equal-byte count of a[] and b[] up to n, result in job->result (<= n)
+__device__ __forceinline__ void wg_count(Job* job, int tid)
+  {
+  const uint8_t* a = job->a;
+  const uint8_t* b = job->b;
+  const uint32_t n = job->n;
+  for (uint32_t base = 0; base < n; base += WG * 64u)
+    {
+    uint32_t first = 0xffffffffu;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      {
+      const uint32_t o = base + (uint32_t)q * WG * 16u + 16u * (uint32_t)tid;
+      if (o + 16u <= n)
+        {
+        const u32x4 x = ld128(a + o), y = ld128(b + o);
+        const uint64_t d0 = ((uint64_t)(x.y ^ y.y) << 32) | (x.x ^ y.x), d1 = ((uint64_t)(x.w ^ y.w) << 32) | (x.z ^ y.z);
+        if (d0 | d1)
+          {
+          const uint32_t e = d0 ? (uint32_t)__builtin_ctzll(d0) >> 3 : 8u + ((uint32_t)__builtin_ctzll(d1) >> 3);
+          first = min(first, o + e);
+          }
+        }
+      else if (o < n)
+        {
+        for (uint32_t k = o; k < n; ++k)
+          if (a[k] != b[k]) { first = min(first, k); break; }
+        }
+      }
+    if (first != 0xffffffffu)
+      atomicMin(&job->result, first);
+    __syncthreads();
+    const uint32_t r = job->result;          // read between two barriers: wave 0 may republish right after
+    __syncthreads();
+    if (r < n)
+      return;
+    }
+  }
+
+// all WG threads: b[0..n) = a[0..n) (non-overlapping)
+__device__ __forceinline__ void wg_copy(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n, int tid)
+  {
+  const uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+  const uint32_t h = head < n ? head : n;
+  if ((uint32_t)tid < h)
+    dst[tid] = src[tid];
+  uint32_t i = h + 16u * (uint32_t)tid;
+  for (; i + 16u <= n; i += WG * 16u)
+    *(u32x4*)(dst + i) = ld128(src + i);
+  // tail: fewer than 16 bytes left for exactly one thread
+  if (i < n && n - i < 16u)
+    for (uint32_t k = i; k < n; ++k)
+      dst[k] = src[k];
+  }
+
+// helper waves: park on the barrier, run jobs until JOB_EXIT
+__device__ __forceinline__ void helper_loop(Job* job, int tid)
+  {
+  for (;;)
+    {
+    __syncthreads();                        // job published
+    const uint32_t kind = job->kind;
+    if (kind == JOB_EXIT)
+      return;
+    if (kind == JOB_COUNT)
+      wg_count(job, tid);
+    else
+      {
+      wg_copy((uint8_t*)job->b, job->a, job->n, tid);
+      __syncthreads();
+      }
+    }
+  }
+
+// wave 0: run a job with the whole workgroup
+__device__ __forceinline__ uint32_t run_count(Job* job, const uint8_t* a, const uint8_t* b, uint32_t n, int tid)
+  {
+  if (tid == 0)
+    {
+    job->kind = JOB_COUNT; job->a = a; job->b = b; job->n = n; job->result = n;
+    }
+  __syncthreads();
+  wg_count(job, tid);
+  // wg_count leaves every thread after a barrier at which job->result is final
+  return uni(job->result);
+  }
+
+__device__ __forceinline__ void run_copy(Job* job, uint8_t* dst, const uint8_t* src, uint32_t n, int tid)
+  {
+  __builtin_amdgcn_s_waitcnt(0);
+  if (tid == 0)
+    {
+    job->kind = JOB_COPY; job->a = src; job->b = (const uint8_t*)dst; job->n = n;
+    }
+  __syncthreads();
+  wg_copy(dst, src, n, tid);
+  __syncthreads();
+  }
+
+__device__ __forceinline__ void run_exit(Job* job, int tid)
+  {
+  if (tid == 0)
+    job->kind = JOB_EXIT;
+  __syncthreads();
+  }
+
+// ---- wave-level primitives (wave 0 only) ----------------------------------------------------------------
+
+// number of equal bytes of a[] and b[], at most `limit`
+__device__ __forceinline__ uint32_t wave_count(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint32_t limit, int lane,
+                                               uint32_t max_bytes)
   {
   uint32_t done = 0;
-  while (done < limit)
+  const uint32_t lim = limit < max_bytes ? limit : max_bytes;
+  while (done < lim)
     {
     const uint32_t o = done + 8u * (uint32_t)lane;
     uint64_t x = 0;
@@ -41,10 +171,10 @@ __device__ __forceinline__ uint32_t wave_count(const uint8_t* __restrict__ src, 
       {
       valid = limit - o < 8u ? limit - o : 8u;
       if (valid == 8u)
-        x = ld64(src + a + o) ^ ld64(src + b + o);
+        x = ld64(a + o) ^ ld64(b + o);
       else
         for (uint32_t k = 0; k < valid; ++k)
-          x |= (uint64_t)(src[a + o + k] ^ src[b + o + k]) << (8u * k);
+          x |= (uint64_t)(a[o + k] ^ b[o + k]) << (8u * k);
       }
     const uint32_t eq = x ? (uint32_t)__builtin_ctzll(x) >> 3 : valid;     // equal bytes in this lane's window
     const uint64_t stop = __ballot(eq < 8u);                                // lanes where the run ends (mismatch or limit)
@@ -56,10 +186,10 @@ __device__ __forceinline__ uint32_t wave_count(const uint8_t* __restrict__ src, 
       }
     done += 512u;
     }
-  return limit;
+  return done;          // all of the first `done` bytes are equal (done >= lim)
   }
 
-// dst[0..n) = src[0..n), non-overlapping, any alignment, all lanes participate
+// dst[0..n) = src[0..n), non-overlapping, any alignment
 __device__ __forceinline__ void wave_copy(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n, int lane)
   {
   uint32_t i = 0;
@@ -70,14 +200,28 @@ __device__ __forceinline__ void wave_copy(uint8_t* __restrict__ dst, const uint8
       dst[lane] = src[lane];
     i = head;
     for (; i + 1024u <= n; i += 1024u)
-      {
-      const u32x4 v = ((const u128u*)(src + i + 16u * lane))->v;
-      *(u32x4*)(dst + i + 16u * lane) = v;
-      }
+      *(u32x4*)(dst + i + 16u * lane) = ld128(src + i + 16u * lane);
     }
   for (; i < n; i += 64u)
     if (i + lane < n)
       dst[i + lane] = src[i + lane];
+  }
+
+__device__ __forceinline__ uint32_t any_count(Job* job, const uint8_t* a, const uint8_t* b, uint32_t limit, int tid)
+  {
+  // probe the first BULK_MIN bytes with the wave; continue with the workgroup if they are all equal
+  uint32_t m = wave_count(a, b, limit, tid, BULK_MIN);
+  if (m >= BULK_MIN && m < limit)
+    m += run_count(job, a + m, b + m, limit - m, tid);
+  return m;
+  }
+
+__device__ __forceinline__ void any_copy(Job* job, uint8_t* dst, const uint8_t* src, uint32_t n, int tid)
+  {
+  if (n >= BULK_MIN)
+    run_copy(job, dst, src, n, tid);
+  else
+    wave_copy(dst, src, n, tid);
   }
 
 __device__ __forceinline__ uint8_t* put_len(uint8_t* op, uint32_t len, int lane)
@@ -92,14 +236,21 @@ __device__ __forceinline__ uint8_t* put_len(uint8_t* op, uint32_t len, int lane)
   }
 
 // ---- compressor -----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_lz4_encode_wave(const uint8_t* __restrict__ planes, size_t plane_stride, uint32_t n,
-                                                        uint8_t* __restrict__ out_base, size_t out_stride, uint32_t* __restrict__ sizes)
+__global__ void __launch_bounds__(WG) k_lz4_encode(const uint8_t* __restrict__ planes, size_t plane_stride, uint32_t n,
+                                                   uint8_t* __restrict__ out_base, size_t out_stride, uint32_t* __restrict__ sizes)
   {
   __shared__ uint32_t tab[4096];   // u32[4096] or, for n < 65547, u16[8192] in the same 16 KiB
-  const int lane = threadIdx.x;
-  for (int i = lane; i < 4096; i += 64)
+  __shared__ Job job;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 4096; i += WG)
     tab[i] = 0;
   __syncthreads();
+  if (tid >= 64)
+    {
+    helper_loop(&job, tid);
+    return;
+    }
+  const int lane = tid;
   const uint8_t* src = planes + (size_t)blockIdx.x * plane_stride;
   uint8_t* dst = out_base + (size_t)blockIdx.x * out_stride;
   uint16_t* tab16 = (uint16_t*)tab;
@@ -135,7 +286,7 @@ __global__ void __launch_bounds__(64) k_lz4_encode_wave(const uint8_t* __restric
       if (done) break;
       // catch up (lz4.c:960-961): extend the match backwards over equal bytes
       {
-      uint32_t maxback = ip - anchor < cand ? ip - anchor : cand;
+      const uint32_t maxback = ip - anchor < cand ? ip - anchor : cand;
       uint32_t back = 0;
       while (back < maxback)
         {
@@ -157,7 +308,7 @@ __global__ void __launch_bounds__(64) k_lz4_encode_wave(const uint8_t* __restric
       uint8_t* token = op++;
       uint32_t tok = lit >= 15u ? 0xf0u : (lit << 4);
       if (lit >= 15u) op = put_len(op, lit - 15u, lane);
-      wave_copy(op, src + anchor, lit, lane);
+      any_copy(&job, op, src + anchor, lit, tid);
       op += lit;
       for (;;)
         {
@@ -169,7 +320,7 @@ __global__ void __launch_bounds__(64) k_lz4_encode_wave(const uint8_t* __restric
           }
         op += 2;
         const uint32_t room = mlim > ip + 4u ? mlim - (ip + 4u) : 0u;
-        const uint32_t m = wave_count(src, ip + 4u, cand + 4u, room, lane);
+        const uint32_t m = any_count(&job, src + ip + 4u, src + cand + 4u, room, tid);
         ip += m + 4u;
         if (m >= 15u)
           {
@@ -203,11 +354,12 @@ __global__ void __launch_bounds__(64) k_lz4_encode_wave(const uint8_t* __restric
     *op = run >= 15u ? 0xf0 : (uint8_t)(run << 4);
   op += 1;
   if (run >= 15u) op = put_len(op, run - 15u, lane);
-  wave_copy(op, src + anchor, run, lane);
+  any_copy(&job, op, src + anchor, run, tid);
   op += run;
   }
   if (lane == 0)
     sizes[blockIdx.x] = (uint32_t)(op - dst);
+  run_exit(&job, tid);
 #undef LZ_HASH
 #undef LZ_GET
 #undef LZ_SET
@@ -221,54 +373,33 @@ struct Lz4DecArgs
   };
 
 // dst[0..n) = dst[-off..), the LZ77 overlap-aware copy.  With overlap (off < n) the result is periodic
-// with period `off`: the first P bytes (P = smallest multiple of off >= 4096) are produced with a modulo
-// fill from the bytes before dst, the rest 4 KiB per iteration from P bytes back (already written).
-__device__ __forceinline__ void wave_match_copy(uint8_t* __restrict__ dst, uint32_t off, uint32_t n, int lane)
+// with period `off`: copy one period from before dst, then the already written prefix (a whole number
+// of periods) is replicated by doubling: dst[w .. w+c) = dst[0 .. c), c <= w, non-overlapping copies that
+// go to the whole workgroup once they are long.
+__device__ __forceinline__ void match_copy(Job* job, uint8_t* __restrict__ dst, uint32_t off, uint32_t n, int tid)
   {
-  if (off >= n)
+  uint32_t w = off < n ? off : n;
+  any_copy(job, dst, dst - off, w, tid);
+  while (w < n)
     {
-    wave_copy(dst, dst - off, n, lane);
-    return;
+    __builtin_amdgcn_s_waitcnt(0);                  // the prefix must have landed before it is re-read
+    const uint32_t c = n - w < w ? n - w : w;
+    any_copy(job, dst + w, dst, c, tid);
+    w += c;
     }
-  const uint8_t* period = dst - off;
-  const uint32_t P = off >= 4096u ? off : off * ((4096u + off - 1u) / off);
-  const uint32_t first = n < P ? n : P;
-  if (off >= 64u)
-    {
-    // chunks of 64 bytes only read bytes at least `off` >= 64 back: written by earlier iterations
-    for (uint32_t i = 0; i < first; i += 64u)
-      {
-      if (i + lane < first)
-        dst[i + lane] = period[i + lane];        // (not dst[i + lane - off]: that index wraps as uint32)
-      __builtin_amdgcn_s_waitcnt(0);
-      }
-    }
-  else
-    for (uint32_t i = 0; i < first; i += 64u)
-      if (i + lane < first)
-        dst[i + lane] = period[(i + lane) % off];
-  __builtin_amdgcn_s_waitcnt(0);
-  uint32_t i = first;
-  for (; i + 4096u <= n; i += 4096u)
-    {
-    u32x4 v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      v[q] = ((const u128u*)(dst + i + 1024u * q + 16u * lane - P))->v;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      ((u128u*)(dst + i + 1024u * q + 16u * lane))->v = v[q];
-    __builtin_amdgcn_s_waitcnt(0);
-    }
-  for (; i < n; i += 64u)
-    if (i + lane < n)
-      dst[i + lane] = dst[i + lane - P];
   }
 
-__global__ void __launch_bounds__(64) k_lz4_decode_wave(Lz4DecArgs a, uint8_t* __restrict__ planes, size_t plane_stride, uint32_t cap,
-                                                        uint32_t* __restrict__ status)
+__global__ void __launch_bounds__(WG) k_lz4_decode(Lz4DecArgs a, uint8_t* __restrict__ planes, size_t plane_stride, uint32_t cap,
+                                                   uint32_t* __restrict__ status)
   {
-  const int lane = threadIdx.x;
+  __shared__ Job job;
+  const int tid = threadIdx.x;
+  if (tid >= 64)
+    {
+    helper_loop(&job, tid);
+    return;
+    }
+  const int lane = tid;
   const uint8_t* src = a.pay[blockIdx.x];
   const uint32_t n = a.size[blockIdx.x];
   uint8_t* dst = planes + (size_t)blockIdx.x * plane_stride;
@@ -287,7 +418,7 @@ __global__ void __launch_bounds__(64) k_lz4_decode_wave(Lz4DecArgs a, uint8_t* _
       if (bad) break;
       }
     if (lit > n - ip || lit > cap - op) { bad = true; break; }
-    wave_copy(dst + op, src + ip, lit, lane);
+    any_copy(&job, dst + op, src + ip, lit, tid);
     ip += lit; op += lit;
     if (ip == n) break;                                   // last sequence: literals only
     if (n - ip < 2u) { bad = true; break; }
@@ -303,13 +434,13 @@ __global__ void __launch_bounds__(64) k_lz4_decode_wave(Lz4DecArgs a, uint8_t* _
       }
     ml += 4u;
     if (ml > cap - op) { bad = true; break; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_s_waitcnt(0);                        // earlier stores of this wave must land before they are re-read
-    wave_match_copy(dst + op, off, ml, lane);
+    match_copy(&job, dst + op, off, ml, tid);
     op += ml;
     }
   if ((bad || op != cap) && lane == 0)
     atomicOr(status, 8u);
+  run_exit(&job, tid);
   }
 
 } // namespace
@@ -317,9 +448,9 @@ __global__ void __launch_bounds__(64) k_lz4_decode_wave(Lz4DecArgs a, uint8_t* _
 int launch_lz4_encode_wave(const uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, int nplanes, uint8_t* d_out,
                            size_t out_stride, uint32_t* d_sizes)
   {
-  hipLaunchKernelGGL(k_lz4_encode_wave, dim3(nplanes), dim3(64), 0, current_stream(),
+  hipLaunchKernelGGL(k_lz4_encode, dim3(nplanes), dim3(WG), 0, current_stream(),
                      d_planes, plane_stride, plane_bytes, d_out, out_stride, d_sizes);
-  return hip_ok(hipGetLastError(), "k_lz4_encode_wave") ? 1 : 0;
+  return hip_ok(hipGetLastError(), "k_lz4_encode") ? 1 : 0;
   }
 
 int launch_lz4_decode_wave(const uint8_t* const d_payloads[8], const uint32_t sizes[8], int nplanes,
@@ -331,9 +462,9 @@ int launch_lz4_decode_wave(const uint8_t* const d_payloads[8], const uint32_t si
     a.pay[c] = c < nplanes ? d_payloads[c] : nullptr;
     a.size[c] = c < nplanes ? sizes[c] : 0;
     }
-  hipLaunchKernelGGL(k_lz4_decode_wave, dim3(nplanes), dim3(64), 0, current_stream(),
+  hipLaunchKernelGGL(k_lz4_decode, dim3(nplanes), dim3(WG), 0, current_stream(),
                      a, d_planes, plane_stride, plane_bytes, d_status);
-  return hip_ok(hipGetLastError(), "k_lz4_decode_wave") ? 1 : 0;
+  return hip_ok(hipGetLastError(), "k_lz4_decode") ? 1 : 0;
   }
 
 } // namespace trico

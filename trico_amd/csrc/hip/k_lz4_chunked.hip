@@ -1,0 +1,648 @@
+// k_lz4_chunked.hip — chunk-speculative, byte-exact LZ4 1.9.2 block compressor for large byte planes.
+//
+// Problem: LZ4_compress_generic (lz4.c:793-1181) is one dependent chain per plane: the 4096-entry hash
+// table depends on the whole parse history, and Trico compresses each plane as ONE block (trico.c:343-368).
+// A lone wave needs microseconds per sequence, and a 300 MB plane can hold millions of sequences.
+//
+// Observation that makes an exact parallel parse possible: the parser's behaviour from a point p on
+// depends on the table only through entries within 65535 bytes of p (lz4.c:945-948: older candidates are
+// rejected before they are even read), and every match end is a clean synchronisation point with
+// anchor == ip.  So:
+//   parse   (k_lz4_parse):  chunk k > 0 starts WARM bytes before its start with an empty table and
+//            parses speculatively.  At the first match end at or after the chunk start it snapshots
+//            (ip, table) and from there records its sequences as descriptors until the first match end
+//            at or after the chunk end, where it stores its end state.  Chunk 0 is the true parse.
+//   stitch  (k_lz4_stitch): walks the chain: the end state of the last accepted chunk lies in some chunk
+//            j; chunk j's speculation is accepted iff its snapshot is at the same ip and its table is
+//            equal entry by entry, except where both entries are already out of range at ip.  From an
+//            equivalent state the deterministic parser produces identical sequences, so accepted output
+//            is exactly the reference's.  Otherwise chunk j is re-parsed from the true state (exact, just
+//            slower).  Worst case = the serial parse; typical case = all chunks accepted.
+//   sizes / offsets / emit: descriptors -> encoded byte counts -> exclusive scan -> block bytes
+//            (token, length extension bytes, literals, offset) written in parallel.
+// The descriptor form also takes literal copying off the parsing waves.
+#include "common.hpp"
+#include <stdlib.h>
+
+namespace trico {
+
+namespace {
+
+constexpr uint32_t MAXD = 65535u;          // LZ4_DISTANCE_MAX (lz4.h:535)
+constexpr int EMIT_T = 256;
+
+struct __attribute__((packed, aligned(1))) u32u { uint32_t v; };
+struct __attribute__((packed, aligned(1))) u64u { uint64_t v; };
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(1))) u128u { u32x4 v; };
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return ((const u32u*)p)->v; }
+__device__ __forceinline__ uint64_t ld64(const uint8_t* p) { return ((const u64u*)p)->v; }
+__device__ __forceinline__ u32x4 ld128(const uint8_t* p) { return ((const u128u*)p)->v; }
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint32_t hash5(const uint8_t* p) { return (uint32_t)(((ld64(p) << 24) * 889523592379ull) >> 52); }   // lz4.c:643-648
+
+struct Desc { uint32_t lit, ml, off; };    // literal run, match length incl. MINMATCH (0 = final run), offset
+
+enum { END_NONE = 0, END_MATCH = 1, END_FINAL = 2 };
+struct Meta
+  {
+  uint32_t snap_valid, snap_ip;            // first match end at or after the chunk start (speculative chunks)
+  uint32_t end_kind, end_ip;               // END_MATCH: state after a match ended at end_ip; END_FINAL: block finished
+  uint32_t ndesc;
+  uint32_t accepted;                        // set by the stitch pass
+  uint32_t first_in;                        // input position where this chunk's first descriptor starts
+  uint32_t reparsed;
+  };
+
+// number of equal bytes of a[] and b[], at most `limit`; 4 KiB per iteration
+__device__ __forceinline__ uint32_t wave_count(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint32_t limit, int lane)
+  {
+  uint32_t done = 0;
+  // short probe first: most matches are short
+  {
+  const uint32_t o = 8u * (uint32_t)lane;
+  uint64_t x = 0;
+  uint32_t valid = 0;
+  if (o < limit)
+    {
+    valid = limit - o < 8u ? limit - o : 8u;
+    if (valid == 8u)
+      x = ld64(a + o) ^ ld64(b + o);
+    else
+      for (uint32_t k = 0; k < valid; ++k)
+        x |= (uint64_t)(a[o + k] ^ b[o + k]) << (8u * k);
+    }
+  const uint32_t eq = x ? (uint32_t)__builtin_ctzll(x) >> 3 : valid;
+  const uint64_t stop = __ballot(eq < 8u);
+  if (stop)
+    {
+    const int first = __builtin_ctzll(stop);
+    return 8u * (uint32_t)first + (uint32_t)__builtin_amdgcn_readlane((int)eq, first);
+    }
+  done = 512u;
+  }
+  while (done < limit)
+    {
+    uint32_t first = 0xffffffffu;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      {
+      const uint32_t o = done + 1024u * (uint32_t)q + 16u * (uint32_t)lane;
+      if (o + 16u <= limit)
+        {
+        const u32x4 x = ld128(a + o), y = ld128(b + o);
+        const uint64_t d0 = ((uint64_t)(x.y ^ y.y) << 32) | (x.x ^ y.x), d1 = ((uint64_t)(x.w ^ y.w) << 32) | (x.z ^ y.z);
+        if (d0 | d1)
+          first = min(first, o + (d0 ? (uint32_t)__builtin_ctzll(d0) >> 3 : 8u + ((uint32_t)__builtin_ctzll(d1) >> 3)));
+        }
+      else if (o < limit)
+        {
+        uint32_t k = o;
+        while (k < limit && a[k] == b[k]) ++k;
+        first = min(first, k);                 // k == limit also ends the count
+        }
+      else
+        first = min(first, limit);
+      }
+    // wave minimum of `first`
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1)
+      first = min(first, (uint32_t)__shfl_xor((int)first, s));
+    if (first != 0xffffffffu)
+      return first < limit ? first : limit;
+    done += 4096u;
+    }
+  return limit;
+  }
+
+// The parser.  One wave; `tab` (LDS, 4096 x u32) holds the table for the start state.
+//   start_match_end: true  -> state "a match just ended at ip0" (anchor == ip0), table = tab
+//                    false -> state "search loop starts at ip0" (anchor == ip0), table = tab
+//   fresh: chunk 0 start (lz4.c:865-867: insert position 0, ip = 1)
+//   emit_from_start: record descriptors from the first sequence on (chunk 0, re-parse); otherwise wait for
+//                    the first match end >= c_lo, snapshot there, then record
+// Stops at the first match end >= c_hi (END_MATCH) or at the end of the block (END_FINAL).
+__device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t* tab, uint32_t ip0, bool start_match_end, bool fresh,
+                          bool emit_from_start, uint32_t c_lo, uint32_t c_hi, Desc* __restrict__ desc, uint32_t dcap,
+                          Meta* __restrict__ meta, uint32_t* __restrict__ snapT, uint32_t* __restrict__ endT, int lane)
+  {
+  const uint32_t mfl1 = n - 11u, mlim = n - 5u;                                    // lz4.c:825-826 (n >= 13 here)
+  bool emit = emit_from_start;
+  uint32_t nd = 0;
+  uint32_t ip = ip0, anchor = ip0;
+  uint32_t end_kind = END_NONE, end_ip = 0;
+  uint32_t first_in = ip0;
+  uint32_t fh = 0;
+  bool at_match_end = start_match_end;
+  if (fresh)
+    {
+    if (lane == 0) tab[uni(hash5(src))] = 0u;
+    ip = 1;
+    anchor = 0;
+    first_in = 0;
+    fh = uni(hash5(src + 1));
+    at_match_end = false;
+    }
+  else if (!start_match_end)
+    fh = uni(hash5(src + ip));
+  bool overflow = false;
+  for (;;)
+    {
+    uint32_t cand = 0;
+    bool have_match = false;
+    uint8_t tok_lit0 = 0;
+    (void)tok_lit0;
+    if (at_match_end)
+      {
+      // ---- state: a match ended at ip, anchor == ip ----
+      if (!emit && ip >= c_lo)
+        {
+        // snapshot (speculative chunk): from here on sequences are recorded
+        for (int i = lane; i < 4096; i += 64)
+          snapT[i] = tab[i];
+        if (lane == 0) { meta->snap_valid = 1u; meta->snap_ip = ip; }
+        emit = true;
+        first_in = ip;
+        }
+      if (emit && ip >= c_hi)
+        {
+        end_kind = END_MATCH;
+        end_ip = ip;
+        break;
+        }
+      if (!emit && ip >= c_hi)
+        break;                                                                     // useless speculation: no match end inside the chunk
+      if (ip >= mfl1)                                                              // lz4.c:1085 "Test end of chunk"
+        {
+        // final literals follow
+        if (emit)
+          {
+          if (nd < dcap) { if (lane == 0) { desc[nd].lit = n - anchor; desc[nd].ml = 0; desc[nd].off = 0; } ++nd; }
+          else overflow = true;
+          end_kind = END_FINAL;
+          end_ip = n;
+          }
+        break;
+        }
+      if (lane == 0) tab[uni(hash5(src + ip - 2))] = ip - 2u;                      // lz4.c:1088
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const uint32_t h = uni(hash5(src + ip));
+      cand = uni(tab[h]);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (lane == 0) tab[h] = ip;
+      if (cand + MAXD >= ip && uni(ld32(src + cand)) == uni(ld32(src + ip)))
+        have_match = true;                                                         // lz4.c:1101-1138: literal length 0, no catch-up
+      else
+        {
+        ++ip;
+        fh = uni(hash5(src + ip));
+        }
+      at_match_end = false;
+      }
+    if (!have_match)
+      {
+      // ---- search loop (lz4.c:898-956) ----
+      uint32_t fwd = ip, step = 1, nb = 64;
+      bool final = false;
+      for (;;)
+        {
+        const uint32_t h = fh, cur = fwd;
+        cand = uni(tab[h]);
+        ip = fwd;
+        fwd += step;
+        step = nb++ >> 6;
+        if (fwd > mfl1) { final = true; break; }
+        fh = uni(hash5(src + fwd));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane == 0) tab[h] = cur;
+        if (cand + MAXD < cur) continue;
+        if (uni(ld32(src + cand)) == uni(ld32(src + ip))) break;
+        }
+      if (final)
+        {
+        if (emit)
+          {
+          if (nd < dcap) { if (lane == 0) { desc[nd].lit = n - anchor; desc[nd].ml = 0; desc[nd].off = 0; } ++nd; }
+          else overflow = true;
+          end_kind = END_FINAL;
+          end_ip = n;
+          }
+        break;
+        }
+      // catch up (lz4.c:960-961)
+      const uint32_t maxback = ip - anchor < cand ? ip - anchor : cand;
+      uint32_t back = 0;
+      while (back < maxback)
+        {
+        const uint32_t k = back + (uint32_t)lane + 1u;
+        const bool eq = k <= maxback && src[ip - k] == src[cand - k];
+        const uint64_t ne = ~__ballot(eq);
+        if (ne)
+          {
+          back += (uint32_t)__builtin_ctzll(ne);
+          break;
+          }
+        back += 64u;
+        }
+      if (back > maxback) back = maxback;
+      ip -= back;
+      cand -= back;
+      }
+    // ---- a match starts at ip against cand (lz4.c:1007-1077) ----
+    if (!emit && ip + 4u >= c_hi)
+      break;                                                                       // warm-up ran past the chunk: useless speculation
+    const uint32_t room = mlim > ip + 4u ? mlim - (ip + 4u) : 0u;
+    uint32_t limit = room;
+    if (!emit && ip + 4u < c_hi)
+      {
+      // warm-up: a match running past the chunk end makes this speculation useless; don't count further
+      const uint32_t cap = c_hi - (ip + 4u);
+      if (cap < limit) limit = cap;
+      }
+    const uint32_t m = wave_count(src + ip + 4u, src + cand + 4u, limit, lane);
+    if (!emit && limit < room && m >= limit)
+      break;                                                                       // ran past c_hi during warm-up
+    if (emit)
+      {
+      if (nd < dcap) { if (lane == 0) { desc[nd].lit = ip - anchor; desc[nd].ml = m + 4u; desc[nd].off = ip - cand; } ++nd; }
+      else { overflow = true; break; }
+      }
+    ip += m + 4u;
+    anchor = ip;
+    at_match_end = true;
+    }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (end_kind == END_MATCH)
+    for (int i = lane; i < 4096; i += 64)
+      endT[i] = tab[i];
+  if (lane == 0)
+    {
+    meta->end_kind = overflow ? END_NONE : end_kind;
+    meta->end_ip = end_ip;
+    meta->ndesc = nd;
+    meta->first_in = first_in;
+    }
+  }
+
+struct Geom { uint32_t n, chunk, warm, K, dcap; size_t plane_stride; };
+
+__global__ void __launch_bounds__(64) k_lz4_parse(const uint8_t* __restrict__ planes, Geom g, Desc* __restrict__ descs, Meta* __restrict__ metas,
+                                                  uint32_t* __restrict__ snapTs, uint32_t* __restrict__ endTs)
+  {
+  __shared__ uint32_t tab[4096];
+  const int lane = threadIdx.x;
+  const uint32_t k = blockIdx.x, p = blockIdx.y;
+  for (int i = lane; i < 4096; i += 64)
+    tab[i] = 0u;
+  __syncthreads();
+  const size_t ck = (size_t)p * g.K + k;
+  Meta* meta = metas + ck;
+  if (lane == 0)
+    {
+    meta->snap_valid = 0; meta->snap_ip = 0; meta->end_kind = END_NONE; meta->end_ip = 0; meta->ndesc = 0; meta->accepted = 0;
+    meta->first_in = 0; meta->reparsed = 0;
+    }
+  const uint8_t* src = planes + (size_t)p * g.plane_stride;
+  const uint32_t c_lo = k * g.chunk;
+  const uint32_t c_hi = (k + 1u == g.K) ? 0xffffffffu : c_lo + g.chunk;
+  lz4_parse(src, g.n, tab, k == 0 ? 0u : c_lo - g.warm, false, k == 0, k == 0, c_lo, c_hi, descs + ck * g.dcap, g.dcap, meta,
+            snapTs + ck * 4096, endTs + ck * 4096, lane);
+  }
+
+// one wave per plane: accept speculative chunks whose snapshot is equivalent to the true state, re-parse the others
+__global__ void __launch_bounds__(64) k_lz4_stitch(const uint8_t* __restrict__ planes, Geom g, Desc* __restrict__ descs, Meta* __restrict__ metas,
+                                                   uint32_t* __restrict__ snapTs, uint32_t* __restrict__ endTs, uint32_t* __restrict__ status)
+  {
+  __shared__ uint32_t tab[4096];
+  const int lane = threadIdx.x;
+  const uint32_t p = blockIdx.x;
+  const uint8_t* src = planes + (size_t)p * g.plane_stride;
+  Meta* pm = metas + (size_t)p * g.K;
+  uint32_t cur = 0;                               // last accepted chunk
+  if (lane == 0) pm[0].accepted = 1u;
+  for (uint32_t guard = 0; guard < g.K + 2u; ++guard)
+    {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    const uint32_t kind = uni(pm[cur].end_kind), ip = uni(pm[cur].end_ip);
+    if (kind == END_FINAL)
+      return;
+    if (kind != END_MATCH)
+      {
+      if (lane == 0) atomicOr(status, 16u);      // descriptor overflow / parser did not finish: must not happen
+      return;
+      }
+    uint32_t j = ip / g.chunk;
+    if (j >= g.K) j = g.K - 1u;
+    if (j <= cur)
+      {
+      if (lane == 0) atomicOr(status, 32u);      // no forward progress: must not happen
+      return;
+      }
+    const uint32_t* curT = endTs + ((size_t)p * g.K + cur) * 4096;
+    const uint32_t* snT = snapTs + ((size_t)p * g.K + j) * 4096;
+    bool ok = uni(pm[j].snap_valid) != 0u && uni(pm[j].snap_ip) == ip && uni(pm[j].end_kind) != END_NONE;
+    if (ok)
+      {
+      bool same = true;
+      for (int i = lane; i < 4096; i += 64)
+        {
+        const uint32_t a = curT[i], b = snT[i];
+        same = same && (a == b || (a + MAXD < ip && b + MAXD < ip));
+        }
+      ok = __ballot(!same) == 0ull;
+      }
+    if (!ok)
+      {
+      // exact re-parse of chunk j from the true state
+      for (int i = lane; i < 4096; i += 64)
+        tab[i] = curT[i];
+      __syncthreads();
+      const uint32_t c_hi = (j + 1u == g.K) ? 0xffffffffu : (j + 1u) * g.chunk;
+      const size_t cj = (size_t)p * g.K + j;
+      lz4_parse(src, g.n, tab, ip, true, false, true, j * g.chunk, c_hi, descs + cj * g.dcap, g.dcap, pm + j,
+                snapTs + cj * 4096, endTs + cj * 4096, lane);
+      if (lane == 0) pm[j].reparsed = 1u;
+      __syncthreads();
+      }
+    if (lane == 0)
+      {
+      pm[j].accepted = 1u;
+      atomicAdd(status + 1, 1u);                 // statistics: accepted chunks, re-parsed chunks
+      if (!ok) atomicAdd(status + 2, 1u);
+      }
+    cur = j;
+    }
+  if (lane == 0) atomicOr(status, 64u);
+  }
+
+__device__ __forceinline__ uint32_t ext_bytes(uint32_t len) { return len >= 15u ? (len - 15u) / 255u + 1u : 0u; }
+__device__ __forceinline__ uint32_t enc_size(const Desc& d)
+  {
+  uint32_t s = 1u + ext_bytes(d.lit) + d.lit;
+  if (d.ml)
+    s += 2u + ext_bytes(d.ml - 4u);
+  return s;
+  }
+
+// encoded bytes of every accepted chunk
+__global__ void __launch_bounds__(256) k_lz4_sizes(Geom g, const Desc* __restrict__ descs, const Meta* __restrict__ metas,
+                                                   uint32_t* __restrict__ chunk_bytes)
+  {
+  __shared__ uint32_t red[256];
+  const uint32_t k = blockIdx.x, p = blockIdx.y;
+  const size_t ck = (size_t)p * g.K + k;
+  uint32_t sum = 0;
+  if (metas[ck].accepted)
+    {
+    const Desc* d = descs + ck * g.dcap;
+    const uint32_t nd = metas[ck].ndesc;
+    for (uint32_t i = threadIdx.x; i < nd; i += 256u)
+      sum += enc_size(d[i]);
+    }
+  red[threadIdx.x] = sum;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1)
+    {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+    }
+  if (threadIdx.x == 0)
+    chunk_bytes[ck] = red[0];
+  }
+
+// exclusive scan of chunk sizes per plane (accepted chunks are in increasing order)
+__global__ void __launch_bounds__(1024) k_lz4_offsets(Geom g, const uint32_t* __restrict__ chunk_bytes, uint32_t* __restrict__ chunk_off,
+                                                      uint32_t* __restrict__ sizes)
+  {
+  __shared__ uint32_t part[1024];
+  const uint32_t p = blockIdx.x;
+  const uint32_t per = (g.K + 1023u) / 1024u;
+  const uint32_t k0 = threadIdx.x * per, k1 = (k0 + per < g.K) ? k0 + per : g.K;
+  uint32_t sum = 0;
+  for (uint32_t k = k0; k < k1; ++k)
+    sum += chunk_bytes[(size_t)p * g.K + k];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (uint32_t o = 1; o < 1024u; o <<= 1)
+    {
+    const uint32_t add = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+    }
+  uint32_t run = part[threadIdx.x] - sum;
+  for (uint32_t k = k0; k < k1; ++k)
+    {
+    chunk_off[(size_t)p * g.K + k] = run;
+    run += chunk_bytes[(size_t)p * g.K + k];
+    }
+  if (threadIdx.x == 1023u)
+    sizes[p] = part[1023];
+  }
+
+// block-wide copy / fill helpers for the emit pass
+__device__ __forceinline__ void block_copy(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n, int tid)
+  {
+  const uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+  const uint32_t h = head < n ? head : n;
+  if ((uint32_t)tid < h)
+    dst[tid] = src[tid];
+  uint32_t i = h + 16u * (uint32_t)tid;
+  for (; i + 16u <= n; i += EMIT_T * 16u)
+    *(u32x4*)(dst + i) = ld128(src + i);
+  if (i < n && n - i < 16u)
+    for (uint32_t k = i; k < n; ++k)
+      dst[k] = src[k];
+  }
+
+// writes the block bytes of every accepted chunk
+__global__ void __launch_bounds__(EMIT_T) k_lz4_emit(const uint8_t* __restrict__ planes, Geom g, const Desc* __restrict__ descs,
+                                                     const Meta* __restrict__ metas, const uint32_t* __restrict__ chunk_off,
+                                                     uint8_t* __restrict__ out_base, size_t out_stride)
+  {
+  __shared__ uint32_t sc_out[EMIT_T], sc_in[EMIT_T];
+  __shared__ uint32_t jobs[EMIT_T];
+  __shared__ uint32_t njobs;
+  const uint32_t k = blockIdx.x, p = blockIdx.y;
+  const size_t ck = (size_t)p * g.K + k;
+  if (!metas[ck].accepted)
+    return;
+  const int tid = threadIdx.x;
+  const uint8_t* src = planes + (size_t)p * g.plane_stride;
+  uint8_t* out = out_base + (size_t)p * out_stride;
+  const Desc* dl = descs + ck * g.dcap;
+  const uint32_t nd = metas[ck].ndesc;
+  uint32_t carry_out = chunk_off[ck], carry_in = metas[ck].first_in;
+  for (uint32_t base = 0; base < nd; base += EMIT_T)
+    {
+    const uint32_t i = base + (uint32_t)tid;
+    Desc d; d.lit = 0; d.ml = 0; d.off = 0;
+    uint32_t es = 0, is = 0;
+    if (i < nd)
+      {
+      d = dl[i];
+      es = enc_size(d);
+      is = d.lit + d.ml;
+      }
+    sc_out[tid] = es;
+    sc_in[tid] = is;
+    if (tid == 0) njobs = 0;
+    __syncthreads();
+    for (int o = 1; o < EMIT_T; o <<= 1)
+      {
+      const uint32_t a = tid >= o ? sc_out[tid - o] : 0u, b = tid >= o ? sc_in[tid - o] : 0u;
+      __syncthreads();
+      sc_out[tid] += a;
+      sc_in[tid] += b;
+      __syncthreads();
+      }
+    const uint32_t opos = carry_out + sc_out[tid] - es, ipos = carry_in + sc_in[tid] - is;
+    if (i < nd)
+      {
+      uint8_t* o = out + opos;
+      const uint32_t mcode = d.ml ? d.ml - 4u : 0u;
+      const uint32_t tl = d.lit >= 15u ? 15u : d.lit, tm = d.ml ? (mcode >= 15u ? 15u : mcode) : 0u;
+      *o++ = (uint8_t)((tl << 4) | tm);
+      const uint32_t le = ext_bytes(d.lit);
+      const bool long_job = d.lit > 96u || le > 96u || ext_bytes(mcode) > 96u;
+      if (long_job)
+        jobs[atomicAdd(&njobs, 1u)] = (uint32_t)tid;
+      else
+        {
+        if (le)
+          {
+          for (uint32_t q = 0; q + 1u < le; ++q) *o++ = 255;
+          *o++ = (uint8_t)((d.lit - 15u) % 255u);
+          }
+        for (uint32_t q = 0; q < d.lit; ++q) o[q] = src[ipos + q];
+        o += d.lit;
+        if (d.ml)
+          {
+          *o++ = (uint8_t)d.off;
+          *o++ = (uint8_t)(d.off >> 8);
+          const uint32_t me = ext_bytes(mcode);
+          if (me)
+            {
+            for (uint32_t q = 0; q + 1u < me; ++q) *o++ = 255;
+            *o++ = (uint8_t)((mcode - 15u) % 255u);
+            }
+          }
+        }
+      }
+    __syncthreads();
+    // long runs: the whole block works on one descriptor at a time
+    const uint32_t nj = njobs;
+    for (uint32_t jn = 0; jn < nj; ++jn)
+      {
+      const uint32_t t = jobs[jn];
+      const Desc dj = dl[base + t];
+      const uint32_t es_j = enc_size(dj);
+      uint8_t* o = out + (carry_out + sc_out[t] - es_j) + 1u;
+      const uint32_t ip_j = carry_in + sc_in[t] - (dj.lit + dj.ml);
+      const uint32_t le = ext_bytes(dj.lit);
+      if (le)
+        {
+        for (uint32_t q = (uint32_t)tid; q + 1u < le; q += EMIT_T) o[q] = 255;
+        if (tid == 0) o[le - 1u] = (uint8_t)((dj.lit - 15u) % 255u);
+        o += le;
+        }
+      block_copy(o, src + ip_j, dj.lit, tid);
+      o += dj.lit;
+      if (dj.ml)
+        {
+        const uint32_t mcode = dj.ml - 4u;
+        if (tid == 0) { o[0] = (uint8_t)dj.off; o[1] = (uint8_t)(dj.off >> 8); }
+        o += 2;
+        const uint32_t me = ext_bytes(mcode);
+        if (me)
+          {
+          for (uint32_t q = (uint32_t)tid; q + 1u < me; q += EMIT_T) o[q] = 255;
+          if (tid == 0) o[me - 1u] = (uint8_t)((mcode - 15u) % 255u);
+          }
+        }
+      }
+    carry_out += sc_out[EMIT_T - 1];
+    carry_in += sc_in[EMIT_T - 1];
+    __syncthreads();
+    }
+  }
+
+struct Plan { Geom g; size_t off_desc, off_meta, off_snap, off_end, off_cbytes, off_coff, total; };
+
+Plan make_plan(uint32_t n, int nplanes, size_t plane_stride)
+  {
+  static uint32_t chunk = 0, warm = 0;
+  if (!chunk)
+    {
+    const char* e = getenv("TRICO_LZ4_CHUNK");
+    chunk = e ? (uint32_t)atoi(e) : (1u << 20);
+    if (chunk < (1u << 17)) chunk = 1u << 17;
+    const char* w = getenv("TRICO_LZ4_WARM");
+    warm = w ? (uint32_t)atoi(w) : (384u << 10);
+    if (warm < 70000u) warm = 70000u;
+    if (warm > chunk) warm = chunk;
+    }
+  Plan p;
+  p.g.n = n;
+  p.g.chunk = chunk;
+  p.g.warm = warm;
+  p.g.K = (uint32_t)(((uint64_t)n + chunk - 1) / chunk);
+  p.g.dcap = chunk / 4u + 16u;
+  p.g.plane_stride = plane_stride;
+  const size_t cells = (size_t)p.g.K * nplanes;
+  size_t o = 0;
+  p.off_desc = o;   o += align_up(cells * p.g.dcap * sizeof(Desc), 256);
+  p.off_meta = o;   o += align_up(cells * sizeof(Meta), 256);
+  p.off_snap = o;   o += cells * 4096 * 4;
+  p.off_end = o;    o += cells * 4096 * 4;
+  p.off_cbytes = o; o += align_up(cells * 4, 256);
+  p.off_coff = o;   o += align_up(cells * 4, 256);
+  p.total = o + 256;
+  return p;
+  }
+
+} // namespace
+
+// planes at or above this size take the chunked path (below, one workgroup per plane is faster)
+uint32_t lz4_chunked_threshold()
+  {
+  static uint32_t t = 0;
+  if (!t)
+    {
+    const char* e = getenv("TRICO_LZ4_CHUNKED_MIN");
+    t = e ? (uint32_t)atoi(e) : (4u << 20);
+    if (t < 65547u) t = 65547u;
+    }
+  return t;
+  }
+
+size_t lz4_chunked_workspace(uint32_t n, int nplanes, size_t plane_stride)
+  {
+  return make_plan(n, nplanes, plane_stride).total;
+  }
+
+int launch_lz4_encode_chunked(const uint8_t* d_planes, size_t plane_stride, uint32_t n, int nplanes, uint8_t* d_out, size_t out_stride,
+                              uint32_t* d_sizes, uint8_t* d_ws, size_t ws_bytes, uint32_t* d_status)
+  {
+  const Plan p = make_plan(n, nplanes, plane_stride);
+  if (p.total > ws_bytes)
+    {
+    set_error("lz4 chunked encode: workspace too small");
+    return 0;
+    }
+  hipStream_t st = current_stream();
+  Desc* descs = (Desc*)(d_ws + p.off_desc);
+  Meta* metas = (Meta*)(d_ws + p.off_meta);
+  uint32_t* snapTs = (uint32_t*)(d_ws + p.off_snap);
+  uint32_t* endTs = (uint32_t*)(d_ws + p.off_end);
+  uint32_t* cbytes = (uint32_t*)(d_ws + p.off_cbytes);
+  uint32_t* coff = (uint32_t*)(d_ws + p.off_coff);
+  hipLaunchKernelGGL(k_lz4_parse, dim3(p.g.K, nplanes), dim3(64), 0, st, d_planes, p.g, descs, metas, snapTs, endTs);
+  hipLaunchKernelGGL(k_lz4_stitch, dim3(nplanes), dim3(64), 0, st, d_planes, p.g, descs, metas, snapTs, endTs, d_status);
+  hipLaunchKernelGGL(k_lz4_sizes, dim3(p.g.K, nplanes), dim3(256), 0, st, p.g, descs, metas, cbytes);
+  hipLaunchKernelGGL(k_lz4_offsets, dim3(nplanes), dim3(1024), 0, st, p.g, cbytes, coff, d_sizes);
+  hipLaunchKernelGGL(k_lz4_emit, dim3(p.g.K, nplanes), dim3(EMIT_T), 0, st, d_planes, p.g, descs, metas, coff, d_out, out_stride);
+  return hip_ok(hipGetLastError(), "lz4 chunked encode kernels") ? 1 : 0;
+  }
+
+} // namespace trico

@@ -118,6 +118,7 @@ ProfSpan::~ProfSpan()
   }
 
 static int g_device_state = 0;   // 0 unknown, 1 ok, -1 none
+static thread_local uint32_t g_stats[4] = { 0, 0, 0, 0 };
 
 static bool device_ready()
   {
@@ -193,6 +194,7 @@ void trico_hip_ctx_destroy(trico_hip_ctx* ctx)
   ctx->out.release();
   ctx->tmp.release();
   ctx->aux.release();
+  ctx->ws.release();
   if (ctx->h_pinned)
     (void)hipHostFree(ctx->h_pinned);
   delete ctx;
@@ -416,14 +418,37 @@ int trico_hip_int_encode(trico_hip_ctx* ctx, const void* src, uint32_t count, in
     d_planes = ctx->tmp.p;
     }
   uint32_t* d_sizes = (uint32_t*)ctx->aux.p;
+  uint32_t* d_status = d_sizes + 16;
+  TRICO_HIP_TRY(hipMemsetAsync(d_status, 0, 16, current_stream()));
   {
   ProfSpan span(TRICO_HIP_K_LZ4_ENCODE);
-  if (!(force_serial_stage(4) ? launch_lz4_encode_serial(d_planes, plane_stride, count, width, ctx->out.p, stride, d_sizes)
-                       : launch_lz4_encode_wave(d_planes, plane_stride, count, width, ctx->out.p, stride, d_sizes)))
+  if (force_serial_stage(4))
+    {
+    if (!launch_lz4_encode_serial(d_planes, plane_stride, count, width, ctx->out.p, stride, d_sizes))
+      return 0;
+    }
+  else if (count >= lz4_chunked_threshold())
+    {
+    const size_t ws = lz4_chunked_workspace(count, width, plane_stride);
+    if (!ctx->ws.reserve(ws))
+      return 0;
+    if (!launch_lz4_encode_chunked(d_planes, plane_stride, count, width, ctx->out.p, stride, d_sizes, ctx->ws.p, ctx->ws.cap, d_status))
+      return 0;
+    }
+  else if (!launch_lz4_encode_wave(d_planes, plane_stride, count, width, ctx->out.p, stride, d_sizes))
     return 0;
   }
-  if (!read_back_words(ctx, d_sizes, width, ctx->out_sizes))
+  if (!read_back_words(ctx, d_sizes, 20, ctx->out_sizes_raw))
     return 0;
+  if (ctx->out_sizes_raw[16] != 0)
+    {
+    set_error("trico_hip_int_encode: internal LZ4 stitch error");
+    return 0;
+    }
+  for (int c = 0; c < width; ++c)
+    ctx->out_sizes[c] = ctx->out_sizes_raw[c];
+  g_stats[0] = ctx->out_sizes_raw[17];      // chunks accepted by the LZ4 stitch pass (beyond chunk 0)
+  g_stats[1] = ctx->out_sizes_raw[18];      // of those, re-parsed because the speculation was not provably equivalent
   ctx->out_count = width;
   for (int c = 0; c < width; ++c)
     sizes[c] = ctx->out_sizes[c];
@@ -530,6 +555,11 @@ const uint8_t* trico_hip_payload_device_pointer(trico_hip_ctx* ctx, int c)
   }
 
 // ---- profiling ----------------------------------------------------------------------------------
+
+void trico_hip_last_stats(uint32_t out[4])
+  {
+  for (int i = 0; i < 4; ++i) out[i] = g_stats[i];
+  }
 
 void trico_hip_profile_enable(int on) { g_prof_on = on != 0; }
 
