@@ -120,7 +120,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from trico_amd import api, meshgen
-    from trico_amd.parallel import gather_archives
+    from trico_amd.parallel import gather_archives, wrap_device_bytes
     L = api.lib()
     if not L.trico_hip_available():
         raise SystemExit("bench.py: no HIP device: " + api.last_error())
@@ -152,7 +152,7 @@ def main():
         te1 = time.perf_counter()
         size = a.get_size()
         if dist is not None:
-            gathered = gather_archives(dist, a.get_buffer_pointer(), size, dev, dst=0)
+            gathered = gather_archives(dist, wrap_device_bytes(a.get_buffer_pointer(), size, dev), dst=0)
             torch.cuda.synchronize()
             state["gathered_bytes"] = gathered
         tg1 = time.perf_counter()

@@ -1,0 +1,74 @@
+"""CPU tier: the N>1 path (one process per rank, shard independent units, size exchange + point-to-point
+gather of variable-length archives onto rank 0) on the gloo backend with world_size 2 and 3.  The bytes
+gathered are oracle archives, so the test also shows that per-rank archives are position independent."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from trico_amd import meshgen
+    from trico_amd.parallel import gather_archives, shard_units, split_archives
+    n_units = 5
+    mine = shard_units(n_units, world, rank)
+    blobs = []
+    for u in mine:
+        v, t = meshgen.grid(24 + u, 10, meshgen.GRID_SEED + u)
+        a = O.OracleArchive()
+        a.write("vertices", v, (24 + u) * 10)
+        a.write("triangles", t, 2 * (24 + u) * 10)
+        blobs.append(a.tobytes())
+        a.close()
+    local = torch.from_numpy(np.frombuffer(b"".join(blobs), np.uint8).copy())
+    res = gather_archives(dist, local, dst=0)
+    if rank == 0:
+        buf, sizes = res
+        parts = split_archives(buf, sizes)
+        q.put((sizes, [bytes(p.numpy().tobytes()) for p in parts]))
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_archives_gloo(world, native_libs):
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    from trico_amd import meshgen
+    from trico_amd.parallel import shard_units
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + world * 7 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    sizes, parts = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # expected: per rank, its units' archives concatenated in unit order
+    for r in range(world):
+        want = b""
+        for u in shard_units(5, world, r):
+            v, t = meshgen.grid(24 + u, 10, meshgen.GRID_SEED + u)
+            a = O.OracleArchive()
+            a.write("vertices", v, (24 + u) * 10)
+            a.write("triangles", t, 2 * (24 + u) * 10)
+            want += a.tobytes()
+            a.close()
+        assert sizes[r] == len(want)
+        assert parts[r] == want

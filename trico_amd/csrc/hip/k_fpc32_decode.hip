@@ -4,19 +4,22 @@
 // 58-66): the decoded component is written straight into its slot of the interleaved output.
 //
 // The format leaves no parallelism inside a stream: value i is xor_i ^ prediction_i and the table keys
-// for prediction_{i+1} come from the decoded value i (fpsc.c:308-326).  So the design minimises the
-// latency of that one dependent chain instead:
-//   * the compressed bytes are staged through LDS in 8 KiB windows with coalesced loads;
-//   * per group of 8 values, lanes 0..7 parse the 3-byte header, locate and byte-swap their residuals in
-//     parallel (off the chain);
-//   * the chain itself runs wave-uniform on the scalar unit: the FCM table (16 entries) lives in one
-//     VGPR across lanes 0..15 (v_readlane / v_writelane with scalar index), the DFCM table (1024) in LDS
-//     and its read is only waited for when the next code actually uses it;
-//   * decoded values are collected in a VGPR (one per lane) and stored 64 at a time.
-// Generic table exponents up to (4,10) are honoured (hash_info byte); the archive API always writes (4,10).
+// for prediction_{i+1} come from the decoded value i (fpsc.c:308-326).  A lone wave on gfx950 issues
+// one instruction per ~5-9 cycles (tools/ubench/issue.hip), so the kernel is organised to put as few
+// instructions as possible on that one chain:
+//   * compressed bytes are staged through LDS in 8 KiB windows (coalesced loads);
+//   * values are handled in batches of 64 = 8 groups.  The 8 group positions are found by a short
+//     scalar walk over the 3-byte headers (residual lengths from bit tricks, no per-code loop); then all
+//     64 lanes locate, align and byte-swap their own residual at once, and one ballot says which values
+//     use the DFCM prediction;
+//   * the chain itself is fully unrolled and wave-uniform: residual by v_readlane with a constant lane,
+//     FCM table (16 entries) in one VGPR across lanes (compare/select to write, v_readlane to read), DFCM
+//     table (1024 entries) in LDS, read only when the value's code asks for it; ~17 instructions per value;
+//   * decoded values are dropped into a VGPR with v_writelane and stored 64 at a time.
+// Streams with table exponents other than the (4,10) the archive API writes use the generic loop below.
 //
-// This kernel is latency-bound by construction; algorithmic bytes per value:
-// its payload share read + 4 written.
+// Latency-bound by construction; algorithmic bytes per value: its payload share
+// read + 4 written.
 #include "common.hpp"
 
 namespace trico {
@@ -24,8 +27,7 @@ namespace trico {
 namespace {
 
 constexpr int WINW = 2048;             // staging window, dwords (8 KiB)
-constexpr int WIN_LOW = 64;            // refill when fewer than this many bytes remain (a group needs <= 35)
-typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+constexpr uint32_t BATCH_BYTES = 8 * 35;   // a batch of 8 groups needs at most this many payload bytes
 
 struct DecodeArgs
   {
@@ -35,14 +37,61 @@ struct DecodeArgs
 
 __device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
+// sum of the residual lengths of the 3-bit codes packed in x (codes 0..4 -> 0..4 bytes, 5..7 -> 1..3 bytes)
+__device__ __forceinline__ uint32_t lens_sum(uint32_t x)
+  {
+  const uint32_t b0 = x & 0x249249u, b1 = (x >> 1) & 0x249249u, b2 = (x >> 2) & 0x249249u;
+  const uint32_t hi = b2 & (b1 | b0);                            // codes 5, 6, 7
+  return (uint32_t)__popc(b0) + 2u * (uint32_t)__popc(b1) + 4u * ((uint32_t)__popc(b2) - (uint32_t)__popc(hi));
+  }
+
+struct Chain
+  {
+  uint32_t h1, h2, p1, last;   // wave-uniform
+  uint32_t T1;                 // FCM table: entry h in lane h
+  uint32_t outv;               // lane k: value k of the current batch
+  };
+
+template <int K>
+__device__ __forceinline__ void chain_step(Chain& c, uint32_t xr, uint64_t dfcm, uint32_t* __restrict__ T2, int lane)
+  {
+  const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)xr, K);
+  uint32_t p = c.p1;
+  if ((dfcm >> K) & 1ull)
+    p = c.last + rfl(T2[c.h2]);                                    // decoder keeps value + stride (fpsc.c:310-311, 323)
+  const uint32_t v = x ^ p;
+  c.T1 = ((uint32_t)lane == c.h1) ? v : c.T1;                      // hash_table_1[hash1] = value
+  c.h1 = v >> 28;                                                  // fpsc.c:76-79 with e1 = 4: the old hash is masked away
+  c.p1 = (uint32_t)__builtin_amdgcn_readlane((int)c.T1, (int)c.h1);
+  const uint32_t s = v - c.last;
+  T2[c.h2] = s;                                                    // hash_table_2[hash2] = stride
+  c.h2 = ((c.h2 << 5) & 1023u) ^ (s >> 22);                        // fpsc.c:81-84 with e2 = 10
+  c.last = v;
+  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(c.outv) : "s"(v), "n"(K));
+  }
+
+template <int K, int N> struct Unroll
+  {
+  static __device__ __forceinline__ void run(Chain& c, uint32_t xr, uint64_t dfcm, uint32_t* __restrict__ T2, int lane)
+    {
+    chain_step<K>(c, xr, dfcm, T2, lane);
+    Unroll<K + 1, N>::run(c, xr, dfcm, T2, lane);
+    }
+  };
+template <int N> struct Unroll<N, N>
+  {
+  static __device__ __forceinline__ void run(Chain&, uint32_t, uint64_t, uint32_t* __restrict__, int) {}
+  };
+
 __global__ void __launch_bounds__(64) k_fpc32_decode(DecodeArgs args, int arity, uint32_t n, uint32_t* __restrict__ dst,
                                                      uint32_t* __restrict__ status)
   {
   __shared__ uint32_t win[WINW + 4];
+  __shared__ uint32_t T2[1024];
   const int lane = threadIdx.x;
-  const int c = blockIdx.x;
-  const uint8_t* in = args.pay[c];
-  const uint32_t len = args.size[c];
+  const int comp = blockIdx.x;
+  const uint8_t* in = args.pay[comp];
+  const uint32_t len = args.size[comp];
   if (len < 5u)
     {
     if (lane == 0) atomicOr(status, 1u);
@@ -55,96 +104,115 @@ __global__ void __launch_bounds__(64) k_fpc32_decode(DecodeArgs args, int arity,
     if (lane == 0) atomicOr(status, 2u);
     return;
     }
-  // DFCM table (up to 1024 entries) in 16 VGPRs: entry e lives in register e & 15, lane e >> 4
-  u32x16 T2 = (u32x16)(0u);
-  const uint32_t m1 = (1u << e1) - 1u, m2 = (1u << e2) - 1u, sh1 = 32u - e1, sh2 = 32u - e2, e2h = e2 >> 1;
+  for (int i = lane; i < 1024; i += 64)
+    T2[i] = 0u;
   // window over the payload, in units of aligned dwords of the underlying buffer
   const uint32_t al = (uint32_t)((uintptr_t)in & 3u);
   const uint32_t* abase = (const uint32_t*)(in - al);
   const uint32_t total_q = len + al;                     // payload end in aligned-byte coordinates
+  const uint32_t ndw = (total_q + 3u) >> 2;
   uint32_t wd = 0;                                       // first dword of the window
   uint32_t q = 5u + al;                                  // read cursor, aligned-byte coordinates
   auto refill = [&](uint32_t from_q)
     {
+    __syncthreads();
     wd = from_q >> 2;
-    const uint32_t ndw = (total_q + 3u) >> 2;
     for (uint32_t i = (uint32_t)lane; i < (uint32_t)WINW + 4u; i += 64u)
       win[i] = (wd + i < ndw) ? abase[wd + i] : 0u;
     __syncthreads();
     };
   refill(q);
-  uint32_t T1 = 0;                  // FCM table: entry h lives in lane h
-  uint32_t h1 = 0, h2 = 0, p1 = 0, p2 = 0, last = 0;
-  uint32_t outv = 0;                // lane j holds value (i0 + j) of the current batch of 64
+  Chain c;
+  c.h1 = 0; c.h2 = 0; c.p1 = 0; c.last = 0; c.T1 = 0; c.outv = 0;
+  const bool standard = (e1 == 4u && e2 == 10u);
+  uint32_t i0 = 0;
   bool bad = false;
-  for (uint32_t i = 0; i < n; i += 8u)
+  if (standard)
     {
-    if (q + WIN_LOW > 4u * (wd + (uint32_t)WINW))
+    for (; i0 + 64u <= n; i0 += 64u)
       {
-      __syncthreads();
-      refill(q);
-      }
-    // ---- parallel part: lanes 0..7 fetch their residuals --------------------------------------------
-    const uint32_t lq = q - 4u * wd;                       // cursor inside the window (bytes)
-    const uint8_t* wb = (const uint8_t*)win;
-    const uint32_t bc = ((uint32_t)wb[lq] << 16) | ((uint32_t)wb[lq + 1u] << 8) | wb[lq + 2u];
-    const uint32_t j = (uint32_t)lane & 7u;
-    const uint32_t code = (bc >> (3u * j)) & 7u;
-    const uint32_t nb = code <= 4u ? code : code - 4u;
-    // bytes of the residuals before mine: sum of lengths of codes 0..j-1
-    uint32_t before = 0;
+      if (q + BATCH_BYTES + 8u > 4u * (wd + (uint32_t)WINW))
+        refill(q);
+      // ---- positions of the 8 groups: scalar walk over the headers -----------------------------------
+      uint32_t lq = q - 4u * wd;
+      uint32_t bcv = 0, myq = 0;
 #pragma unroll
-    for (uint32_t t = 0; t < 7u; ++t)
-      {
-      const uint32_t ct = (bc >> (3u * t)) & 7u;
-      before += (t < j) ? (ct <= 4u ? ct : ct - 4u) : 0u;
+      for (uint32_t g = 0; g < 8u; ++g)
+        {
+        const uint32_t w = rfl(__builtin_amdgcn_alignbyte(win[(lq >> 2) + 1u], win[lq >> 2], lq & 3u));
+        const uint32_t bc = __builtin_bswap32(w) >> 8;              // 3 header bytes, big-endian (fpsc.c:245-247)
+        if (((uint32_t)lane >> 3) == g)
+          {
+          bcv = bc;
+          myq = lq;
+          }
+        lq += 3u + lens_sum(bc);
+        }
+      const uint32_t qend = 4u * wd + lq;
+      if (qend > total_q)
+        {
+        bad = true;
+        break;
+        }
+      q = qend;
+      // ---- all 64 lanes fetch their residual ------------------------------------------------------------
+      const uint32_t j3 = 3u * ((uint32_t)lane & 7u);
+      const uint32_t code = (bcv >> j3) & 7u;
+      const uint32_t nb = code <= 4u ? code : code - 4u;
+      const uint32_t rp = myq + 3u + lens_sum(bcv & ((1u << j3) - 1u));
+      const uint32_t raw = __builtin_amdgcn_alignbyte(win[(rp >> 2) + 1u], win[rp >> 2], rp & 3u);
+      const uint32_t xr = nb ? __builtin_bswap32(raw) >> (8u * (4u - nb)) : 0u;
+      const uint64_t dfcm = __ballot(code > 4u);
+      // ---- the dependent chain ---------------------------------------------------------------------------
+      Unroll<0, 64>::run(c, xr, dfcm, T2, lane);
+      dst[(size_t)(i0 + (uint32_t)lane) * arity + comp] = c.outv;
       }
-    const uint32_t rp = lq + 3u + before;                  // my residual starts here
-    const uint32_t lo = win[rp >> 2], hi = win[(rp >> 2) + 1u];
-    const uint32_t raw = __builtin_amdgcn_alignbyte(hi, lo, rp & 3u);         // 4 stream bytes, first in the low byte
-    const uint32_t be = __builtin_bswap32(raw);                                // first stream byte on top
-    const uint32_t xr = nb ? be >> (8u * (4u - nb)) : 0u;
-    // total bytes of the group = 3 + sum of all 8 lengths (lane 7 knows: before + nb)
-    const uint32_t gbytes = 3u + rfl((uint32_t)__builtin_amdgcn_readlane((int)(before + nb), 7));
-    const uint32_t m = (n - i < 8u) ? (n - i) : 8u;        // values in this group (tail: fpsc.c:329-414)
-    if (q + gbytes > total_q)
+    }
+  if (!bad && i0 < n)
+    {
+    // generic loop: tail of the stream (fewer than 64 values, fpsc.c:329-414) or non-standard exponents
+    const uint32_t m1 = (1u << e1) - 1u, m2 = (1u << e2) - 1u, sh1 = 32u - e1, sh2 = 32u - e2, e2h = e2 >> 1;
+    uint32_t p2 = c.last;
+    for (uint32_t i = i0; i < n; i += 8u)
       {
-      bad = true;
-      break;
-      }
-    q += gbytes;
-    // ---- the dependent chain (wave-uniform) ----------------------------------------------------------
-#pragma unroll
-    for (uint32_t k = 0; k < 8u; ++k)
-      {
-      if (k < m)
+      if (q + 64u > 4u * (wd + (uint32_t)WINW))
+        refill(q);
+      const uint32_t lq = q - 4u * wd;
+      const uint32_t w = rfl(__builtin_amdgcn_alignbyte(win[(lq >> 2) + 1u], win[lq >> 2], lq & 3u));
+      const uint32_t bc = __builtin_bswap32(w) >> 8;
+      const uint32_t j3 = 3u * ((uint32_t)lane & 7u);
+      const uint32_t code = (bc >> j3) & 7u;
+      const uint32_t nb = code <= 4u ? code : code - 4u;
+      const uint32_t rp = lq + 3u + lens_sum(bc & ((1u << j3) - 1u));
+      const uint32_t raw = __builtin_amdgcn_alignbyte(win[(rp >> 2) + 1u], win[rp >> 2], rp & 3u);
+      const uint32_t xr = nb ? __builtin_bswap32(raw) >> (8u * (4u - nb)) : 0u;
+      const uint32_t gbytes = 3u + lens_sum(bc);
+      if (q + gbytes > total_q)
+        {
+        bad = true;
+        break;
+        }
+      q += gbytes;
+      const uint32_t m = (n - i < 8u) ? (n - i) : 8u;
+      for (uint32_t k = 0; k < m; ++k)
         {
         const uint32_t ck = (bc >> (3u * k)) & 7u;
         const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)xr, (int)k);
-        uint32_t p = p1;
+        uint32_t p = c.p1;
         if (ck > 4u)
-          p = p2 + (uint32_t)__builtin_amdgcn_readlane((int)T2[h2 & 15u], (int)(h2 >> 4));   // value + stride (fpsc.c:323)
+          p = p2 + rfl(T2[c.h2]);
         const uint32_t v = x ^ p;
-        T1 = ((uint32_t)lane == h1) ? v : T1;             // v_writelane semantics via compare + select
-        h1 = ((h1 << e1) ^ (v >> sh1)) & m1;
-        p1 = (uint32_t)__builtin_amdgcn_readlane((int)T1, (int)h1);
-        const uint32_t s = v - last;
-        {
-        const uint32_t r = h2 & 15u;
-        T2[r] = ((uint32_t)lane == (h2 >> 4)) ? s : T2[r];
-        }
-        h2 = ((h2 << e2h) ^ (s >> sh2)) & m2;
+        c.T1 = ((uint32_t)lane == c.h1) ? v : c.T1;
+        c.h1 = ((c.h1 << e1) ^ (v >> sh1)) & m1;
+        c.p1 = (uint32_t)__builtin_amdgcn_readlane((int)c.T1, (int)c.h1);
+        const uint32_t s = v - c.last;
+        T2[c.h2] = s;
+        c.h2 = ((c.h2 << e2h) ^ (s >> sh2)) & m2;
         p2 = v;
-        last = v;
-        outv = ((uint32_t)lane == ((i + k) & 63u)) ? v : outv;
+        c.last = v;
+        if (lane == 0)
+          dst[(size_t)(i + k) * arity + comp] = v;
         }
-      }
-    if (((i + 8u) & 63u) == 0u || i + 8u >= n)
-      {
-      const uint32_t i0 = i & ~63u;
-      const uint32_t idx = i0 + (uint32_t)lane;
-      if (idx < n)
-        dst[(size_t)idx * arity + c] = outv;
       }
     }
   if (bad && lane == 0)
