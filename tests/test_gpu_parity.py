@@ -215,3 +215,30 @@ def test_config1_vertices(api, kind, hashes):
         sizes.append(nb)
         pos += 4 + nb
     assert sizes == want_sizes
+
+
+@pytest.mark.parametrize("kind", ["grid", "walk", "multi"])
+def test_config1_full_archives_vs_reference_hash(api, kind, hashes):
+    """BASELINE config 1 (1M vertices + 2M triangles) and its walk / multi siblings: whole archive sha256 and
+    size against the golden produced by the compiled reference; then decode and compare with the input."""
+    streams = mesh_streams(kind, 1000, 1000)
+    got = write_archive(api, streams)
+    h = hashes["%s_1000x1000" % kind]
+    assert len(got) == h["size"]
+    assert hashlib.sha256(got).hexdigest() == h["sha256"]
+    read_back(api, got, streams)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 127, 128, 129, 4097, 100001])
+@pytest.mark.parametrize("kind", ["smooth", "noisy", "randbits", "steps"])
+def test_fp64_wave_coder_vs_oracle(api, n, kind):
+    """Wave-wide double coder (k_fpc64.hip): step/batch boundaries, odd tails, class collisions."""
+    rng = np.random.default_rng(n * 11 + len(kind))
+    if kind == "randbits":
+        a3 = rng.integers(0, 2**63, 3 * n, dtype=np.uint64).view(np.float64)
+    else:
+        a3 = _fp32_data(kind, 3 * n, rng).astype(np.float64) + (1e-9 * np.arange(3 * n) if kind == "smooth" else 0.0)
+    streams = [("vertices_double", a3, n), ("attributes_double", a3[:n].copy(), n)]
+    got = write_archive(api, streams)
+    assert got == oracle_archive(streams)
+    read_back(api, got, streams)

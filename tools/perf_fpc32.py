@@ -23,6 +23,12 @@ for it in range(6):
         L.trico_hip_profile_reset()
     t0 = time.perf_counter()
     assert L.trico_hip_fpc_encode(ctx, d.data_ptr(), n, 3, 4, sizes) == 1, api.last_error()
+    if it == 0:
+        dst = torch.empty(sum(sizes) + 1024, dtype=torch.uint8, device="cuda")
+    off = 0
+    for c in range(3):          # payloads gathered straight to their (device) destination, as the archive writer does
+        assert L.trico_hip_fetch_payload(ctx, c, dst.data_ptr() + off) == 1, api.last_error()
+        off += sizes[c]
     L.trico_hip_synchronize()
     t1 = time.perf_counter()
     print("iter", it, "wall ms %.3f" % ((t1 - t0) * 1e3), list(sizes), flush=True)

@@ -41,6 +41,11 @@ struct trico_hip_ctx
   uint32_t out_sizes[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
   uint32_t out_sizes_raw[24] = { 0 };
   int out_count = 0;
+  // float encoder: payloads stay in segment slots (tmp) until they are gathered to their destination
+  bool out_in_slots = false;
+  uint32_t slots_n = 0;
+  int slots_arity = 0;
+  bool out_materialized[3] = { false, false, false };
   uint32_t* h_pinned = nullptr;   // 64 words of pinned host memory for size/status read-back
   };
 
@@ -50,9 +55,9 @@ namespace trico {
 struct ProfSpan
   {
   int k;
-  bool active;
+  bool active, counted;
   hipEvent_t e0, e1;
-  explicit ProfSpan(int kernel_id);
+  explicit ProfSpan(int kernel_id, bool count_launch = true);
   ~ProfSpan();
   };
 
@@ -83,12 +88,18 @@ int launch_lz4_decode_serial(const uint8_t* const d_payloads[8], const uint32_t 
 size_t fpc32_encode_workspace(uint32_t n, int arity);
 int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
                         uint8_t* d_ws, size_t ws_bytes);
+int launch_fpc32_gather(uint32_t n, int arity, int c, const uint8_t* d_ws, uint8_t* d_dst);
 bool force_serial();              // TRICO_HIP_SERIAL: see shim.hip
 bool force_serial_stage(int bit);
 
 // latency-optimised float decoder (k_fpc32_decode.hip): one wave per component stream
 int launch_fpc32_decode(const uint8_t* const d_payloads[3], const uint32_t sizes[3], int arity, uint32_t n, void* d_dst,
                         uint32_t* d_status);
+
+// double-precision coder (k_fpc64.hip): one wave per component stream, 2 x 2^20-entry tables per stream in d_tables (zeroed)
+int launch_fpc64_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes, uint64_t* d_tables);
+int launch_fpc64_decode(const uint8_t* const d_payloads[3], const uint32_t sizes[3], int arity, uint32_t n, void* d_dst,
+                        uint64_t* d_tables, uint32_t* d_status);
 
 // wave-cooperative LZ4 (k_lz4.hip): one wave per plane, wide match counting / copies
 int launch_lz4_encode_wave(const uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, int nplanes, uint8_t* d_out,

@@ -38,9 +38,9 @@ constexpr int TAB = 1040;      // 16 FCM entries followed by 1024 DFCM entries
 constexpr int ROW = 1040;      // words per (segment, component) row in the global index tables
 constexpr int CH = 32;         // segments per chunk in the cross-segment scan
 constexpr int RING = 1024;     // bytes of per-wave output staging ring
-constexpr int LIDW = 272;      // words of the lane-id table (1040 bytes, padded)
+constexpr int MASKW = 2 * TAB;  // words of the per-class lane-mask table (u64 per class)
 constexpr int LDSW_A = TAB;                        // per-wave LDS words, sweep A
-constexpr int LDSW_C = TAB + RING / 4 + LIDW;      // per-wave LDS words, sweep C
+constexpr int LDSW_C = TAB + RING / 4 + MASKW;     // per-wave LDS words, sweep C (13,504 B: 4 x 3 waves per CU)
 constexpr int PF = 8;          // steps (of 64 values) whose loads are kept in flight per wave
 
 __device__ __forceinline__ uint32_t dpp_shr1(uint32_t carry, uint32_t v)
@@ -119,6 +119,11 @@ __device__ __forceinline__ void next_carry(Carry& cy, uint32_t v)
   }
 
 // ---- sweep A: last writer index (+1) per class of every segment ---------------------------------------
+// "Last writer" is a maximum over value indices, so a segment may be swept by several waves at once:
+// every segment is cut into ISPLIT sub-ranges (grid.y), each with its own LDS table, combined into the
+// segment's row with global atomicMax (the rows are zeroed before the launch).
+constexpr uint32_t ISPLIT = 2;
+
 __global__ void __launch_bounds__(192) k_fpc32_index(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t L,
                                                      uint32_t* __restrict__ summ)
   {
@@ -129,8 +134,12 @@ __global__ void __launch_bounds__(192) k_fpc32_index(const uint32_t* __restrict_
   for (int i = lane; i < TAB; i += 64)
     T[i] = 0u;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  const uint32_t i_begin = g * L;
-  const uint32_t i_end = (n - i_begin < L) ? n : i_begin + L;
+  const uint32_t sub = L / ISPLIT;                       // L is a multiple of 64 * ISPLIT
+  const uint32_t seg_end = (n - g * L < L) ? n : g * L + L;
+  const uint32_t i_begin = g * L + blockIdx.y * sub;
+  if (i_begin >= seg_end)
+    return;
+  const uint32_t i_end = (seg_end - i_begin < sub) ? seg_end : i_begin + sub;
   Carry cy = load_carry(src, i_begin, arity, c);
   uint32_t cur[PF], nxt[PF];
   load_block(cur, src, i_begin, i_end, arity, c, lane);
@@ -161,7 +170,11 @@ __global__ void __launch_bounds__(192) k_fpc32_index(const uint32_t* __restrict_
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   uint32_t* row = summ + ((size_t)g * arity + c) * ROW;
   for (int i = lane; i < TAB; i += 64)
-    row[i] = T[i];
+    {
+    const uint32_t t = T[i];
+    if (t)
+      atomicMax(&row[i], t);
+    }
   }
 
 // ---- scan: incoming index table of segment g = max over earlier segments -----------------------------
@@ -203,47 +216,36 @@ __global__ void __launch_bounds__(256) k_fpc32_scan_b(const uint32_t* __restrict
 // ---- sweep C -------------------------------------------------------------------------------------------
 
 // Who wrote my class last, inside this step?  Lanes form runs of equal class.  Inside a run it is the
-// previous lane.  A run START normally has no earlier lane of its class in the step (-> LDS table);
-// if the class has several runs in this step, the nearest lower run END of that class is the answer.
-// Detection: every run end stores its lane id at LID[class]; every start/end reads it back and
-// compares with the end lane of its own run: a mismatch anywhere means the class has >= 2 runs, and
-// those classes are resolved exactly with ballots (one loop iteration per such class).
+// previous lane.  A run START needs the nearest lower lane of its class, which is the END lane of an
+// earlier run: run ends OR their lane bit into M[class] (u64 per class, zero between steps), every lane
+// reads its class's mask back, ends clear it.  Constant cost for any number of classes; both predictors
+// (FCM classes [0,16), DFCM classes [16,1040)) are resolved together so their LDS round trips overlap.
 //   src  : lane holding the latest earlier value of my class inside this step, -1 if none
 //   last : I am the last value of my class in this step (I own the table write)
-__device__ __forceinline__ void wave_pred(uint32_t key, bool act, uint8_t* __restrict__ LID, uint64_t lt, int lane,
-                                          bool& start, int& src, bool& last)
+struct Pred { bool st1, st2, last1, last2; int src1, src2; };
+
+__device__ __forceinline__ Pred wave_pred2(uint32_t k1, uint32_t k2, bool act, uint64_t* __restrict__ M, uint64_t lt, int lane)
   {
-  const uint32_t kp = dpp_shr1(0xfffffffeu, key);
-  const uint32_t kn = dpp_shl1(0xfffffffeu, key);
-  start = act && key != kp;
-  const bool end = act && key != kn;
-  const uint64_t E = __ballot(end);
-  const uint64_t up = E & ~lt;                        // run ends at or above my lane
-  const uint32_t my_end = (uint32_t)__builtin_ctzll(up | (1ull << 63));
-  if (end)
-    LID[key] = (uint8_t)lane;
+  Pred r;
+  const uint32_t kp1 = dpp_shr1(0xfffffffeu, k1), kn1 = dpp_shl1(0xfffffffeu, k1);
+  const uint32_t kp2 = dpp_shr1(0xfffffffeu, k2), kn2 = dpp_shl1(0xfffffffeu, k2);
+  r.st1 = act && k1 != kp1;
+  r.st2 = act && k2 != kp2;
+  const bool en1 = act && k1 != kn1, en2 = act && k2 != kn2;
+  const unsigned long long bit = 1ull << lane;
+  if (en1) atomicOr((unsigned long long*)&M[k1], bit);
+  if (en2) atomicOr((unsigned long long*)&M[k2], bit);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  uint32_t w = my_end;
-  if (start || end)
-    w = LID[key];
-  src = start ? -1 : lane - 1;
-  last = end;
-  uint64_t todo = __ballot(act && w != my_end);
-  while (todo)                                        // classes with several runs in this step (rare)
-    {
-    const int leader = __builtin_ctzll(todo);
-    const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
-    const bool mine = key == kk;
-    const uint64_t mE = __ballot(mine && end);
-    if (mine)
-      {
-      const uint64_t lower = mE & lt;
-      if (start)
-        src = lower ? 63 - __builtin_clzll(lower) : -1;
-      last = end && (mE >> lane) == 1ull;
-      }
-    todo &= ~__ballot(mine);
-    }
+  const uint64_t m1 = M[act ? k1 : 0u], m2 = M[act ? k2 : 16u];       // unconditional (broadcast) reads
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (en1) M[k1] = 0ull;
+  if (en2) M[k2] = 0ull;
+  const uint64_t lo1 = m1 & lt, lo2 = m2 & lt;
+  r.src1 = r.st1 ? (lo1 ? 63 - __builtin_clzll(lo1) : -1) : lane - 1;
+  r.src2 = r.st2 ? (lo2 ? 63 - __builtin_clzll(lo2) : -1) : lane - 1;
+  r.last1 = en1 && (m1 >> lane) == 1ull;
+  r.last2 = en2 && (m2 >> lane) == 1ull;
+  return r;
   }
 
 // store the bytes of ring word `w` (byte offset off inside the slot, multiple of 4) that lie below hi
@@ -264,10 +266,12 @@ __global__ void __launch_bounds__(192) k_fpc32_code(const uint32_t* __restrict__
   extern __shared__ uint32_t lds[];
   const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t g = blockIdx.x;
-  uint32_t* T = lds + c * LDSW_C;
+  uint32_t* T = lds + c * LDSW_C;                      // [TAB] payload table, directly followed by the ring
   uint32_t* ringw = T + TAB;
   uint8_t* ring = (uint8_t*)ringw;
-  uint8_t* LID = (uint8_t*)(T + TAB + RING / 4);
+  uint64_t* M = (uint64_t*)(T + TAB + RING / 4);       // [TAB] lane masks
+  for (int k = lane; k < TAB; k += 64)
+    M[k] = 0ull;
   // incoming table: payload of the last writer of every class before this segment (0 if none)
   const uint32_t* row = inc + ((size_t)g * arity + c) * ROW;
   for (int k = lane; k < TAB; k += 64)
@@ -316,27 +320,20 @@ __global__ void __launch_bounds__(192) k_fpc32_code(const uint32_t* __restrict__
       uint32_t a, b, k1, k2;
       classes(v, cy, act, a, b, k1, k2);
       const uint32_t s = v - a;
-      int src1, src2;
-      bool st1, st2, last1, last2;
-      wave_pred(k1, act, LID, lt, lane, st1, src1, last1);
-      wave_pred(k2, act, LID, lt, lane, st2, src2, last2);
-      uint32_t p1 = a, p2 = a - b;           // inside a run: previous lane's value / stride
-      const bool t1 = st1 && src1 < 0, t2 = st2 && src2 < 0;      // first of my class in this step
-      uint32_t tv1 = 0, tv2 = 0;
-      if (t1) tv1 = T[k1];
-      if (t2) tv2 = T[k2];
-      if (__ballot((st1 && src1 >= 0) || (st2 && src2 >= 0)))
-        {
-        const uint32_t q1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src1 << 2, (int)v);
-        const uint32_t q2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src2 << 2, (int)s);
-        if (st1) p1 = q1;
-        if (st2) p2 = q2;
-        }
-      if (t1) p1 = tv1;
-      if (t2) p2 = tv2;
+      const Pred pr = wave_pred2(k1, k2, act, M, lt, lane);
+      // Branch-free LDS traffic: lanes that have nothing to read/write are redirected instead of masked
+      // (every exec-mask region costs 3-4 instructions on the CU's single scalar unit).  The ring bytes
+      // [pos+512, pos+768) are never live (at most 536 bytes are in flight), they serve as the dump.
+      const uint32_t dump = (pos + 512u) & (RING - 1);
+      const uint32_t tv1 = T[act ? k1 : 0u], tv2 = T[act ? k2 : 0u];
+      const uint32_t q1 = (uint32_t)__builtin_amdgcn_ds_bpermute(pr.src1 << 2, (int)v);
+      const uint32_t q2 = (uint32_t)__builtin_amdgcn_ds_bpermute(pr.src2 << 2, (int)s);
+      const uint32_t p1 = pr.st1 ? (pr.src1 >= 0 ? q1 : tv1) : a;            // inside a run: previous lane's value
+      const uint32_t p2 = pr.st2 ? (pr.src2 >= 0 ? q2 : tv2) : a - b;        //               previous lane's stride
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      if (last1) T[k1] = v;
-      if (last2) T[k2] = s;
+      const uint32_t dumpw = TAB + (((dump >> 2) + (uint32_t)lane) & (RING / 4 - 1));
+      T[pr.last1 ? k1 : dumpw] = v;
+      T[pr.last2 ? k2 : dumpw] = s;
       uint32_t len, x;
       uint32_t code = pick(v ^ p1, v ^ (a + p2), len, x);
       const bool slot = act || (i_end == n && i < n8);          // value or tail padding slot (fpsc.c:196-204)
@@ -355,17 +352,18 @@ __global__ void __launch_bounds__(192) k_fpc32_code(const uint32_t* __restrict__
       bc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bc, 0x141, 0xf, 0xf, true);    // row_half_mirror
       const uint32_t grp = lane >> 3;
       const uint32_t rpos = pos + 3u * (grp + 1u) + pre;
-      if (len > 0u) ring[(rpos) & (RING - 1)] = (uint8_t)(x >> (8u * (len - 1u)));
-      if (len > 1u) ring[(rpos + 1u) & (RING - 1)] = (uint8_t)(x >> (8u * (len - 2u)));
-      if (len > 2u) ring[(rpos + 2u) & (RING - 1)] = (uint8_t)(x >> (8u * (len - 3u)));
-      if (len > 3u) ring[(rpos + 3u) & (RING - 1)] = (uint8_t)x;
-      if (slot && (lane & 7) == 0)
-        {
-        const uint32_t hpos = pos + 3u * grp + pre;
-        ring[hpos & (RING - 1)] = (uint8_t)(bc >> 16);
-        ring[(hpos + 1u) & (RING - 1)] = (uint8_t)(bc >> 8);
-        ring[(hpos + 2u) & (RING - 1)] = (uint8_t)bc;
-        }
+      const uint32_t dumpb = dump + 4u * (uint32_t)lane;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+      for (uint32_t kb = 0; kb < 4u; ++kb)
+        ring[(len > kb ? rpos + kb : dumpb + kb) & (RING - 1)] = (uint8_t)(x >> (8u * ((len - 1u - kb) & 3u)));
+      {
+      const bool lead = slot && (lane & 7) == 0;
+      const uint32_t hpos = lead ? pos + 3u * grp + pre : dumpb;
+      ring[hpos & (RING - 1)] = (uint8_t)(bc >> 16);
+      ring[(hpos + 1u) & (RING - 1)] = (uint8_t)(bc >> 8);
+      ring[(hpos + 2u) & (RING - 1)] = (uint8_t)bc;
+      }
       const uint32_t nslots = (uint32_t)__popcll(__ballot(slot));
       pos += 3u * (nslots >> 3) + (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -469,13 +467,13 @@ Plan make_plan(uint32_t n, int arity)
   if (!waves)
     {
     const char* e = getenv("TRICO_FPC32_WAVES");      // tuning knob: waves per sweep
-    waves = e ? atoi(e) : 6144;
+    waves = e ? atoi(e) : 3072;
     if (waves < 3) waves = 3;
     }
   Plan p;
   const uint32_t target = (uint32_t)waves / (uint32_t)arity;
   uint64_t L = ((uint64_t)n + target - 1) / target;
-  L = (L + 63) / 64 * 64;
+  L = (L + 127) / 128 * 128;                    // multiple of 64 * ISPLIT
   if (L < 1024) L = 1024;
   p.L = (uint32_t)L;
   p.S = (uint32_t)(((uint64_t)n + L - 1) / L);
@@ -525,16 +523,31 @@ int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
   uint8_t* slots = d_ws + p.off_slots;
   const uint32_t* src = (const uint32_t*)d_src;
   const unsigned threads = 64u * (unsigned)arity;
-  hipLaunchKernelGGL(k_fpc32_index, dim3(p.S), dim3(threads), (size_t)arity * LDSW_A * 4, st, src, n, arity, p.L, summ);
+  if (!hip_ok(hipMemsetAsync(summ, 0, p.rows * ROW * 4, st), "memset(summ)"))
+    return 0;
+  hipLaunchKernelGGL(k_fpc32_index, dim3(p.S, ISPLIT), dim3(threads), (size_t)arity * LDSW_A * 4, st, src, n, arity, p.L, summ);
   const unsigned colblocks = ((unsigned)arity * TAB + 255u) / 256u;
   hipLaunchKernelGGL(k_fpc32_scan_a, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax);
   hipLaunchKernelGGL(k_fpc32_scan_b, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax, inc);
   hipLaunchKernelGGL(k_fpc32_code, dim3(p.S), dim3(threads), (size_t)arity * LDSW_C * 4, st,
                      src, n, arity, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes);
   hipLaunchKernelGGL(k_fpc32_offsets, dim3(arity), dim3(1024), 0, st, segbytes, p.S, segoff, d_sizes);
-  hipLaunchKernelGGL(k_fpc32_gather, dim3(p.S, arity), dim3(256), 0, st, slots, p.slot_stride, p.segcap, p.S, segbytes, segoff,
-                     d_out, out_stride);
   return hip_ok(hipGetLastError(), "fpc32 encode kernels") ? 1 : 0;
+  }
+
+// Moves component `c` of the last launch_fpc32_encode (same n, arity, workspace) from its segment slots to
+// `d_dst`, contiguous.  This is the one copy the payload needs to reach its place in the archive.
+int launch_fpc32_gather(uint32_t n, int arity, int c, const uint8_t* d_ws, uint8_t* d_dst)
+  {
+  if (n == 0)
+    return 1;           // the empty-stream kernel wrote the payload in place
+  const Plan p = make_plan(n, arity);
+  const uint32_t* segbytes = (const uint32_t*)(d_ws + p.off_segbytes);
+  const uint32_t* segoff = (const uint32_t*)(d_ws + p.off_segoff);
+  const uint8_t* slots = d_ws + p.off_slots;
+  hipLaunchKernelGGL(k_fpc32_gather, dim3(p.S, 1), dim3(256), 0, current_stream(), slots + (size_t)c * p.slot_stride, (size_t)0,
+                     p.segcap, p.S, segbytes + (size_t)c * p.S, segoff + (size_t)c * p.S, d_dst, (size_t)0);
+  return hip_ok(hipGetLastError(), "k_fpc32_gather") ? 1 : 0;
   }
 
 } // namespace trico

@@ -1,0 +1,389 @@
+// k_fpc64.hip — double-precision FCM/DFCM coder: wave-wide encoder and batch-parsing decoder.
+//
+// Replaces trico_compress_double_precision / trico_decompress_double_precision (fpsc.c:576-800 / 803-1164)
+// with exponents (20,20) as the archive API passes them (trico.c:396), fused with the double AoS<->SoA
+// transposes (transpose_aos_to_soa.c:28-46, 68-82).
+//
+// The two tables have 2^20 u64 entries each (8 MiB): they cannot live in LDS, and per-segment copies as in
+// the float encoder are impossible, so one wave owns one component stream and walks it in order with the
+// tables in global memory (zeroed per call, resident in L2 / Infinity Cache):
+//   encoder: 64 values per step.  Classes come from the input alone: FCM class = top 20
+//     bits of v[i-1], DFCM class = f(v[i-3..i-1]).  Inside a step the latest earlier value of a class is
+//     found with ballots over the distinct classes present (runs of equal class are resolved by the
+//     previous lane), across steps by one gather per table; the last lane of every class scatters its
+//     payload.  4-bit codes, two values per header byte, residual bytes MSB first; bytes are staged in an
+//     LDS ring and flushed as aligned dwords straight to their final place (the wave writes sequentially).
+//     One global round trip per step bounds it: ~1 us per 64 values per stream.
+//   decoder: compressed bytes staged through LDS; batches of 64 values: a scalar walk over the 32 header
+//     bytes finds the group positions, all lanes fetch/align/byte-swap their residual, then the dependent
+//     chain runs wave-uniform.  A table read is skipped when the key did not change (then the entry is the
+//     value just written) — the common case on smooth data; otherwise it is a dependent L2 access.
+// Latency-bound by construction; algorithmic bytes per value: 8 + its payload share.
+#include "common.hpp"
+
+namespace trico {
+
+namespace {
+
+typedef unsigned long long u64;
+
+constexpr uint32_t E = 20;                 // table exponent (both tables)
+constexpr uint32_t TSIZE = 1u << E;
+constexpr uint32_t RING = 4096;            // bytes, encoder output staging (a step emits at most 32 + 512 bytes)
+constexpr int PF = 4;
+
+__device__ __forceinline__ uint32_t dpp_shr1(uint32_t carry, uint32_t v)
+  {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)v, 0x138, 0xf, 0xf, false);
+  }
+__device__ __forceinline__ uint32_t dpp_shl1(uint32_t carry, uint32_t v)
+  {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)v, 0x130, 0xf, 0xf, false);
+  }
+__device__ __forceinline__ u64 dpp_shr1_64(u64 carry, u64 v)
+  {
+  return ((u64)dpp_shr1((uint32_t)(carry >> 32), (uint32_t)(v >> 32)) << 32) | dpp_shr1((uint32_t)carry, (uint32_t)v);
+  }
+__device__ __forceinline__ u64 readlane64(u64 v, int l)
+  {
+  return ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+  }
+__device__ __forceinline__ u64 bpermute64(int src_lane, u64 v)
+  {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)(v >> 32));
+  return ((u64)hi << 32) | lo;
+  }
+__device__ __forceinline__ uint32_t popc_below(uint64_t mask)
+  {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+  }
+__device__ __forceinline__ uint32_t blen64(u64 x) { return x ? (71u - (uint32_t)__builtin_clzll(x)) >> 3 : 0u; }
+
+// coherent table access (the same wave re-reads entries it wrote a step earlier: bypass the vector L1)
+__device__ __forceinline__ u64 tab_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void tab_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// src = nearest lower active lane with the same key (-1 if none), last = no higher active lane has it.
+// Runs of equal keys are resolved by neighbours; only run boundaries enter the loop over distinct keys.
+__device__ __forceinline__ void wave_pred(uint32_t key, bool act, uint64_t lt, int lane, bool& start, int& src, bool& last)
+  {
+  const uint32_t kp = dpp_shr1(0xfffffffeu, key), kn = dpp_shl1(0xfffffffeu, key);
+  start = act && key != kp;
+  const bool end = act && key != kn;
+  src = start ? -1 : lane - 1;
+  last = end;
+  // a class needs the loop only if it has more than one run in this step
+  uint64_t todo = __ballot(start);
+  while (todo)
+    {
+    const int leader = __builtin_ctzll(todo);
+    const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+    const bool mine = key == kk;
+    const uint64_t mS = __ballot(mine && start);
+    if (mS & (mS - 1ull))                                  // several runs of this class
+      {
+      const uint64_t mE = __ballot(mine && end);
+      if (mine)
+        {
+        const uint64_t lower = mE & lt;
+        if (start)
+          src = lower ? 63 - __builtin_clzll(lower) : -1;
+        last = end && (mE >> lane) == 1ull;
+        }
+      }
+    todo &= ~mS;
+    }
+  }
+
+struct Carry64 { u64 m1, m2, m3; };
+
+// ---- encoder -------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_fpc64_encode(const u64* __restrict__ src, uint32_t n, int arity, uint8_t* __restrict__ out_base,
+                                                     size_t out_stride, uint32_t* __restrict__ sizes, u64* __restrict__ tables)
+  {
+  __shared__ uint32_t ringw[RING / 4];
+  uint8_t* ring = (uint8_t*)ringw;
+  const int lane = threadIdx.x;
+  const int c = blockIdx.x;
+  u64* T1 = tables + (size_t)c * 2 * TSIZE;
+  u64* T2 = T1 + TSIZE;
+  uint8_t* out = out_base + (size_t)c * out_stride;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  uint32_t pos = 5, flushed = 0;
+  if (lane == 0)
+    {
+    ring[0] = 0xaa;                          // (20/2) << 4 | (20/2), fpsc.c:609
+    ring[1] = (uint8_t)(n >> 24); ring[2] = (uint8_t)(n >> 16); ring[3] = (uint8_t)(n >> 8); ring[4] = (uint8_t)n;
+    }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  Carry64 cy = { 0, 0, 0 };
+  const uint32_t n2 = (n + 1u) & ~1u;        // slots incl. the tail padding slot (fpsc.c:789-794)
+  u64 cur[PF], nxt[PF];
+#pragma unroll
+  for (int pu = 0; pu < PF; ++pu)
+    {
+    const uint32_t i = 64u * pu + lane;
+    cur[pu] = i < n ? src[(size_t)i * arity + c] : 0ull;
+    }
+  for (uint32_t ib = 0; ib < n || ib == 0; ib += 64u * PF)
+    {
+#pragma unroll
+    for (int pu = 0; pu < PF; ++pu)
+      {
+      const uint32_t i = ib + 64u * PF + 64u * pu + lane;
+      nxt[pu] = i < n ? src[(size_t)i * arity + c] : 0ull;
+      }
+#pragma unroll
+    for (int pu = 0; pu < PF; ++pu)
+      {
+      const uint32_t i0 = ib + 64u * pu;
+      if (i0 >= n && !(n == 0 && i0 == 0))
+        break;
+      const uint32_t i = i0 + lane;
+      const bool act = i < n;
+      const u64 v = cur[pu];
+      const u64 a = dpp_shr1_64(cy.m1, v), b = dpp_shr1_64(cy.m2, a), d = dpp_shr1_64(cy.m3, b);
+      const u64 s = v - a, s1 = a - b, s2 = b - d;
+      uint32_t k1 = (uint32_t)(a >> 44);                                                     // fpsc.c:565-568, e1 = 20
+      uint32_t k2 = ((((uint32_t)(s2 >> 44)) & 1023u) << 10) ^ (uint32_t)(s1 >> 44);       // fpsc.c:570-573, e2 = 20
+      if (!act)
+        k1 = k2 = 0xffffffffu;
+      int src1, src2;
+      bool st1, st2, last1, last2;
+      wave_pred(k1, act, lt, lane, st1, src1, last1);
+      wave_pred(k2, act, lt, lane, st2, src2, last2);
+      u64 p1 = a, p2 = s1;                   // inside a run: previous lane's value / stride
+      const bool t1 = st1 && src1 < 0, t2 = st2 && src2 < 0;
+      u64 tv1 = 0, tv2 = 0;
+      if (__ballot(t1 || t2))
+        __builtin_amdgcn_s_waitcnt(0);       // scatters of earlier steps must have reached L2 before they are re-read
+      if (t1) tv1 = tab_load(&T1[k1]);
+      if (t2) tv2 = tab_load(&T2[k2]);
+      if (__ballot((st1 && src1 >= 0) || (st2 && src2 >= 0)))
+        {
+        const u64 q1 = bpermute64(src1, v), q2 = bpermute64(src2, s);
+        if (st1) p1 = q1;
+        if (st2) p2 = q2;
+        }
+      if (t1) p1 = tv1;
+      if (t2) p2 = tv2;
+      if (last1) tab_store(&T1[k1], v);
+      if (last2) tab_store(&T2[k2], s);
+      // code selection (fpsc.c:635-782)
+      const u64 x1 = v ^ p1, x2 = v ^ (a + p2);
+      const uint32_t n1 = blen64(x1);
+      uint32_t nn2 = blen64(x2);
+      nn2 = nn2 ? nn2 : 1u;
+      const bool use2 = n1 > 1u && nn2 < n1;
+      uint32_t len = use2 ? nn2 : n1;
+      uint32_t code = use2 ? 8u + nn2 : n1;
+      u64 x = use2 ? x2 : x1;
+      const bool slot = act || (i < n2) || (n == 0 && i < 2u);
+      if (!act)
+        {
+        code = slot ? 1u : 0u;
+        len = slot ? 1u : 0u;
+        x = 0;
+        }
+      // layout of the step: [hdr g0][res 0][res 1][hdr g1][res 2][res 3]...
+      const uint64_t b0 = __ballot(len & 1u), b1 = __ballot(len & 2u), b2 = __ballot(len & 4u), b3 = __ballot(len & 8u);
+      const uint32_t pre = popc_below(b0) + 2u * popc_below(b1) + 4u * popc_below(b2) + 8u * popc_below(b3);
+      const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)code, 0xB1, 0xf, 0xf, true);    // partner lane's code
+      const uint32_t grp = (uint32_t)lane >> 1;
+      const uint32_t rpos = pos + (grp + 1u) + pre;
+      for (uint32_t kb = 0; kb < len; ++kb)
+        ring[(rpos + kb) & (RING - 1)] = (uint8_t)(x >> (8u * (len - 1u - kb)));
+      if (slot && (lane & 1) == 0)
+        ring[(pos + grp + pre) & (RING - 1)] = (uint8_t)((other << 4) | code);
+      const uint32_t nslots = (uint32_t)__popcll(__ballot(slot));
+      pos += (nslots >> 1) + (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2) + 8u * (uint32_t)__popcll(b3);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      while (pos - flushed >= 256u)
+        {
+        const uint32_t off = flushed + 4u * lane;
+        *(uint32_t*)(out + off) = ringw[(off & (RING - 1)) >> 2];
+        flushed += 256u;
+        }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      cy.m1 = readlane64(v, 63);
+      cy.m2 = readlane64(v, 62);
+      cy.m3 = readlane64(v, 61);
+      }
+#pragma unroll
+    for (int pu = 0; pu < PF; ++pu)
+      cur[pu] = nxt[pu];
+    if (n == 0)
+      break;
+    }
+  while (flushed < pos)
+    {
+    const uint32_t off = flushed + 4u * lane;
+    if (off < pos)
+      {
+      const uint32_t w = ringw[(off & (RING - 1)) >> 2];
+      if (off + 4u <= pos)
+        *(uint32_t*)(out + off) = w;
+      else
+        for (uint32_t bb = 0; off + bb < pos; ++bb)
+          out[off + bb] = (uint8_t)(w >> (8u * bb));
+      }
+    flushed += 256u;
+    }
+  if (lane == 0)
+    sizes[c] = pos;
+  }
+
+// ---- decoder -------------------------------------------------------------------------------------------
+constexpr int WINW = 4096;                 // staging window, dwords (16 KiB)
+constexpr uint32_t BATCH_BYTES = 32 * 17;  // 32 groups of at most 1 + 16 bytes
+
+struct DecodeArgs
+  {
+  const uint8_t* pay[3];
+  uint32_t size[3];
+  };
+
+__device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint32_t nib_len(uint32_t c) { return c <= 8u ? c : c - 8u; }
+
+__global__ void __launch_bounds__(64) k_fpc64_decode(DecodeArgs args, int arity, uint32_t n, u64* __restrict__ dst, u64* __restrict__ tables,
+                                                     uint32_t* __restrict__ status)
+  {
+  __shared__ uint32_t win[WINW + 8];
+  const int lane = threadIdx.x;
+  const int comp = blockIdx.x;
+  const uint8_t* in = args.pay[comp];
+  const uint32_t len = args.size[comp];
+  if (len < 5u)
+    {
+    if (lane == 0) atomicOr(status, 1u);
+    return;
+    }
+  const uint32_t e1 = (uint32_t)(in[0] >> 4) << 1, e2 = (uint32_t)(in[0] & 15) << 1;
+  const uint32_t cnt = ((uint32_t)in[1] << 24) | ((uint32_t)in[2] << 16) | ((uint32_t)in[3] << 8) | in[4];
+  if (cnt != n || e1 == 0u || e2 == 0u || e1 > E || e2 > E)
+    {
+    if (lane == 0) atomicOr(status, 2u);
+    return;
+    }
+  u64* T1 = tables + (size_t)comp * 2 * TSIZE;
+  u64* T2 = T1 + TSIZE;
+  const u64 m1 = (1ull << e1) - 1ull, m2 = (1ull << e2) - 1ull;
+  const uint32_t sh1 = 64u - e1, sh2 = 64u - e2, e2h = e2 >> 1;
+  const uint32_t al = (uint32_t)((uintptr_t)in & 3u);
+  const uint32_t* abase = (const uint32_t*)(in - al);
+  const uint32_t total_q = len + al;
+  const uint32_t ndw = (total_q + 3u) >> 2;
+  uint32_t wd = 0, q = 5u + al;
+  auto refill = [&](uint32_t from_q)
+    {
+    __syncthreads();
+    wd = from_q >> 2;
+    for (uint32_t i = (uint32_t)lane; i < (uint32_t)WINW + 8u; i += 64u)
+      win[i] = (wd + i < ndw) ? abase[wd + i] : 0u;
+    __syncthreads();
+    };
+  refill(q);
+  const uint8_t* wb = (const uint8_t*)win;
+  u64 h1 = 0, h2 = 0, p1 = 0, last = 0, t2v = 0;      // wave-uniform; t2v = T2[h2] as of now
+  bool bad = false;
+  for (uint32_t i0 = 0; i0 < n; i0 += 64u)
+    {
+    if (q + BATCH_BYTES + 16u > 4u * (wd + (uint32_t)WINW))
+      refill(q);
+    const uint32_t nvals = n - i0 < 64u ? n - i0 : 64u;
+    const uint32_t ngroups = (nvals + 1u) >> 1;
+    // ---- positions of the groups: scalar walk over the header bytes ---------------------------------
+    uint32_t lq = q - 4u * wd;
+    uint32_t myhdr = 0, myq = 0;
+    for (uint32_t g = 0; g < ngroups; ++g)
+      {
+      const uint32_t hdr = rfl((uint32_t)wb[lq]);
+      if (((uint32_t)lane >> 1) == g)
+        {
+        myhdr = hdr;
+        myq = lq;
+        }
+      lq += 1u + nib_len(hdr & 15u) + nib_len(hdr >> 4);
+      }
+    const uint32_t qend = 4u * wd + lq;
+    if (qend > total_q)
+      {
+      bad = true;
+      break;
+      }
+    q = qend;
+    // ---- all lanes fetch their residual -----------------------------------------------------------------
+    const uint32_t code = (lane & 1) ? (myhdr >> 4) : (myhdr & 15u);
+    const uint32_t nb = nib_len(code);
+    const uint32_t rp = myq + 1u + ((lane & 1) ? nib_len(myhdr & 15u) : 0u);
+    const uint32_t w0 = win[rp >> 2], w1 = win[(rp >> 2) + 1u], w2 = win[(rp >> 2) + 2u];
+    const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, rp & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, rp & 3u);
+    const u64 be = ((u64)__builtin_bswap32(lo) << 32) | __builtin_bswap32(hi);      // first stream byte on top
+    const u64 xr = nb ? be >> (8u * (8u - nb)) : 0ull;
+    const uint64_t dfcm = __ballot(code > 8u);
+    // ---- the dependent chain (wave-uniform) ---------------------------------------------------------------
+    u64 outv = 0;
+    for (uint32_t k = 0; k < nvals; ++k)
+      {
+      const u64 x = readlane64(xr, (int)k);
+      u64 p = p1;
+      if ((dfcm >> k) & 1ull)
+        p = last + t2v;                                           // fpsc.c:977-978 with prediction2 = value + table
+      const u64 v = x ^ p;
+      tab_store(&T1[h1], v);
+      const u64 nh1 = ((h1 << e1) ^ (v >> sh1)) & m1;
+      if (nh1 != h1)
+        {
+        __builtin_amdgcn_s_waitcnt(0);
+        p1 = tab_load(&T1[nh1]);
+        }
+      else
+        p1 = v;                                                   // same key: the entry is the value just written
+      h1 = nh1;
+      const u64 s = v - last;
+      tab_store(&T2[h2], s);
+      const u64 nh2 = ((h2 << e2h) ^ (s >> sh2)) & m2;
+      if (nh2 != h2)
+        {
+        __builtin_amdgcn_s_waitcnt(0);
+        t2v = tab_load(&T2[nh2]);
+        }
+      else
+        t2v = s;
+      h2 = nh2;
+      last = v;
+      outv = ((uint32_t)lane == k) ? v : outv;
+      }
+    const uint32_t idx = i0 + (uint32_t)lane;
+    if (idx < n)
+      dst[(size_t)idx * arity + comp] = outv;
+    }
+  if (bad && lane == 0)
+    atomicOr(status, 4u);
+  }
+
+} // namespace
+
+int launch_fpc64_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes, uint64_t* d_tables)
+  {
+  hipLaunchKernelGGL(k_fpc64_encode, dim3(arity), dim3(64), 0, current_stream(),
+                     (const u64*)d_src, n, arity, d_out, out_stride, d_sizes, (u64*)d_tables);
+  return hip_ok(hipGetLastError(), "k_fpc64_encode") ? 1 : 0;
+  }
+
+int launch_fpc64_decode(const uint8_t* const d_payloads[3], const uint32_t sizes[3], int arity, uint32_t n, void* d_dst,
+                        uint64_t* d_tables, uint32_t* d_status)
+  {
+  DecodeArgs a;
+  for (int c = 0; c < 3; ++c)
+    {
+    a.pay[c] = c < arity ? d_payloads[c] : nullptr;
+    a.size[c] = c < arity ? sizes[c] : 0;
+    }
+  hipLaunchKernelGGL(k_fpc64_decode, dim3(arity), dim3(64), 0, current_stream(), a, arity, n, (u64*)d_dst, (u64*)d_tables, d_status);
+  return hip_ok(hipGetLastError(), "k_fpc64_decode") ? 1 : 0;
+  }
+
+} // namespace trico

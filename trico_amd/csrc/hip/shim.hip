@@ -67,7 +67,7 @@ void DevBuf::release()
   }
 
 // ---- profiling ---------------------------------------------------------------------------------
-struct ProfRec { hipEvent_t e0, e1; int k; };
+struct ProfRec { hipEvent_t e0, e1; int k; bool counted; };
 static bool g_prof_on = false;
 static ProfRec* g_prof = nullptr;
 static size_t g_prof_n = 0, g_prof_cap = 0;
@@ -82,7 +82,7 @@ static void prof_drain()
     if (hipEventSynchronize(g_prof[i].e1) == hipSuccess && hipEventElapsedTime(&ms, g_prof[i].e0, g_prof[i].e1) == hipSuccess)
       {
       g_prof_ms[g_prof[i].k] += ms;
-      g_prof_spans[g_prof[i].k] += 1;
+      g_prof_spans[g_prof[i].k] += g_prof[i].counted ? 1 : 0;
       }
     (void)hipEventDestroy(g_prof[i].e0);
     (void)hipEventDestroy(g_prof[i].e1);
@@ -90,7 +90,7 @@ static void prof_drain()
   g_prof_n = 0;
   }
 
-ProfSpan::ProfSpan(int kernel_id) : k(kernel_id), active(false)
+ProfSpan::ProfSpan(int kernel_id, bool count_launch) : k(kernel_id), active(false), counted(count_launch)
   {
   if (!g_prof_on)
     return;
@@ -114,7 +114,7 @@ ProfSpan::~ProfSpan()
     g_prof = np;
     g_prof_cap = nc;
     }
-  g_prof[g_prof_n++] = ProfRec{ e0, e1, k };
+  g_prof[g_prof_n++] = ProfRec{ e0, e1, k, counted };
   }
 
 static int g_device_state = 0;   // 0 unknown, 1 ok, -1 none
@@ -269,6 +269,7 @@ int trico_hip_fpc_encode(trico_hip_ctx* ctx, const void* src, uint32_t n, int ar
     return 0;
   ctx->out_stride = stride;
   ctx->out_count = 0;
+  ctx->out_in_slots = false;
   const void* d_src = n ? stage_in(ctx->in, src, in_bytes) : ctx->in.p;
   if (!d_src)
     return 0;
@@ -291,6 +292,16 @@ int trico_hip_fpc_encode(trico_hip_ctx* ctx, const void* src, uint32_t n, int ar
     if (!ctx->tmp.reserve(ws))
       return 0;
     if (!launch_fpc32_encode(d_src, n, arity, ctx->out.p, stride, d_sizes, ctx->tmp.p, ctx->tmp.cap))
+      return 0;
+    ctx->out_in_slots = n != 0;
+    ctx->slots_n = n;
+    ctx->slots_arity = arity;
+    for (int c = 0; c < 3; ++c)
+      ctx->out_materialized[c] = false;
+    }
+  else if (width == 8 && !force_serial_stage(1))
+    {
+    if (!launch_fpc64_encode(d_src, n, arity, ctx->out.p, stride, d_sizes, d_tables))
       return 0;
     }
   else if (!launch_fpc_encode_serial(d_src, n, arity, width, ctx->out.p, stride, d_sizes, d_tables))
@@ -369,6 +380,11 @@ int trico_hip_fpc_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[3], c
     if (!launch_fpc32_decode(d_pay, sizes, arity, n, d_dst, d_status))
       return 0;
     }
+  else if (width == 8 && !force_serial_stage(2))
+    {
+    if (!launch_fpc64_decode(d_pay, sizes, arity, n, d_dst, d_tables, d_status))
+      return 0;
+    }
   else if (!launch_fpc_decode_serial(d_pay, sizes, arity, width, n, d_dst, d_tables, d_status))
     return 0;
   }
@@ -406,6 +422,7 @@ int trico_hip_int_encode(trico_hip_ctx* ctx, const void* src, uint32_t count, in
     return 0;
   ctx->out_stride = stride;
   ctx->out_count = 0;
+  ctx->out_in_slots = false;
   const void* d_src = count ? stage_in(ctx->in, src, in_bytes) : ctx->in.p;
   if (!d_src)
     return 0;
@@ -537,6 +554,18 @@ int trico_hip_int_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[8], c
   return 1;
   }
 
+// float payloads of the throughput encoder live in segment slots: gather component c into ctx->out
+static int materialize(trico_hip_ctx* ctx, int c)
+  {
+  if (!ctx->out_in_slots || ctx->out_materialized[c])
+    return 1;
+  ProfSpan span(TRICO_HIP_K_FPC32_ENCODE, false);
+  if (!launch_fpc32_gather(ctx->slots_n, ctx->slots_arity, c, ctx->tmp.p, ctx->out.p + (size_t)c * ctx->out_stride))
+    return 0;
+  ctx->out_materialized[c] = true;
+  return 1;
+  }
+
 int trico_hip_fetch_payload(trico_hip_ctx* ctx, int c, void* dst)
   {
   if (!ctx || c < 0 || c >= ctx->out_count)
@@ -544,12 +573,24 @@ int trico_hip_fetch_payload(trico_hip_ctx* ctx, int c, void* dst)
     set_error("trico_hip_fetch_payload: no such payload");
     return 0;
     }
+  if (ctx->out_in_slots && !ctx->out_materialized[c] && trico_hip_pointer_is_device(dst))
+    {
+    // straight from the segment slots into the destination (e.g. the device-resident archive buffer)
+    ProfSpan span(TRICO_HIP_K_FPC32_ENCODE, false);
+    if (!launch_fpc32_gather(ctx->slots_n, ctx->slots_arity, c, ctx->tmp.p, (uint8_t*)dst))
+      return 0;
+    return 1;
+    }
+  if (!materialize(ctx, c))
+    return 0;
   return trico_hip_copy(dst, ctx->out.p + (size_t)c * ctx->out_stride, ctx->out_sizes[c]);
   }
 
 const uint8_t* trico_hip_payload_device_pointer(trico_hip_ctx* ctx, int c)
   {
   if (!ctx || c < 0 || c >= ctx->out_count)
+    return nullptr;
+  if (!materialize(ctx, c))
     return nullptr;
   return ctx->out.p + (size_t)c * ctx->out_stride;
   }
