@@ -65,16 +65,27 @@ __device__ __forceinline__ u64 tab_load(const u64* p) { return __hip_atomic_load
 __device__ __forceinline__ void tab_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // src = nearest lower active lane with the same key (-1 if none), last = no higher active lane has it.
-// Runs of equal keys are resolved by neighbours; only run boundaries enter the loop over distinct keys.
-__device__ __forceinline__ void wave_pred(uint32_t key, bool act, uint64_t lt, int lane, bool& start, int& src, bool& last)
+// Runs of equal keys are resolved by neighbours.  Whether a class has several runs in this step is probed
+// through a 4096-entry lane-id table in LDS (run starts write their lane at LID[key & 4095] and read it
+// back: a lane that does not read itself shares the slot with another run); only such classes enter the
+// ballot loop.  On data with 64 different classes per step the loop does not run at all.
+__device__ __forceinline__ void wave_pred(uint32_t key, bool act, uint8_t* __restrict__ LID, uint64_t lt, int lane,
+                                          bool& start, int& src, bool& last)
   {
   const uint32_t kp = dpp_shr1(0xfffffffeu, key), kn = dpp_shl1(0xfffffffeu, key);
   start = act && key != kp;
   const bool end = act && key != kn;
   src = start ? -1 : lane - 1;
   last = end;
-  // a class needs the loop only if it has more than one run in this step
-  uint64_t todo = __ballot(start);
+  const uint32_t slot = key & 4095u;
+  if (start)
+    LID[slot] = (uint8_t)lane;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  uint32_t w = (uint32_t)lane;
+  if (start)
+    w = LID[slot];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  uint64_t todo = __ballot(start && w != (uint32_t)lane);
   while (todo)
     {
     const int leader = __builtin_ctzll(todo);
@@ -103,6 +114,7 @@ __global__ void __launch_bounds__(64) k_fpc64_encode(const u64* __restrict__ src
                                                      size_t out_stride, uint32_t* __restrict__ sizes, u64* __restrict__ tables)
   {
   __shared__ uint32_t ringw[RING / 4];
+  __shared__ uint8_t LID[4096];
   uint8_t* ring = (uint8_t*)ringw;
   const int lane = threadIdx.x;
   const int c = blockIdx.x;
@@ -151,8 +163,8 @@ __global__ void __launch_bounds__(64) k_fpc64_encode(const u64* __restrict__ src
         k1 = k2 = 0xffffffffu;
       int src1, src2;
       bool st1, st2, last1, last2;
-      wave_pred(k1, act, lt, lane, st1, src1, last1);
-      wave_pred(k2, act, lt, lane, st2, src2, last2);
+      wave_pred(k1, act, LID, lt, lane, st1, src1, last1);
+      wave_pred(k2, act, LID, lt, lane, st2, src2, last2);
       u64 p1 = a, p2 = s1;                   // inside a run: previous lane's value / stride
       const bool t1 = st1 && src1 < 0, t2 = st2 && src2 < 0;
       u64 tv1 = 0, tv2 = 0;
@@ -237,6 +249,7 @@ __global__ void __launch_bounds__(64) k_fpc64_encode(const u64* __restrict__ src
 // ---- decoder -------------------------------------------------------------------------------------------
 constexpr int WINW = 4096;                 // staging window, dwords (16 KiB)
 constexpr uint32_t BATCH_BYTES = 32 * 17;  // 32 groups of at most 1 + 16 bytes
+constexpr int CACHE = 4096;                // entries per table cache (2 x 48 KiB of LDS; one wave per CU anyway)
 
 struct DecodeArgs
   {
@@ -251,9 +264,16 @@ __global__ void __launch_bounds__(64) k_fpc64_decode(DecodeArgs args, int arity,
                                                      uint32_t* __restrict__ status)
   {
   __shared__ uint32_t win[WINW + 8];
+  __shared__ uint32_t ctag1[CACHE], ctag2[CACHE];      // direct-mapped write-through cache of the two tables
+  __shared__ u64 cval1[CACHE], cval2[CACHE];
   const int lane = threadIdx.x;
   const int comp = blockIdx.x;
   const uint8_t* in = args.pay[comp];
+  for (int i = lane; i < CACHE; i += 64)
+    {
+    ctag1[i] = 0xffffffffu;                            // no key equals this (keys have at most 20 bits)
+    ctag2[i] = 0xffffffffu;
+    }
   const uint32_t len = args.size[comp];
   if (len < 5u)
     {
@@ -324,6 +344,10 @@ __global__ void __launch_bounds__(64) k_fpc64_decode(DecodeArgs args, int arity,
     const u64 xr = nb ? be >> (8u * (8u - nb)) : 0ull;
     const uint64_t dfcm = __ballot(code > 8u);
     // ---- the dependent chain (wave-uniform) ---------------------------------------------------------------
+    // Table writes go through to global memory (fire and forget) and into a direct-mapped LDS cache; a read
+    // is served by the "same key as just written" shortcut, else by the cache, else by a dependent L2 load.
+    // Lane 0 performs every global store and load itself, so per-thread same-address ordering makes the loads
+    // see the earlier stores without draining the store queue.
     u64 outv = 0;
     for (uint32_t k = 0; k < nvals; ++k)
       {
@@ -332,23 +356,53 @@ __global__ void __launch_bounds__(64) k_fpc64_decode(DecodeArgs args, int arity,
       if ((dfcm >> k) & 1ull)
         p = last + t2v;                                           // fpsc.c:977-978 with prediction2 = value + table
       const u64 v = x ^ p;
-      tab_store(&T1[h1], v);
+      if (lane == 0) tab_store(&T1[h1], v);
+      {
+      const uint32_t cs = (uint32_t)h1 & (CACHE - 1);
+      ctag1[cs] = (uint32_t)h1;
+      cval1[cs] = v;
+      }
       const u64 nh1 = ((h1 << e1) ^ (v >> sh1)) & m1;
       if (nh1 != h1)
         {
-        __builtin_amdgcn_s_waitcnt(0);
-        p1 = tab_load(&T1[nh1]);
+        const uint32_t cs = (uint32_t)nh1 & (CACHE - 1);
+        if (rfl(ctag1[cs]) == (uint32_t)nh1)
+          p1 = cval1[cs];
+        else
+          {
+          p1 = 0;
+          if (lane == 0) p1 = tab_load(&T1[nh1]);      // lane 0 did the stores: per-thread ordering
+          p1 = ((u64)rfl((uint32_t)(p1 >> 32)) << 32) | rfl((uint32_t)p1);
+          ctag1[cs] = (uint32_t)nh1;
+          cval1[cs] = p1;
+          }
+        p1 = ((u64)rfl((uint32_t)(p1 >> 32)) << 32) | rfl((uint32_t)p1);
         }
       else
         p1 = v;                                                   // same key: the entry is the value just written
       h1 = nh1;
       const u64 s = v - last;
-      tab_store(&T2[h2], s);
+      if (lane == 0) tab_store(&T2[h2], s);
+      {
+      const uint32_t cs = (uint32_t)h2 & (CACHE - 1);
+      ctag2[cs] = (uint32_t)h2;
+      cval2[cs] = s;
+      }
       const u64 nh2 = ((h2 << e2h) ^ (s >> sh2)) & m2;
       if (nh2 != h2)
         {
-        __builtin_amdgcn_s_waitcnt(0);
-        t2v = tab_load(&T2[nh2]);
+        const uint32_t cs = (uint32_t)nh2 & (CACHE - 1);
+        if (rfl(ctag2[cs]) == (uint32_t)nh2)
+          t2v = cval2[cs];
+        else
+          {
+          t2v = 0;
+          if (lane == 0) t2v = tab_load(&T2[nh2]);
+          t2v = ((u64)rfl((uint32_t)(t2v >> 32)) << 32) | rfl((uint32_t)t2v);
+          ctag2[cs] = (uint32_t)nh2;
+          cval2[cs] = t2v;
+          }
+        t2v = ((u64)rfl((uint32_t)(t2v >> 32)) << 32) | rfl((uint32_t)t2v);
         }
       else
         t2v = s;

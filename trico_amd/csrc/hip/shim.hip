@@ -529,7 +529,7 @@ int trico_hip_int_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[8], c
   {
   ProfSpan span(TRICO_HIP_K_LZ4_DECODE);
   if (!(force_serial_stage(8) ? launch_lz4_decode_serial(d_pay, sizes, width, d_planes, plane_stride, count, d_status)
-                       : launch_lz4_decode_wave(d_pay, sizes, width, d_planes, plane_stride, count, d_status)))
+                       : launch_lz4_decode_lds(d_pay, sizes, width, d_planes, plane_stride, count, d_status)))
     return 0;
   }
   if (width > 1)
