@@ -145,7 +145,7 @@ def main():
 
     def step(check=False):
         te0 = time.perf_counter()
-        a = api.Archive.open_for_writing(1 << 20, device=True)
+        a = api.Archive.open_for_writing(raw_bytes // 4, device=True)      # caller-chosen initial size: no regrowth
         assert a.write("vertices", d_v, nv) == 1, api.last_error()
         assert a.write("triangles", d_t, nt) == 1, api.last_error()
         torch.cuda.synchronize()

@@ -116,3 +116,21 @@ def test_planes_roundtrip():
         p = O.split_planes(a)
         for k in range(dt().itemsize):
             assert np.array_equal(p[k], ((a >> (8 * k)) & 0xFF).astype(np.uint8))
+
+
+BUNNY_SHA256 = "91eb3432634421fc2e7807998fef01557df6dc7e732f821316bfb289cd3d1766"     # 584,613 B
+
+
+def test_bunny_real_mesh(gold_dir):
+    """The reference's only fixture (trico.tests/data/StanfordBunny.stl) through the restated STL reader
+    (iostl.c:70-195 order) and the oracle: size and sha256 of the archive the reference produces."""
+    from stl import read_stl
+    v, t, nt = read_stl(os.path.join(gold_dir, "StanfordBunny.stl"))
+    assert (v.size // 3, nt) == (34834, 69451)
+    a = O.OracleArchive()
+    a.write("vertices", v, v.size // 3)
+    a.write("triangles", t, nt)
+    got = a.tobytes()
+    a.close()
+    assert len(got) == 584613
+    assert hashlib.sha256(got).hexdigest() == BUNNY_SHA256

@@ -23,8 +23,9 @@ struct DevBuf
   uint8_t* p = nullptr;
   size_t cap = 0;
   bool reserve(size_t bytes);   // grow-only, contents NOT preserved
-  void release();
+  void release();               // returns the memory to a process-wide pool
   };
+void trim_pool();               // hipFree everything the pool holds
 
 } // namespace trico
 

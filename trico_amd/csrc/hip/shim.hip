@@ -2,6 +2,7 @@
 // host<->device staging and dispatch to the gfx950 kernels.  No compute happens on the host.
 #include "common.hpp"
 
+#include <mutex>
 #include <new>
 #include <stdio.h>
 #include <stdlib.h>
@@ -44,15 +45,41 @@ static int serial_mask()
 bool force_serial() { return serial_mask() == 15; }
 bool force_serial_stage(int bit) { return (serial_mask() & bit) != 0; }
 
+// Device workspaces are recycled across contexts (one context per archive handle): hipMalloc / hipFree of
+// multi-GB buffers cost hundreds of milliseconds and an implicit device sync each.
+struct PoolEntry { uint8_t* p; size_t cap; };
+static PoolEntry g_pool[24];
+static int g_pool_n = 0;
+static std::mutex g_pool_mutex;
+
 bool DevBuf::reserve(size_t bytes)
   {
   if (bytes <= cap)
     return true;
   release();
+  {
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  int best = -1;
+  for (int i = 0; i < g_pool_n; ++i)
+    if (g_pool[i].cap >= bytes && (best < 0 || g_pool[i].cap < g_pool[best].cap))
+      best = i;
+  if (best >= 0 && g_pool[best].cap <= 4 * bytes + (64u << 20))
+    {
+    p = g_pool[best].p;
+    cap = g_pool[best].cap;
+    g_pool[best] = g_pool[--g_pool_n];
+    return true;
+    }
+  }
   const size_t want = align_up(bytes + bytes / 8, 4096);
   void* np = nullptr;
   if (!hip_ok(hipMalloc(&np, want), "hipMalloc(workspace)"))
-    return false;
+    {
+    // out of memory: give the pooled buffers back and retry once
+    trim_pool();
+    if (!hip_ok(hipMalloc(&np, want), "hipMalloc(workspace)"))
+      return false;
+    }
   p = (uint8_t*)np;
   cap = want;
   return true;
@@ -61,9 +88,23 @@ bool DevBuf::reserve(size_t bytes)
 void DevBuf::release()
   {
   if (p)
-    (void)hipFree(p);
+    {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    if (g_pool_n < (int)(sizeof(g_pool) / sizeof(g_pool[0])))
+      g_pool[g_pool_n++] = PoolEntry{ p, cap };
+    else
+      (void)hipFree(p);
+    }
   p = nullptr;
   cap = 0;
+  }
+
+void trim_pool()
+  {
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  for (int i = 0; i < g_pool_n; ++i)
+    (void)hipFree(g_pool[i].p);
+  g_pool_n = 0;
   }
 
 // ---- profiling ---------------------------------------------------------------------------------
@@ -225,20 +266,48 @@ int trico_hip_pointer_is_device(const void* p)
   return attr.type == hipMemoryTypeDevice ? 1 : 0;
   }
 
+// device allocations handed to the host code (archive buffers) come from the same pool as the workspaces
+struct LiveAlloc { void* p; size_t cap; };
+static LiveAlloc g_live[64];
+static int g_live_n = 0;
+static std::mutex g_live_mutex;
+
 void* trico_hip_device_alloc(size_t bytes)
   {
   if (!device_ready())
     return nullptr;
-  void* p = nullptr;
-  if (!hip_ok(hipMalloc(&p, bytes ? bytes : 1), "hipMalloc"))
+  DevBuf b;
+  if (!b.reserve(bytes ? bytes : 1))
     return nullptr;
-  return p;
+  std::lock_guard<std::mutex> lock(g_live_mutex);
+  if (g_live_n == (int)(sizeof(g_live) / sizeof(g_live[0])))
+    {
+    (void)hipFree(b.p);              // table full: untracked allocations are simply freed on release
+    void* p = nullptr;
+    return hip_ok(hipMalloc(&p, bytes ? bytes : 1), "hipMalloc") ? p : nullptr;
+    }
+  g_live[g_live_n++] = LiveAlloc{ b.p, b.cap };
+  return b.p;
   }
 
 void trico_hip_device_free(void* p)
   {
-  if (p)
-    (void)hipFree(p);
+  if (!p)
+    return;
+  {
+  std::lock_guard<std::mutex> lock(g_live_mutex);
+  for (int i = 0; i < g_live_n; ++i)
+    if (g_live[i].p == p)
+      {
+      DevBuf b;
+      b.p = (uint8_t*)p;
+      b.cap = g_live[i].cap;
+      g_live[i] = g_live[--g_live_n];
+      b.release();                   // back to the pool
+      return;
+      }
+  }
+  (void)hipFree(p);
   }
 
 int trico_hip_copy(void* dst, const void* src, size_t bytes)
