@@ -37,10 +37,8 @@ namespace {
 constexpr int TAB = 1040;      // 16 FCM entries followed by 1024 DFCM entries
 constexpr int ROW = 1040;      // words per (segment, component) row in the global index tables
 constexpr int CH = 32;         // segments per chunk in the cross-segment scan
-constexpr int RING = 1024;     // bytes of per-wave output staging ring
 constexpr int MASKW = 2 * TAB;  // words of the per-class lane-mask table (u64 per class)
 constexpr int LDSW_A = TAB;                        // per-wave LDS words, sweep A
-constexpr int LDSW_C = TAB + RING / 4 + MASKW;     // per-wave LDS words, sweep C (13,504 B: 4 x 3 waves per CU)
 constexpr int PF = 8;          // steps (of 64 values) whose loads are kept in flight per wave
 
 __device__ __forceinline__ uint32_t dpp_shr1(uint32_t carry, uint32_t v)
@@ -214,41 +212,104 @@ __global__ void __launch_bounds__(256) k_fpc32_scan_b(const uint32_t* __restrict
   }
 
 // ---- sweep C -------------------------------------------------------------------------------------------
+//
+// Instruction count is what bounds this sweep (a wave64 VALU instruction occupies its 16-lane SIMD for 4
+// cycles; at ~100+ instructions per 64 values the VALU time exceeds the HBM time by far), so the step is
+// organised around doing nothing that the data does not ask for:
+//   * lane 0 compares its class with the class of the previous step's last value (carried in SGPRs), so a
+//     run of equal classes can span any number of steps.  A step without a run start in a predictor needs
+//     no table access for it at all: every value is predicted from the previous lane (FCM: previous value,
+//     DFCM: previous stride), and the table write of the step's last value stays *pending* in the carry;
+//   * only when a predictor has a run start in the step, its pending write is flushed and the run starts
+//     are resolved (mask table M + payload table T, below), for that predictor alone or for both at once
+//     so that their LDS round trips overlap;
+//   * the packed bytes of a step go to a linear LDS staging area, so byte addresses are base + immediate;
+//     a residual is stored as the 4 big-endian bytes that END at its last byte: the leading zero bytes
+//     land on bytes of earlier lanes / headers of the same step, all of which are written by a later
+//     instruction (proof in DESIGN.md), so there is no per-byte predicate;
+//   * full steps (64 values, the normal case) are a separate instantiation without activity masks.
+//
+// Run starts: lanes form runs of equal class.  A run START needs the nearest lower lane of its class, which
+// is the END lane of an earlier run: run ends OR their lane bit into M[class] (u64 per class, zero between
+// steps), every lane reads its class's mask back, ends clear it.  The nearest lower set bit is the source
+// lane (ds_bpermute); no bit below means the table T holds the latest earlier value (from an earlier step
+// or the segment's incoming table).  The run end whose mask has no higher bit owns the table write.
 
-// Who wrote my class last, inside this step?  Lanes form runs of equal class.  Inside a run it is the
-// previous lane.  A run START needs the nearest lower lane of its class, which is the END lane of an
-// earlier run: run ends OR their lane bit into M[class] (u64 per class, zero between steps), every lane
-// reads its class's mask back, ends clear it.  Constant cost for any number of classes; both predictors
-// (FCM classes [0,16), DFCM classes [16,1040)) are resolved together so their LDS round trips overlap.
-//   src  : lane holding the latest earlier value of my class inside this step, -1 if none
-//   last : I am the last value of my class in this step (I own the table write)
-struct Pred { bool st1, st2, last1, last2; int src1, src2; };
+constexpr int STAGE_LIVE = 544;                   // < 256 unflushed + <= 280 of the step, rounded
+constexpr int STAGE = STAGE_LIVE + 256;           // + 4 dump bytes per lane
+constexpr int LDSW_C = TAB + STAGE / 4 + MASKW;   // per-wave LDS words, sweep C (13,280 B: 4 x 3 waves per CU)
 
-__device__ __forceinline__ Pred wave_pred2(uint32_t k1, uint32_t k2, bool act, uint64_t* __restrict__ M, uint64_t lt, int lane)
+struct LaneK                                      // per-lane constants
   {
-  Pred r;
-  const uint32_t kp1 = dpp_shr1(0xfffffffeu, k1), kn1 = dpp_shl1(0xfffffffeu, k1);
-  const uint32_t kp2 = dpp_shr1(0xfffffffeu, k2), kn2 = dpp_shl1(0xfffffffeu, k2);
-  r.st1 = act && k1 != kp1;
-  r.st2 = act && k2 != kp2;
-  const bool en1 = act && k1 != kn1, en2 = act && k2 != kn2;
-  const unsigned long long bit = 1ull << lane;
-  if (en1) atomicOr((unsigned long long*)&M[k1], bit);
-  if (en2) atomicOr((unsigned long long*)&M[k2], bit);
+  int lane;
+  uint64_t lt, bit;
+  uint32_t sh3, grp3, dumpw, dumpq;
+  bool lead;
+  };
+
+struct Sweep                                      // wave-uniform running state
+  {
+  Carry cy;
+  uint32_t kc1, kc2;                              // classes of the previous step's last value
+  bool pend1, pend2;                              // its table writes are still pending
+  uint32_t posl, flushed;                         // bytes staged in LDS / bytes already in the slot
+  };
+
+template <bool FULL, bool D1, bool D2>
+__device__ __forceinline__ void resolve(uint32_t k1, uint32_t k2, bool st1, bool st2, bool act, uint32_t v, uint32_t s,
+                                        uint32_t& p1, uint32_t& p2, uint32_t* __restrict__ T, uint64_t* __restrict__ M,
+                                        Sweep& sw, const LaneK& lk)
+  {
+  // pending writes of the previous step's last value (lane 0 writes, the others hit their dump word)
+  if (D1 && sw.pend1) T[lk.lane == 0 ? sw.kc1 : lk.dumpw] = sw.cy.m1;
+  if (D2 && sw.pend2) T[lk.lane == 0 ? sw.kc2 : lk.dumpw] = sw.cy.m1 - sw.cy.m2;
+  bool en1 = false, en2 = false;
+  if (D1)
+    {
+    en1 = k1 != dpp_shl1(0xfffffffeu, k1);
+    if (!FULL) en1 = en1 && act;
+    if (en1) atomicOr((unsigned long long*)&M[k1], (unsigned long long)lk.bit);
+    }
+  if (D2)
+    {
+    en2 = k2 != dpp_shl1(0xfffffffeu, k2);
+    if (!FULL) en2 = en2 && act;
+    if (en2) atomicOr((unsigned long long*)&M[k2], (unsigned long long)lk.bit);
+    }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  const uint64_t m1 = M[act ? k1 : 0u], m2 = M[act ? k2 : 16u];       // unconditional (broadcast) reads
+  const uint32_t r1 = FULL ? k1 : (act ? k1 : 0u), r2 = FULL ? k2 : (act ? k2 : 16u);
+  uint64_t m1 = 0, m2 = 0;
+  uint32_t tv1 = 0, tv2 = 0;
+  if (D1) { m1 = M[r1]; tv1 = T[r1]; }
+  if (D2) { m2 = M[r2]; tv2 = T[r2]; }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  if (en1) M[k1] = 0ull;
-  if (en2) M[k2] = 0ull;
-  const uint64_t lo1 = m1 & lt, lo2 = m2 & lt;
-  r.src1 = r.st1 ? (lo1 ? 63 - __builtin_clzll(lo1) : -1) : lane - 1;
-  r.src2 = r.st2 ? (lo2 ? 63 - __builtin_clzll(lo2) : -1) : lane - 1;
-  r.last1 = en1 && (m1 >> lane) == 1ull;
-  r.last2 = en2 && (m2 >> lane) == 1ull;
-  return r;
+  if (D1 && en1) M[k1] = 0ull;
+  if (D2 && en2) M[k2] = 0ull;
+  const uint64_t lo1 = m1 & lk.lt, lo2 = m2 & lk.lt;
+  const bool hit1 = D1 && st1 && lo1 != 0ull, hit2 = D2 && st2 && lo2 != 0ull;
+  if (D1) p1 = st1 ? tv1 : p1;
+  if (D2) p2 = st2 ? tv2 : p2;
+  if (__ballot(hit1 || hit2))
+    {
+    if (D1)
+      {
+      const uint32_t q = (uint32_t)__builtin_amdgcn_ds_bpermute((63 - __builtin_clzll(lo1 | 1ull)) << 2, (int)v);
+      p1 = hit1 ? q : p1;
+      }
+    if (D2)
+      {
+      const uint32_t q = (uint32_t)__builtin_amdgcn_ds_bpermute((63 - __builtin_clzll(lo2 | 1ull)) << 2, (int)s);
+      p2 = hit2 ? q : p2;
+      }
+    }
+  // table writes by the last value of every class (after the reads: LDS operations of a wave stay in order)
+  if (D1) T[(en1 && (m1 >> lk.lane) == 1ull) ? k1 : lk.dumpw] = v;
+  if (D2) T[(en2 && (m2 >> lk.lane) == 1ull) ? k2 : lk.dumpw] = s;
+  if (D1) { sw.kc1 = (uint32_t)__builtin_amdgcn_readlane((int)k1, 63); sw.pend1 = false; }
+  if (D2) { sw.kc2 = (uint32_t)__builtin_amdgcn_readlane((int)k2, 63); sw.pend2 = false; }
   }
 
-// store the bytes of ring word `w` (byte offset off inside the slot, multiple of 4) that lie below hi
+// store the bytes of staged word `w` (byte offset off inside the slot, multiple of 4) that lie below hi
 __device__ __forceinline__ void store_span(uint8_t* __restrict__ gbase, uint32_t off, uint32_t w, uint32_t hi)
   {
   if (off + 4u <= hi)
@@ -259,6 +320,108 @@ __device__ __forceinline__ void store_span(uint8_t* __restrict__ gbase, uint32_t
         gbase[off + bb] = (uint8_t)(w >> (8u * bb));
   }
 
+// one step: 64 values starting at index i0 (FULL: all of them inside the segment)
+template <bool FULL>
+__device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_end, uint32_t n, uint32_t* __restrict__ T,
+                                          uint64_t* __restrict__ M, uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase,
+                                          Sweep& sw, const LaneK& lk)
+  {
+  const uint32_t i = i0 + (uint32_t)lk.lane;
+  const bool act = FULL || i < i_end;
+  // classes (fpsc.c:76-84 with e1 = 4, e2 = 10): k1 from v[i-1], k2 from the strides of v[i-1] and v[i-2]
+  const uint32_t a = dpp_shr1(sw.cy.m1, v);                 // v[i-1]
+  const uint32_t b = dpp_shr1(sw.cy.m2, a);                 // v[i-2]
+  const uint32_t s1 = a - b;                                // stride of v[i-1]
+  const uint32_t s2 = dpp_shr1(sw.cy.m2 - sw.cy.m3, s1);    // stride of v[i-2]
+  uint32_t k1 = a >> 28;
+  uint32_t k2 = 16u + ((((s2 >> 22) & 31u) << 5) ^ (s1 >> 22));
+  if (!FULL && !act)
+    k1 = k2 = 0xffffffffu;
+  bool st1 = k1 != dpp_shr1(sw.kc1, k1), st2 = k2 != dpp_shr1(sw.kc2, k2);
+  if (!FULL) { st1 = st1 && act; st2 = st2 && act; }
+  const bool any1 = __ballot(st1) != 0ull, any2 = __ballot(st2) != 0ull;
+  const uint32_t s = v - a;
+  uint32_t p1 = a, p2 = s1;                                 // inside a run: previous value / previous stride
+  if (any1 && any2)
+    resolve<FULL, true, true>(k1, k2, st1, st2, act, v, s, p1, p2, T, M, sw, lk);
+  else if (any1)
+    {
+    resolve<FULL, true, false>(k1, k2, st1, st2, act, v, s, p1, p2, T, M, sw, lk);
+    sw.pend2 = true;
+    }
+  else if (any2)
+    {
+    resolve<FULL, false, true>(k1, k2, st1, st2, act, v, s, p1, p2, T, M, sw, lk);
+    sw.pend1 = true;
+    }
+  else
+    sw.pend1 = sw.pend2 = true;
+  // residual selection (fpsc.c:146-189)
+  const uint32_t x1 = v ^ p1, x2 = v ^ (a + p2);
+  const uint32_t n1 = (39u - (uint32_t)__clz((int)x1)) >> 3;
+  const uint32_t n2 = (39u - (uint32_t)__clz((int)(x2 | 1u))) >> 3;        // DFCM residuals take at least one byte
+  const bool use2 = n1 > 1u && n2 < n1;
+  uint32_t len = use2 ? n2 : n1;
+  uint32_t x = use2 ? x2 : x1;
+  uint32_t code = use2 ? n2 + 4u : n1;
+  bool slot = true;
+  if (!FULL)
+    {
+    slot = act || (i_end == n && i < ((n + 7u) & ~7u));      // value or tail padding slot (fpsc.c:196-204)
+    if (!act)
+      {
+      code = slot ? 1u : 0u;
+      len = code;
+      x = 0u;
+      }
+    }
+  // byte layout of the step: [hdr g0][residuals 0..7][hdr g1][residuals 8..15]...
+  const uint64_t b0 = __ballot(len & 1u), b1 = __ballot(len & 2u), b2 = __ballot(len & 4u);
+  const uint32_t pre = popc_below(b0) + 2u * popc_below(b1) + 4u * popc_below(b2);
+  uint32_t bc = code << lk.sh3;
+  bc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bc, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+  bc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bc, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+  bc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bc, 0x141, 0xf, 0xf, true);    // row_half_mirror
+  const uint32_t hq = sw.posl + lk.grp3 + pre;               // my group's header (if I lead it), my residual starts at hq + 3
+  {
+  const uint32_t re = len ? hq + len : lk.dumpq;             // residual end - 3
+  // most significant byte first, in this order (a zero byte of lane l must not overtake the byte its owner writes);
+  // volatile keeps four byte stores in program order (merged into one dword store, lanes would race)
+  typedef __attribute__((address_space(3))) volatile uint8_t lds_vu8;
+  lds_vu8* vs = (lds_vu8*)stage;
+  vs[re - 1u] = (uint8_t)(x >> 24);
+  vs[re] = (uint8_t)(x >> 16);
+  vs[re + 1u] = (uint8_t)(x >> 8);
+  vs[re + 2u] = (uint8_t)x;
+  }
+  {
+  const bool lead = FULL ? lk.lead : (lk.lead && slot);
+  const uint32_t ha = lead ? hq : lk.dumpq;
+  stage[ha] = (uint8_t)(bc >> 16);
+  stage[ha + 1u] = (uint8_t)(bc >> 8);
+  stage[ha + 2u] = (uint8_t)bc;
+  }
+  const uint32_t hdr = FULL ? 24u : 3u * ((uint32_t)__popcll(__ballot(slot)) >> 3);
+  sw.posl += hdr + (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (sw.posl >= 256u)
+    {
+    // full 256-byte blocks go to the slot as aligned dwords, the rest moves to the front of the staging area
+    const uint32_t* stw = (const uint32_t*)stage;
+    const uint32_t nb = sw.posl >> 8;                        // 1 or 2
+    *(uint32_t*)(gbase + sw.flushed + 4u * (uint32_t)lk.lane) = stw[lk.lane];
+    if (nb == 2u)
+      *(uint32_t*)(gbase + sw.flushed + 256u + 4u * (uint32_t)lk.lane) = stw[64 + lk.lane];
+    const uint32_t t = stw[nb * 64u + (uint32_t)lk.lane];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    ((uint32_t*)stage)[lk.lane] = t;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    sw.flushed += nb << 8;
+    sw.posl &= 255u;
+    }
+  next_carry(sw.cy, v);
+  }
+
 __global__ void __launch_bounds__(192) k_fpc32_code(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t L, uint32_t S,
                                                     const uint32_t* __restrict__ inc, uint8_t* __restrict__ slots, size_t slot_stride,
                                                     uint32_t segcap, uint32_t* __restrict__ segbytes)
@@ -266,10 +429,9 @@ __global__ void __launch_bounds__(192) k_fpc32_code(const uint32_t* __restrict__
   extern __shared__ uint32_t lds[];
   const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t g = blockIdx.x;
-  uint32_t* T = lds + c * LDSW_C;                      // [TAB] payload table, directly followed by the ring
-  uint32_t* ringw = T + TAB;
-  uint8_t* ring = (uint8_t*)ringw;
-  uint64_t* M = (uint64_t*)(T + TAB + RING / 4);       // [TAB] lane masks
+  uint32_t* T = lds + c * LDSW_C;                      // [TAB] payload table
+  uint8_t* stage = (uint8_t*)(T + TAB);                // [STAGE] packed bytes of the steps not yet flushed + dump
+  uint64_t* M = (uint64_t*)(T + TAB + STAGE / 4);      // [TAB] lane masks
   for (int k = lane; k < TAB; k += 64)
     M[k] = 0ull;
   // incoming table: payload of the last writer of every class before this segment (0 if none)
@@ -286,23 +448,34 @@ __global__ void __launch_bounds__(192) k_fpc32_code(const uint32_t* __restrict__
       }
     T[k] = pay;
     }
-  const uint64_t lt = (1ull << lane) - 1ull;
+  LaneK lk;
+  lk.lane = lane;
+  lk.lt = (1ull << lane) - 1ull;
+  lk.bit = 1ull << lane;
+  lk.sh3 = 3u * ((uint32_t)lane & 7u);
+  lk.grp3 = 3u * ((uint32_t)lane >> 3);
+  lk.dumpw = (uint32_t)(TAB + STAGE_LIVE / 4 + lane);
+  lk.dumpq = (uint32_t)(STAGE_LIVE + 4 * lane + 1);
+  lk.lead = (lane & 7) == 0;
   const uint32_t i_begin = g * L;
   const uint32_t i_end = (n - i_begin < L) ? n : i_begin + L;
-  const uint32_t n8 = (n + 7u) & ~7u;
   uint8_t* gbase = slots + (size_t)c * slot_stride + (size_t)g * segcap;
-  uint32_t pos = 0, flushed = 0;
+  Sweep sw;
+  sw.kc1 = sw.kc2 = 0xfffffffeu;                       // the first value of a segment always looks at the table
+  sw.pend1 = sw.pend2 = false;
+  sw.posl = 0;
+  sw.flushed = 0;
   if (g == 0)
     {
     if (lane == 0)
       {
-      ring[0] = 0x25;                       // (4/2) << 4 | (10/2), fpsc.c:120
-      ring[1] = (uint8_t)(n >> 24); ring[2] = (uint8_t)(n >> 16); ring[3] = (uint8_t)(n >> 8); ring[4] = (uint8_t)n;
+      stage[0] = 0x25;                      // (4/2) << 4 | (10/2), fpsc.c:120
+      stage[1] = (uint8_t)(n >> 24); stage[2] = (uint8_t)(n >> 16); stage[3] = (uint8_t)(n >> 8); stage[4] = (uint8_t)n;
       }
-    pos = 5u;
+    sw.posl = 5u;
     }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  Carry cy = load_carry(src, i_begin, arity, c);
+  sw.cy = load_carry(src, i_begin, arity, c);
   uint32_t cur[PF], nxt[PF];
   load_block(cur, src, i_begin, i_end, arity, c, lane);
   for (uint32_t ib = i_begin; ib < i_end; ib += 64u * PF)
@@ -312,83 +485,23 @@ __global__ void __launch_bounds__(192) k_fpc32_code(const uint32_t* __restrict__
     for (int pu = 0; pu < PF; ++pu)
       {
       const uint32_t i0 = ib + 64u * pu;
-      if (i0 >= i_end)
-        break;
-      const uint32_t i = i0 + lane;
-      const bool act = i < i_end;
-      const uint32_t v = cur[pu];
-      uint32_t a, b, k1, k2;
-      classes(v, cy, act, a, b, k1, k2);
-      const uint32_t s = v - a;
-      const Pred pr = wave_pred2(k1, k2, act, M, lt, lane);
-      // Branch-free LDS traffic: lanes that have nothing to read/write are redirected instead of masked
-      // (every exec-mask region costs 3-4 instructions on the CU's single scalar unit).  The ring bytes
-      // [pos+512, pos+768) are never live (at most 536 bytes are in flight), they serve as the dump.
-      const uint32_t dump = (pos + 512u) & (RING - 1);
-      const uint32_t tv1 = T[act ? k1 : 0u], tv2 = T[act ? k2 : 0u];
-      const uint32_t q1 = (uint32_t)__builtin_amdgcn_ds_bpermute(pr.src1 << 2, (int)v);
-      const uint32_t q2 = (uint32_t)__builtin_amdgcn_ds_bpermute(pr.src2 << 2, (int)s);
-      const uint32_t p1 = pr.st1 ? (pr.src1 >= 0 ? q1 : tv1) : a;            // inside a run: previous lane's value
-      const uint32_t p2 = pr.st2 ? (pr.src2 >= 0 ? q2 : tv2) : a - b;        //               previous lane's stride
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      const uint32_t dumpw = TAB + (((dump >> 2) + (uint32_t)lane) & (RING / 4 - 1));
-      T[pr.last1 ? k1 : dumpw] = v;
-      T[pr.last2 ? k2 : dumpw] = s;
-      uint32_t len, x;
-      uint32_t code = pick(v ^ p1, v ^ (a + p2), len, x);
-      const bool slot = act || (i_end == n && i < n8);          // value or tail padding slot (fpsc.c:196-204)
-      if (!act)
-        {
-        code = slot ? 1u : 0u;
-        len = slot ? 1u : 0u;
-        x = 0u;
-        }
-      // byte layout of the step: [hdr g0][residuals 0..7][hdr g1][residuals 8..15]...
-      const uint64_t b0 = __ballot(len & 1u), b1 = __ballot(len & 2u), b2 = __ballot(len & 4u);
-      const uint32_t pre = popc_below(b0) + 2u * popc_below(b1) + 4u * popc_below(b2);
-      uint32_t bc = code << (3u * (lane & 7u));
-      bc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bc, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
-      bc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bc, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
-      bc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bc, 0x141, 0xf, 0xf, true);    // row_half_mirror
-      const uint32_t grp = lane >> 3;
-      const uint32_t rpos = pos + 3u * (grp + 1u) + pre;
-      const uint32_t dumpb = dump + 4u * (uint32_t)lane;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-      for (uint32_t kb = 0; kb < 4u; ++kb)
-        ring[(len > kb ? rpos + kb : dumpb + kb) & (RING - 1)] = (uint8_t)(x >> (8u * ((len - 1u - kb) & 3u)));
-      {
-      const bool lead = slot && (lane & 7) == 0;
-      const uint32_t hpos = lead ? pos + 3u * grp + pre : dumpb;
-      ring[hpos & (RING - 1)] = (uint8_t)(bc >> 16);
-      ring[(hpos + 1u) & (RING - 1)] = (uint8_t)(bc >> 8);
-      ring[(hpos + 2u) & (RING - 1)] = (uint8_t)bc;
-      }
-      const uint32_t nslots = (uint32_t)__popcll(__ballot(slot));
-      pos += 3u * (nslots >> 3) + (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      while (pos - flushed >= 256u)
-        {
-        const uint32_t off = flushed + 4u * lane;
-        *(uint32_t*)(gbase + off) = ringw[(off & (RING - 1)) >> 2];
-        flushed += 256u;
-        }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      next_carry(cy, v);
+      if (i0 + 64u <= i_end)
+        code_step<true>(cur[pu], i0, i_end, n, T, M, stage, gbase, sw, lk);
+      else if (i0 < i_end)
+        code_step<false>(cur[pu], i0, i_end, n, T, M, stage, gbase, sw, lk);
       }
 #pragma unroll
     for (int pu = 0; pu < PF; ++pu)
       cur[pu] = nxt[pu];
     }
-  while (flushed < pos)
-    {
-    const uint32_t off = flushed + 4u * lane;
-    if (off < pos)
-      store_span(gbase, off, ringw[(off & (RING - 1)) >> 2], pos);
-    flushed += 256u;
-    }
+  // what is left in the staging area (< 256 bytes)
+  {
+  const uint32_t off = 4u * (uint32_t)lane;
+  if (off < sw.posl)
+    store_span(gbase + sw.flushed, off, ((const uint32_t*)stage)[lane], sw.posl);
+  }
   if (lane == 0)
-    segbytes[(size_t)c * S + g] = pos;
+    segbytes[(size_t)c * S + g] = sw.flushed + sw.posl;
   }
 
 // ---- offsets: exclusive scan of segment sizes per component (one workgroup per component) -------------
