@@ -22,6 +22,10 @@
 // read + 4 written.
 #include "common.hpp"
 
+// M0 carries the lane select of v_writelane (gfx9 allows one SGPR on the constant bus); the compiler only ever
+// sets M0 right before its own uses, so clobbering it inside the asm statement is safe.
+#pragma clang diagnostic ignored "-Winline-asm"
+
 namespace trico {
 
 namespace {
@@ -45,49 +49,82 @@ __device__ __forceinline__ uint32_t lens_sum(uint32_t x)
   return (uint32_t)__popc(b0) + 2u * (uint32_t)__popc(b1) + 4u * ((uint32_t)__popc(b2) - (uint32_t)__popc(hi));
   }
 
+// Chain state (all wave-uniform except the tables).  Both predictor tables live in registers and are touched only
+// when the value's class changes:
+//   FCM  table (16 entries): one VGPR, entry h in lane h.  The entry of the current hash is cached in p1: as long
+//        as the hash does not change (top bits of consecutive values equal) the table update is `p1 = value`.
+//   DFCM table (1024 entries): 16 VGPRs, entry h in lane h & 63 of register h >> 6 (dynamic register index via
+//        s_set_gpr_idx, lane via v_readlane / v_writelane).  The entry of the current hash is cached in t2c and
+//        `row` holds its register; only a hash change writes the row back and fetches the new one.
+// A smooth stream therefore runs on ~15 scalar instructions per value with no table traffic; a noisy one pays
+// ~9 more for the register-file table, still without any LDS round trip on the chain.
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+
 struct Chain
   {
-  uint32_t h1, h2, p1, last;   // wave-uniform
-  uint32_t T1;                 // FCM table: entry h in lane h
-  uint32_t outv;               // lane k: value k of the current batch
+  uint32_t h1, h2, p1, t2c, last;   // wave-uniform
+  uint32_t T1;                      // FCM table
+  u32x16 T2;                        // DFCM table
+  uint32_t row;                     // copy of T2[h2 >> 6]
+  uint32_t outv;                    // lane k: value k of the current batch
   };
 
+struct Exps { uint32_t e1, e2h, sh1, sh2, m1, m2; };
+
+__device__ __forceinline__ uint32_t chain_value(Chain& c, uint32_t x, bool dfcm, const Exps& e, int lane)
+  {
+  const uint32_t p = dfcm ? c.last + c.t2c : c.p1;                 // decoder keeps value + stride (fpsc.c:310-311, 323)
+  const uint32_t v = x ^ p;
+  const uint32_t h1n = ((c.h1 << e.e1) ^ (v >> e.sh1)) & e.m1;     // fpsc.c:76-79
+  if (__builtin_expect(h1n != c.h1, 0))
+    {
+    c.T1 = ((uint32_t)lane == c.h1) ? v : c.T1;                    // hash_table_1[hash1] = value
+    c.h1 = h1n;
+    c.p1 = (uint32_t)__builtin_amdgcn_readlane((int)c.T1, (int)h1n);
+    }
+  else
+    c.p1 = v;
+  const uint32_t s = v - c.last;
+  const uint32_t h2n = ((c.h2 << e.e2h) ^ (s >> e.sh2)) & e.m2;    // fpsc.c:81-84
+  if (h2n != c.h2)
+    {
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(c.row) : "s"(s), "s"(c.h2) : "m0");      // hash_table_2[hash2] = stride
+    c.T2[c.h2 >> 6] = c.row;
+    c.h2 = h2n;
+    c.row = c.T2[h2n >> 6];
+    c.t2c = (uint32_t)__builtin_amdgcn_readlane((int)c.row, (int)h2n);
+    }
+  else
+    c.t2c = s;
+  c.last = v;
+  return v;
+  }
+
 template <int K>
-__device__ __forceinline__ void chain_step(Chain& c, uint32_t xr, uint64_t dfcm, uint32_t* __restrict__ T2, int lane)
+__device__ __forceinline__ void chain_step(Chain& c, uint32_t xr, uint64_t dfcm, const Exps& e, int lane)
   {
   const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)xr, K);
-  uint32_t p = c.p1;
-  if ((dfcm >> K) & 1ull)
-    p = c.last + rfl(T2[c.h2]);                                    // decoder keeps value + stride (fpsc.c:310-311, 323)
-  const uint32_t v = x ^ p;
-  c.T1 = ((uint32_t)lane == c.h1) ? v : c.T1;                      // hash_table_1[hash1] = value
-  c.h1 = v >> 28;                                                  // fpsc.c:76-79 with e1 = 4: the old hash is masked away
-  c.p1 = (uint32_t)__builtin_amdgcn_readlane((int)c.T1, (int)c.h1);
-  const uint32_t s = v - c.last;
-  T2[c.h2] = s;                                                    // hash_table_2[hash2] = stride
-  c.h2 = ((c.h2 << 5) & 1023u) ^ (s >> 22);                        // fpsc.c:81-84 with e2 = 10
-  c.last = v;
+  const uint32_t v = chain_value(c, x, ((dfcm >> K) & 1ull) != 0ull, e, lane);
   asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(c.outv) : "s"(v), "n"(K));
   }
 
 template <int K, int N> struct Unroll
   {
-  static __device__ __forceinline__ void run(Chain& c, uint32_t xr, uint64_t dfcm, uint32_t* __restrict__ T2, int lane)
+  static __device__ __forceinline__ void run(Chain& c, uint32_t xr, uint64_t dfcm, const Exps& e, int lane)
     {
-    chain_step<K>(c, xr, dfcm, T2, lane);
-    Unroll<K + 1, N>::run(c, xr, dfcm, T2, lane);
+    chain_step<K>(c, xr, dfcm, e, lane);
+    Unroll<K + 1, N>::run(c, xr, dfcm, e, lane);
     }
   };
 template <int N> struct Unroll<N, N>
   {
-  static __device__ __forceinline__ void run(Chain&, uint32_t, uint64_t, uint32_t* __restrict__, int) {}
+  static __device__ __forceinline__ void run(Chain&, uint32_t, uint64_t, const Exps&, int) {}
   };
 
 __global__ void __launch_bounds__(64) k_fpc32_decode(DecodeArgs args, int arity, uint32_t n, uint32_t* __restrict__ dst,
                                                      uint32_t* __restrict__ status)
   {
   __shared__ uint32_t win[WINW + 4];
-  __shared__ uint32_t T2[1024];
   const int lane = threadIdx.x;
   const int comp = blockIdx.x;
   const uint8_t* in = args.pay[comp];
@@ -104,8 +141,6 @@ __global__ void __launch_bounds__(64) k_fpc32_decode(DecodeArgs args, int arity,
     if (lane == 0) atomicOr(status, 2u);
     return;
     }
-  for (int i = lane; i < 1024; i += 64)
-    T2[i] = 0u;
   // window over the payload, in units of aligned dwords of the underlying buffer
   const uint32_t al = (uint32_t)((uintptr_t)in & 3u);
   const uint32_t* abase = (const uint32_t*)(in - al);
@@ -123,7 +158,8 @@ __global__ void __launch_bounds__(64) k_fpc32_decode(DecodeArgs args, int arity,
     };
   refill(q);
   Chain c;
-  c.h1 = 0; c.h2 = 0; c.p1 = 0; c.last = 0; c.T1 = 0; c.outv = 0;
+  c.h1 = 0; c.h2 = 0; c.p1 = 0; c.t2c = 0; c.last = 0; c.T1 = 0; c.row = 0; c.outv = 0;
+  c.T2 = (u32x16)(0u);
   const bool standard = (e1 == 4u && e2 == 10u);
   uint32_t i0 = 0;
   bool bad = false;
@@ -164,15 +200,15 @@ __global__ void __launch_bounds__(64) k_fpc32_decode(DecodeArgs args, int arity,
       const uint32_t xr = nb ? __builtin_bswap32(raw) >> (8u * (4u - nb)) : 0u;
       const uint64_t dfcm = __ballot(code > 4u);
       // ---- the dependent chain ---------------------------------------------------------------------------
-      Unroll<0, 64>::run(c, xr, dfcm, T2, lane);
+      const Exps es = { 4u, 5u, 28u, 22u, 15u, 1023u };
+      Unroll<0, 64>::run(c, xr, dfcm, es, lane);
       dst[(size_t)(i0 + (uint32_t)lane) * arity + comp] = c.outv;
       }
     }
   if (!bad && i0 < n)
     {
     // generic loop: tail of the stream (fewer than 64 values, fpsc.c:329-414) or non-standard exponents
-    const uint32_t m1 = (1u << e1) - 1u, m2 = (1u << e2) - 1u, sh1 = 32u - e1, sh2 = 32u - e2, e2h = e2 >> 1;
-    uint32_t p2 = c.last;
+    const Exps eg = { e1, e2 >> 1, 32u - e1, 32u - e2, (1u << e1) - 1u, (1u << e2) - 1u };
     for (uint32_t i = i0; i < n; i += 8u)
       {
       if (q + 64u > 4u * (wd + (uint32_t)WINW))
@@ -198,18 +234,7 @@ __global__ void __launch_bounds__(64) k_fpc32_decode(DecodeArgs args, int arity,
         {
         const uint32_t ck = (bc >> (3u * k)) & 7u;
         const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)xr, (int)k);
-        uint32_t p = c.p1;
-        if (ck > 4u)
-          p = p2 + rfl(T2[c.h2]);
-        const uint32_t v = x ^ p;
-        c.T1 = ((uint32_t)lane == c.h1) ? v : c.T1;
-        c.h1 = ((c.h1 << e1) ^ (v >> sh1)) & m1;
-        c.p1 = (uint32_t)__builtin_amdgcn_readlane((int)c.T1, (int)c.h1);
-        const uint32_t s = v - c.last;
-        T2[c.h2] = s;
-        c.h2 = ((c.h2 << e2h) ^ (s >> sh2)) & m2;
-        p2 = v;
-        c.last = v;
+        const uint32_t v = chain_value(c, x, ck > 4u, eg, lane);
         if (lane == 0)
           dst[(size_t)(i + k) * arity + comp] = v;
         }
