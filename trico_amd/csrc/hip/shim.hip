@@ -231,6 +231,12 @@ void trico_hip_ctx_destroy(trico_hip_ctx* ctx)
   if (!ctx)
     return;
   (void)hipStreamSynchronize(current_stream());
+  if (ctx->stream)
+    {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
+    (void)hipEventDestroy(ctx->ready);
+    }
   ctx->in.release();
   ctx->out.release();
   ctx->tmp.release();
@@ -384,18 +390,11 @@ int trico_hip_fpc_encode(trico_hip_ctx* ctx, const void* src, uint32_t n, int ar
   return 1;
   }
 
-int trico_hip_fpc_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[3], const uint32_t sizes[3],
-                         int arity, int width, uint32_t n, void* dst)
+// Stages the payloads, launches the decode into d_dst (ctx->out when NULL) on current_stream() and queues the
+// read-back of the status word; nothing waits.  decode_complete() below does.
+static int fpc_decode_launch(trico_hip_ctx* ctx, const uint8_t* const payloads[3], const uint32_t sizes[3],
+                             int arity, int width, uint32_t n, void* d_dst)
   {
-  if (!ctx || !device_ready())
-    return 0;
-  if (arity < 1 || arity > 3 || (width != 4 && width != 8))
-    {
-    set_error("trico_hip_fpc_decode: bad arguments");
-    return 0;
-    }
-  if (!dst)
-    return 1;
   // stage host payloads back to back (256-byte aligned) in ctx->in
   size_t total = 0, offs[3] = { 0, 0, 0 };
   for (int c = 0; c < arity; ++c)
@@ -421,9 +420,7 @@ int trico_hip_fpc_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[3], c
       return 0;
     }
   const size_t out_bytes = (size_t)n * arity * width;
-  const bool dst_dev = trico_hip_pointer_is_device(dst) != 0;
-  void* d_dst = dst;
-  if (!dst_dev)
+  if (!d_dst)
     {
     if (!ctx->out.reserve(out_bytes + 16))
       return 0;
@@ -457,17 +454,42 @@ int trico_hip_fpc_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[3], c
   else if (!launch_fpc_decode_serial(d_pay, sizes, arity, width, n, d_dst, d_tables, d_status))
     return 0;
   }
-  uint32_t status = 0;
-  if (!read_back_words(ctx, d_status, 1, &status))
-    return 0;
-  if (status != 0)
+  TRICO_HIP_TRY(hipMemcpyAsync(ctx->h_pinned, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, current_stream()));
+  return 1;
+  }
+
+// waits for the decode launched on current_stream() and checks its status word
+static int decode_complete(trico_hip_ctx* ctx, const char* what)
+  {
+  TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
+  if (ctx->h_pinned[0] != 0)
     {
-    set_error("trico_hip_fpc_decode: malformed payload");
+    set_error(what);
     return 0;
     }
+  return 1;
+  }
+
+int trico_hip_fpc_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[3], const uint32_t sizes[3],
+                         int arity, int width, uint32_t n, void* dst)
+  {
+  if (!ctx || !device_ready())
+    return 0;
+  if (arity < 1 || arity > 3 || (width != 4 && width != 8))
+    {
+    set_error("trico_hip_fpc_decode: bad arguments");
+    return 0;
+    }
+  if (!dst)
+    return 1;
+  const bool dst_dev = trico_hip_pointer_is_device(dst) != 0;
+  if (!fpc_decode_launch(ctx, payloads, sizes, arity, width, n, dst_dev ? dst : nullptr) ||
+      !decode_complete(ctx, "trico_hip_fpc_decode: malformed payload"))
+    return 0;
+  const size_t out_bytes = (size_t)n * arity * width;
   if (!dst_dev && out_bytes)
     {
-    TRICO_HIP_TRY(hipMemcpyAsync(dst, d_dst, out_bytes, hipMemcpyDeviceToHost, current_stream()));
+    TRICO_HIP_TRY(hipMemcpyAsync(dst, ctx->out.p, out_bytes, hipMemcpyDeviceToHost, current_stream()));
     TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
     }
   return 1;
@@ -541,18 +563,9 @@ int trico_hip_int_encode(trico_hip_ctx* ctx, const void* src, uint32_t count, in
   return 1;
   }
 
-int trico_hip_int_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[8], const uint32_t sizes[8],
-                         int width, uint32_t count, void* dst)
+static int int_decode_launch(trico_hip_ctx* ctx, const uint8_t* const payloads[8], const uint32_t sizes[8],
+                             int width, uint32_t count, void* d_dst)
   {
-  if (!ctx || !device_ready())
-    return 0;
-  if (width != 1 && width != 2 && width != 4 && width != 8)
-    {
-    set_error("trico_hip_int_decode: bad arguments");
-    return 0;
-    }
-  if (!dst)
-    return 1;
   size_t total = 0, offs[8];
   bool any_host = false;
   for (int c = 0; c < width; ++c)
@@ -576,9 +589,7 @@ int trico_hip_int_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[8], c
       return 0;
     }
   const size_t out_bytes = (size_t)count * width;
-  const bool dst_dev = trico_hip_pointer_is_device(dst) != 0;
-  void* d_dst = dst;
-  if (!dst_dev)
+  if (!d_dst)
     {
     if (!ctx->out.reserve(out_bytes + 16))
       return 0;
@@ -607,20 +618,86 @@ int trico_hip_int_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[8], c
     if (!launch_planes_merge(d_planes, plane_stride, count, width, d_dst))
       return 0;
     }
-  uint32_t status = 0;
-  if (!read_back_words(ctx, d_status, 1, &status))
+  TRICO_HIP_TRY(hipMemcpyAsync(ctx->h_pinned, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, current_stream()));
+  return 1;
+  }
+
+int trico_hip_int_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[8], const uint32_t sizes[8],
+                         int width, uint32_t count, void* dst)
+  {
+  if (!ctx || !device_ready())
     return 0;
-  if (status != 0)
+  if (width != 1 && width != 2 && width != 4 && width != 8)
     {
-    set_error("trico_hip_int_decode: malformed LZ4 block");
+    set_error("trico_hip_int_decode: bad arguments");
     return 0;
     }
+  if (!dst)
+    return 1;
+  const bool dst_dev = trico_hip_pointer_is_device(dst) != 0;
+  if (!int_decode_launch(ctx, payloads, sizes, width, count, dst_dev ? dst : nullptr) ||
+      !decode_complete(ctx, "trico_hip_int_decode: malformed LZ4 block"))
+    return 0;
+  const size_t out_bytes = (size_t)count * width;
   if (!dst_dev && out_bytes)
     {
-    TRICO_HIP_TRY(hipMemcpyAsync(dst, d_dst, out_bytes, hipMemcpyDeviceToHost, current_stream()));
+    TRICO_HIP_TRY(hipMemcpyAsync(dst, ctx->out.p, out_bytes, hipMemcpyDeviceToHost, current_stream()));
     TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
     }
   return 1;
+  }
+
+// ---- read-ahead: decode into the context on a private stream, collect later -----------------------
+// The format leaves one serial chain per component stream, so a single stream keeps a handful of waves busy
+// for seconds while 250 CUs idle.  An archive reader therefore starts the decode of every stream it can see
+// (each on its own context and HIP stream) and the trico_read_* calls only collect results.
+
+int trico_hip_decode_begin(trico_hip_ctx* ctx, int is_int, const uint8_t* const* payloads, const uint32_t* sizes,
+                           int arity, int width, uint32_t n)
+  {
+  if (!ctx || !device_ready() || ctx->pending)
+    return 0;
+  if (is_int ? (width != 1 && width != 2 && width != 4 && width != 8) : (arity < 1 || arity > 3 || (width != 4 && width != 8)))
+    return 0;
+  if (!ctx->stream)
+    {
+    if (!hip_ok(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate") ||
+        !hip_ok(hipEventCreateWithFlags(&ctx->ready, hipEventDisableTiming), "hipEventCreate"))
+      return 0;
+    }
+  // whatever produced the payloads on the caller's stream comes first
+  hipStream_t user = g_stream;
+  TRICO_HIP_TRY(hipEventRecord(ctx->ready, user));
+  TRICO_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ready, 0));
+  g_stream = ctx->stream;
+  const int ok = is_int ? int_decode_launch(ctx, payloads, sizes, width, n, nullptr)
+                        : fpc_decode_launch(ctx, payloads, sizes, arity, width, n, nullptr);
+  g_stream = user;
+  if (!ok)
+    {
+    (void)hipStreamSynchronize(ctx->stream);
+    return 0;
+    }
+  ctx->pending = true;
+  ctx->pending_bytes = (size_t)n * (size_t)width * (size_t)(is_int ? 1 : arity);
+  return 1;
+  }
+
+int trico_hip_decode_finish(trico_hip_ctx* ctx, void* dst)
+  {
+  if (!ctx || !ctx->pending)
+    return 0;
+  ctx->pending = false;
+  hipStream_t user = g_stream;
+  g_stream = ctx->stream;
+  int ok = decode_complete(ctx, "trico read-ahead: malformed payload");
+  if (ok && dst && ctx->pending_bytes)
+    {
+    ok = hip_ok(hipMemcpyAsync(dst, ctx->out.p, ctx->pending_bytes, hipMemcpyDefault, ctx->stream), "read-ahead copy") &&
+         hip_ok(hipStreamSynchronize(ctx->stream), "read-ahead copy") ? 1 : 0;
+    }
+  g_stream = user;
+  return ok;
   }
 
 // float payloads of the throughput encoder live in segment slots: gather component c into ctx->out

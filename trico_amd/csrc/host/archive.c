@@ -44,6 +44,16 @@ struct trico_archive
   uint8_t next_stream_type;
   int writable;
   trico_hip_ctx* ctx;   /* created on first use */
+  /* read-ahead: streams whose decode is already running, keyed by the cursor position of their count field */
+  struct ra_entry* ra;
+  int ra_n;
+  int ra_started;
+  };
+
+struct ra_entry
+  {
+  uint64_t pos;
+  trico_hip_ctx* ctx;
   };
 
 #define TRICO_MAGIC 0x6f637254u   /* "Trco", trico.c:94 */
@@ -230,6 +240,13 @@ void trico_close_archive(void* archive)
     else
       free(a->buffer);
     }
+  for (int i = 0; i < a->ra_n; ++i)
+    if (a->ra[i].ctx)
+      {
+      (void)trico_hip_decode_finish(a->ra[i].ctx, NULL);      /* a stream that was never collected */
+      trico_hip_ctx_destroy(a->ra[i].ctx);
+      }
+  free(a->ra);
   if (a->ctx)
     trico_hip_ctx_destroy(a->ctx);
   free(a);
@@ -419,6 +436,134 @@ static int parse_frames(struct trico_archive* a, int ncomp, uint32_t* count, con
   return ok;
   }
 
+/* ---- read-ahead ------------------------------------------------------------------------------
+ * The reference decodes stream after stream (trico.c:943-1668), and the format leaves one serial chain
+ * per component stream.  On the GPU a chain occupies one wave, so the first read that actually wants
+ * data walks the remaining frames and starts the decode of every stream (one context and HIP stream
+ * each, trico_hip_decode_begin); the trico_read_* calls then collect.  Results and error behaviour are
+ * those of the one-by-one path: a malformed stream fails in its own read call.
+ * TRICO_HIP_READAHEAD_MB bounds the decoded bytes held at once (default 65536, 0 switches it off). */
+
+struct stream_layout { int known, is_int, ncomp, arity, width; uint32_t per_count; };
+
+static struct stream_layout layout_of(uint8_t type)
+  {
+  struct stream_layout fp3f = { 1, 0, 3, 3, 4, 1 }, fp3d = { 1, 0, 3, 3, 8, 1 }, fp2f = { 1, 0, 2, 2, 4, 1 }, fp2d = { 1, 0, 2, 2, 8, 1 };
+  struct stream_layout fp1f = { 1, 0, 1, 1, 4, 1 }, fp1d = { 1, 0, 1, 1, 8, 1 }, none = { 0, 0, 0, 0, 0, 0 };
+  struct stream_layout tri32 = { 1, 1, 4, 1, 4, 3 }, tri64 = { 1, 1, 8, 1, 8, 3 };
+  struct stream_layout i8 = { 1, 1, 1, 1, 1, 1 }, i16 = { 1, 1, 2, 1, 2, 1 }, i32 = { 1, 1, 4, 1, 4, 1 }, i64 = { 1, 1, 8, 1, 8, 1 };
+  switch ((enum trico_stream_type)type)
+    {
+    case trico_vertex_float_stream: case trico_vertex_normal_float_stream: case trico_triangle_normal_float_stream: return fp3f;
+    case trico_vertex_double_stream: case trico_vertex_normal_double_stream: case trico_triangle_normal_double_stream: return fp3d;
+    case trico_uv_per_vertex_float_stream: case trico_uv_per_triangle_float_stream: return fp2f;
+    case trico_uv_per_vertex_double_stream: case trico_uv_per_triangle_double_stream: return fp2d;
+    case trico_attribute_float_stream: return fp1f;
+    case trico_attribute_double_stream: return fp1d;
+    case trico_triangle_uint32_stream: return tri32;
+    case trico_triangle_uint64_stream: return tri64;
+    case trico_vertex_color_stream: case trico_triangle_color_stream: case trico_attribute_uint32_stream: return i32;
+    case trico_attribute_uint8_stream: return i8;
+    case trico_attribute_uint16_stream: return i16;
+    case trico_attribute_uint64_stream: return i64;
+    default: return none;
+    }
+  }
+
+static int parse_frames(struct trico_archive* a, int ncomp, uint32_t* count, const uint8_t** payloads,
+                        uint32_t* sizes, uint64_t* end_pos);
+
+static uint64_t readahead_budget(void)
+  {
+  const char* e = getenv("TRICO_HIP_READAHEAD_MB");
+  const uint64_t mb = e ? strtoull(e, NULL, 10) : 65536ull;
+  return mb << 20;
+  }
+
+static void start_readahead(struct trico_archive* a)
+  {
+  a->ra_started = 1;
+  const uint64_t budget = readahead_budget();
+  if (budget == 0 || !trico_hip_available())
+    return;
+  const uint64_t save_pos = a->pos;
+  const uint8_t save_type = a->next_stream_type;
+  /* pass 1: is there more than one stream left?  (a lone stream gains nothing from the detour) */
+  int streams = 0;
+  while (a->next_stream_type != (uint8_t)trico_empty && streams < 2)
+    {
+    const struct stream_layout L = layout_of(a->next_stream_type);
+    uint32_t count = 0, sizes[8];
+    const uint8_t* pay[8];
+    uint64_t end = 0;
+    if (!L.known || !parse_frames(a, L.ncomp, &count, pay, sizes, &end))
+      break;
+    ++streams;
+    a->pos = end;
+    read_next_stream_type(a);
+    }
+  a->pos = save_pos;
+  a->next_stream_type = save_type;
+  if (streams < 2)
+    return;
+  /* pass 2: start them */
+  uint64_t held = 0;
+  int cap = 0;
+  while (a->next_stream_type != (uint8_t)trico_empty)
+    {
+    const struct stream_layout L = layout_of(a->next_stream_type);
+    uint32_t count = 0, sizes[8];
+    const uint8_t* pay[8];
+    uint64_t end = 0;
+    if (!L.known || !parse_frames(a, L.ncomp, &count, pay, sizes, &end))
+      break;
+    const uint64_t n = (uint64_t)count * L.per_count;
+    const uint64_t bytes = n * (uint64_t)L.width * (uint64_t)(L.is_int ? 1 : L.arity);
+    if (n != 0 && n <= 0xffffffffull && held + bytes <= budget)
+      {
+      if (a->ra_n == cap)
+        {
+        const int ncap = cap ? 2 * cap : 8;
+        struct ra_entry* nr = (struct ra_entry*)realloc(a->ra, (size_t)ncap * sizeof(struct ra_entry));
+        if (!nr)
+          break;
+        a->ra = nr;
+        cap = ncap;
+        }
+      trico_hip_ctx* ctx = trico_hip_ctx_create();
+      if (ctx && trico_hip_decode_begin(ctx, L.is_int, pay, sizes, L.arity, L.width, (uint32_t)n))
+        {
+        a->ra[a->ra_n].pos = a->pos;
+        a->ra[a->ra_n].ctx = ctx;
+        ++a->ra_n;
+        held += bytes;
+        }
+      else if (ctx)
+        trico_hip_ctx_destroy(ctx);       /* the one-by-one path will report what is wrong with it */
+      }
+    a->pos = end;
+    read_next_stream_type(a);
+    }
+  a->pos = save_pos;
+  a->next_stream_type = save_type;
+  }
+
+/* collects the stream at the cursor if its decode was started ahead: 1 done, 0 failed, -1 not started ahead */
+static int collect_readahead(struct trico_archive* a, void* out)
+  {
+  if (!a->ra_started)
+    start_readahead(a);
+  for (int i = 0; i < a->ra_n; ++i)
+    if (a->ra[i].ctx && a->ra[i].pos == a->pos)
+      {
+      const int ok = trico_hip_decode_finish(a->ra[i].ctx, out);
+      trico_hip_ctx_destroy(a->ra[i].ctx);
+      a->ra[i].ctx = NULL;
+      return ok;
+      }
+  return -1;
+  }
+
 /* lib_alloc: the library mallocs *dst (trico_read_attributes_float/double, trico.c:1377,1408) */
 static int read_fp_stream(void* archive, enum trico_stream_type st, void** dst, int arity, int width, int lib_alloc)
   {
@@ -441,7 +586,8 @@ static int read_fp_stream(void* archive, enum trico_stream_type st, void** dst, 
       if (!out)
         return 0;
       }
-    if (!trico_hip_fpc_decode(a->ctx, payloads, sizes, arity, width, count, out))
+    const int ahead = collect_readahead(a, out);
+    if (ahead == 0 || (ahead < 0 && !trico_hip_fpc_decode(a->ctx, payloads, sizes, arity, width, count, out)))
       {
       if (lib_alloc)
         free(out);
@@ -471,7 +617,8 @@ static int read_int_stream(void* archive, enum trico_stream_type st, void** dst,
     {
     if (!arch_ctx(a))
       return 0;
-    if (!trico_hip_int_decode(a->ctx, payloads, sizes, width, count * per_count, *dst))
+    const int ahead = collect_readahead(a, *dst);
+    if (ahead == 0 || (ahead < 0 && !trico_hip_int_decode(a->ctx, payloads, sizes, width, count * per_count, *dst)))
       return 0;
     }
   a->pos = end_pos;
