@@ -33,6 +33,35 @@ import torch
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def pmc_traffic(mesh):
+    """HBM bytes per launch sequence of the float-vertex encoder from the newest committed PMC summary
+    (profiles/*_fpc32_encode_hbm_traffic_pmc.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over
+    tools/perf_fpc32.py, the same kernels on the same grid vertices; KB per dispatch).  Corrections per
+    MI355X_MICROARCH.md: KB units, FETCH_SIZE doubled on gfx950.  None when no summary applies to this mesh."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_fpc32_encode_hbm_traffic_pmc.txt")))
+    if not files or mesh != "grid":
+        return None, None
+    kernel, disp, fetch, write = None, {}, {}, {}
+    for line in open(files[-1]):
+        m = re.match(r"^(\S+) dispatches (\d+)", line)
+        if m:
+            kernel = m.group(1)
+            disp[kernel] = int(m.group(2))
+            continue
+        m = re.match(r"^\s+(FETCH_SIZE|WRITE_SIZE)\s+(\d+) per dispatch", line)
+        if m and kernel and kernel.startswith("k_fpc32"):
+            (fetch if m.group(1) == "FETCH_SIZE" else write)[kernel] = float(m.group(2)) * disp[kernel]
+    if not fetch or not write:
+        return None, None
+    launches = disp.get("k_fpc32_code", 0)
+    if not launches:
+        return None, None
+    total = (2.0 * sum(fetch.values()) + sum(write.values())) * 1024.0 / launches
+    return int(total), os.path.relpath(files[-1], ROOT)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,6 +256,7 @@ def main():
         fe = kms.get("fpc32_encode", {"avg_ms": float("nan")})
         alg_bytes = v.nbytes + state["vertex_payload_bytes"]
         achieved = alg_bytes / (fe["avg_ms"] * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(args.mesh)
         out = {
             "metric": "encode+decode GB/s (input bytes)",
             "value": round(total_raw / step_s / 1e9, 4),
@@ -245,7 +275,7 @@ def main():
             "gather_ms": round(elapsed[2] / args.steps * 1e3, 3),
             "roofline": {"kernel": "float-vertex encoder (k_fpc32_index + scan + k_fpc32_code + offsets + gather)",
                          "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fe["avg_ms"]},
             "kernels": kms,
         }

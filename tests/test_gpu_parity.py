@@ -258,3 +258,63 @@ def test_bunny_real_mesh_gpu(api, gold_dir):
     got = write_archive(api, streams)
     assert got == oracle_archive(streams)
     read_back(api, got, streams)
+
+
+# ---- read-ahead (archive.c start_readahead): streams decode concurrently, reads collect ----------------
+
+def _allstreams_list(allstreams):
+    return [(name, allstreams[name], allstreams[name].size // div) for name, div, _ in ALL_ORDER]
+
+
+def test_readahead_with_skips(api, gold_dir, allstreams):
+    """every other stream is skipped after the decode of all of them has been started"""
+    blob = open(os.path.join(gold_dir, "allstreams.trc"), "rb").read()
+    r = api.Archive.open_for_reading(blob)
+    for i, (name, data, count) in enumerate(_allstreams_list(allstreams)):
+        assert r.get_next_stream_type() == STREAM_TAG[name]
+        if i % 2 == 1:
+            assert r.skip_next_stream() == 1
+            continue
+        if name in ("attributes_float", "attributes_double"):
+            got = r.read_alloc(name, count, data.dtype)
+            assert got is not None, api.last_error()
+        else:
+            got = np.empty_like(data)
+            assert r.read(name, got) == 1, (name, api.last_error())
+        assert got.tobytes() == data.tobytes(), name
+    assert r.get_next_stream_type() == api.trico_empty
+    r.close()
+
+
+def test_readahead_disabled_matches(api, gold_dir, allstreams, monkeypatch):
+    monkeypatch.setenv("TRICO_HIP_READAHEAD_MB", "0")
+    blob = open(os.path.join(gold_dir, "allstreams.trc"), "rb").read()
+    read_back(api, blob, _allstreams_list(allstreams))
+
+
+def test_readahead_corrupt_middle_stream(api, gold_dir):
+    """grid_16x8.trc = vertices + triangles: a broken triangle plane fails in its own read, vertices still decode"""
+    blob = bytearray(open(os.path.join(gold_dir, "grid_16x8.trc"), "rb").read())
+    streams = mesh_streams("grid", 16, 8)
+    r0 = api.Archive.open_for_reading(bytes(blob))
+    v = np.empty_like(streams[0][1])
+    assert r0.read("vertices", v) == 1
+    r0.close()
+    # locate the triangle stream: 8 (header) + tag + count + 3 x (nbytes, payload)
+    pos = 8 + 1 + 4
+    for _ in range(3):
+        nb = int.from_bytes(blob[pos:pos + 4], "little")
+        pos += 4 + nb
+    assert blob[pos] == api.trico_triangle_uint32_stream
+    nb0 = int.from_bytes(blob[pos + 5:pos + 9], "little")
+    blob[pos + 9] = 0xF0            # first token of plane 0: 15+ literals announced ...
+    for k in range(1, min(nb0, 6)):
+        blob[pos + 9 + k] = 0xFF    # ... with a length that runs past the block
+    r = api.Archive.open_for_reading(bytes(blob))
+    got = np.empty_like(streams[0][1])
+    assert r.read("vertices", got) == 1, api.last_error()
+    assert got.tobytes() == streams[0][1].tobytes()
+    tri = np.empty_like(streams[1][1])
+    assert r.read("triangles", tri) == 0
+    assert r.get_next_stream_type() == api.trico_triangle_uint32_stream
+    r.close()

@@ -12,21 +12,23 @@
 // one wave owns one (segment, component) and walks it 64 values per step.
 //   sweep A  (k_fpc32_index):  classes only.  The run-end lane of every class run does an LDS
 //            ds_max of its value index into a 16+1024 entry table -> "last writer index per class"
-//            of the segment.  ~25 VALU instructions per step.
+//            of the segment.
 //   scan     (k_fpc32_scan_*): prefix-max over segments per class = the table every segment starts
 //            with, as value indices (0 = never written = the reference's zeroed table).
 //   sweep C  (k_fpc32_code):   loads the incoming table (payloads gathered from the input by index),
 //            then per step: the latest earlier value of my class is the previous lane inside a run
-//            of equal classes; run starts look at the wave-private LDS table; several runs of one
-//            class inside a step are detected with a lane-id table and fixed up with ballots.
-//            Codes, residual lengths, wave prefix sums (mbcnt), 3-byte group headers (DPP or-reduce),
-//            bytes staged in an LDS ring and flushed as aligned dwords into the segment's slot.
+//            of equal classes (runs span steps through the carry); run starts are resolved with a
+//            per-class lane-mask table + the wave-private payload table, only in steps that have
+//            any (see the comment block above code_step).  Codes, residual lengths, wave prefix sums
+//            (mbcnt), 3-byte group headers (DPP or-reduce), bytes staged in a linear LDS buffer and
+//            flushed as aligned dwords into the segment's slot.
 //   offsets  (k_fpc32_offsets): exclusive scan of the segment byte counts per component.
 //   gather   (k_fpc32_gather): slot -> final position (this is the copy the reference does with
-//            memcpy into the archive, trico.c:57-63; it can target the archive buffer directly).
+//            memcpy into the archive, trico.c:57-63; it targets the archive buffer directly).
 //
-// HBM traffic: 2 x raw input + 2 x payload bytes + ~5 % table traffic.  No MFMA: integer
-// bit-twiddling bounded by HBM bandwidth; algorithmic bytes per value = 4 + its payload share.
+// HBM traffic: 2 x raw input + 2 x payload bytes + table traffic (measured 3.3 x algorithmic, DESIGN.md
+// 4.1).  No MFMA: integer bit-twiddling; algorithmic bytes per value = 4 + its payload share.  The bound
+// today is VALU issue (97 instructions per 64-value step), not HBM.
 #include "common.hpp"
 #include <stdlib.h>
 
