@@ -344,10 +344,12 @@ __global__ void __launch_bounds__(64) k_fpc64_decode(DecodeArgs args, int arity,
     const u64 xr = nb ? be >> (8u * (8u - nb)) : 0ull;
     const uint64_t dfcm = __ballot(code > 8u);
     // ---- the dependent chain (wave-uniform) ---------------------------------------------------------------
-    // Table writes go through to global memory (fire and forget) and into a direct-mapped LDS cache; a read
-    // is served by the "same key as just written" shortcut, else by the cache, else by a dependent L2 load.
-    // Lane 0 performs every global store and load itself, so per-thread same-address ordering makes the loads
-    // see the earlier stores without draining the store queue.
+    // The entry of the current hash of each table is cached in registers (p1 / t2v): while a value's hash equals
+    // its predecessor's, the table update is a register move and nothing touches memory.  A hash change writes
+    // the entry back (global store, fire and forget, plus a direct-mapped LDS cache of recent entries) and
+    // fetches the new one: from the LDS cache if it is there, else by a dependent load.  Lane 0 performs every
+    // global store and load itself, so per-thread same-address ordering makes the loads see the earlier stores
+    // without draining the store queue.
     u64 outv = 0;
     for (uint32_t k = 0; k < nvals; ++k)
       {
@@ -356,57 +358,55 @@ __global__ void __launch_bounds__(64) k_fpc64_decode(DecodeArgs args, int arity,
       if ((dfcm >> k) & 1ull)
         p = last + t2v;                                           // fpsc.c:977-978 with prediction2 = value + table
       const u64 v = x ^ p;
-      if (lane == 0) tab_store(&T1[h1], v);
-      {
-      const uint32_t cs = (uint32_t)h1 & (CACHE - 1);
-      ctag1[cs] = (uint32_t)h1;
-      cval1[cs] = v;
-      }
-      const u64 nh1 = ((h1 << e1) ^ (v >> sh1)) & m1;
-      if (nh1 != h1)
-        {
-        const uint32_t cs = (uint32_t)nh1 & (CACHE - 1);
-        if (rfl(ctag1[cs]) == (uint32_t)nh1)
-          p1 = cval1[cs];
-        else
-          {
-          p1 = 0;
-          if (lane == 0) p1 = tab_load(&T1[nh1]);      // lane 0 did the stores: per-thread ordering
-          p1 = ((u64)rfl((uint32_t)(p1 >> 32)) << 32) | rfl((uint32_t)p1);
-          ctag1[cs] = (uint32_t)nh1;
-          cval1[cs] = p1;
-          }
-        p1 = ((u64)rfl((uint32_t)(p1 >> 32)) << 32) | rfl((uint32_t)p1);
-        }
-      else
-        p1 = v;                                                   // same key: the entry is the value just written
-      h1 = nh1;
       const u64 s = v - last;
-      if (lane == 0) tab_store(&T2[h2], s);
-      {
-      const uint32_t cs = (uint32_t)h2 & (CACHE - 1);
-      ctag2[cs] = (uint32_t)h2;
-      cval2[cs] = s;
-      }
+      const u64 nh1 = ((h1 << e1) ^ (v >> sh1)) & m1;
       const u64 nh2 = ((h2 << e2h) ^ (s >> sh2)) & m2;
-      if (nh2 != h2)
+      const bool c1 = nh1 != h1, c2 = nh2 != h2;
+      if (c1 || c2)
         {
-        const uint32_t cs = (uint32_t)nh2 & (CACHE - 1);
-        if (rfl(ctag2[cs]) == (uint32_t)nh2)
-          t2v = cval2[cs];
-        else
+        u64 a = v, b = s;
+        bool miss1 = false, miss2 = false;
+        if (c1)
           {
-          t2v = 0;
-          if (lane == 0) t2v = tab_load(&T2[nh2]);
-          t2v = ((u64)rfl((uint32_t)(t2v >> 32)) << 32) | rfl((uint32_t)t2v);
-          ctag2[cs] = (uint32_t)nh2;
-          cval2[cs] = t2v;
+          if (lane == 0) tab_store(&T1[h1], v);                   // hash_table_1[hash1] = value
+          const uint32_t cw = (uint32_t)h1 & (CACHE - 1), cr = (uint32_t)nh1 & (CACHE - 1);
+          ctag1[cw] = (uint32_t)h1;
+          cval1[cw] = v;
+          if (rfl(ctag1[cr]) == (uint32_t)nh1)
+            a = cval1[cr];
+          else
+            miss1 = true;
           }
-        t2v = ((u64)rfl((uint32_t)(t2v >> 32)) << 32) | rfl((uint32_t)t2v);
+        if (c2)
+          {
+          if (lane == 0) tab_store(&T2[h2], s);                   // hash_table_2[hash2] = stride
+          const uint32_t cw = (uint32_t)h2 & (CACHE - 1), cr = (uint32_t)nh2 & (CACHE - 1);
+          ctag2[cw] = (uint32_t)h2;
+          cval2[cw] = s;
+          if (rfl(ctag2[cr]) == (uint32_t)nh2)
+            b = cval2[cr];
+          else
+            miss2 = true;
+          }
+        if (miss1 || miss2)
+          {
+          // both dependent loads are in flight together
+          if (lane == 0)
+            {
+            if (miss1) a = tab_load(&T1[nh1]);
+            if (miss2) b = tab_load(&T2[nh2]);
+            }
+          }
+        p1 = ((u64)rfl((uint32_t)(a >> 32)) << 32) | rfl((uint32_t)a);
+        t2v = ((u64)rfl((uint32_t)(b >> 32)) << 32) | rfl((uint32_t)b);
+        h1 = nh1;
+        h2 = nh2;
         }
       else
+        {
+        p1 = v;                                                   // same hashes: the entries are what was just decoded
         t2v = s;
-      h2 = nh2;
+        }
       last = v;
       outv = ((uint32_t)lane == k) ? v : outv;
       }
