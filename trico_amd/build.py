@@ -28,6 +28,9 @@ HIP_HDR = sorted(f for f in os.listdir(os.path.join(CSRC, "hip")) if f.endswith(
 
 LIBTRICO = os.path.join(LIBDIR, "libtrico.so")
 LIBMESHGEN = os.path.join(LIBDIR, "libtrico_meshgen.so")
+LIBIO = os.path.join(LIBDIR, "libtrico_io.so")
+BINDIR = os.path.join(HERE, "bin")
+TOOLS = ["trico_encoder", "trico_decoder"]
 
 
 def _run(cmd):
@@ -68,6 +71,20 @@ def build(force=False, verbose=True):
     mg = os.path.join(CSRC, "tools", "meshgen.c")
     if force or _stale(LIBMESHGEN, [mg]):
         _run([CC, "-O2", "-std=c11", "-fPIC", "-fvisibility=hidden", "-shared", mg, "-o", LIBMESHGEN])
+    # STL / PLY readers and the two command line tools around the path
+    io_src = [os.path.join(CSRC, "io", f) for f in ("iostl.c", "ioply.c")]
+    io_hdr = [os.path.join(INCLUDE, "trico_io", h) for h in ("iostl.h", "ioply.h", "trico_io_api.h")]
+    if force or _stale(LIBIO, io_src + io_hdr):
+        _run([CC, "-O2", "-std=c11", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wextra", "-shared",
+              "-I" + INCLUDE] + io_src + ["-o", LIBIO])
+    os.makedirs(BINDIR, exist_ok=True)
+    for tool in TOOLS:
+        src = os.path.join(CSRC, "tools", tool + ".c")
+        exe = os.path.join(BINDIR, tool)
+        if force or _stale(exe, [src, LIBIO, LIBTRICO] + io_hdr + headers[:1]):
+            # -ffp-contract=off: the decoder's flat normals must round like the reference build
+            _run([CC, "-O2", "-std=gnu11", "-ffp-contract=off", "-Wall", "-Wextra", "-I" + INCLUDE, src, "-o", exe,
+                  "-L" + LIBDIR, "-ltrico_io", "-ltrico", "-lm", "-Wl,-rpath,$ORIGIN/../lib"])
     return LIBTRICO
 
 
