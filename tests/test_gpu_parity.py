@@ -318,3 +318,21 @@ def test_readahead_corrupt_middle_stream(api, gold_dir):
     assert r.read("triangles", tri) == 0
     assert r.get_next_stream_type() == api.trico_triangle_uint32_stream
     r.close()
+
+
+@pytest.mark.parametrize("shift", [1, 2, 3])
+def test_fp32_encoder_unaligned_device_pointer(api, shift):
+    """the staged AoS loads use 16-byte accesses only when the vertex array is 16-byte aligned"""
+    import torch
+    rng = np.random.default_rng(77 + shift)
+    n = 70001
+    v = np.cumsum(rng.normal(0, 1e-3, (n, 3)), axis=0).astype(np.float32)
+    flat = torch.empty(3 * n + 8, dtype=torch.float32, device="cuda")
+    view = flat[shift:shift + 3 * n]
+    view.copy_(torch.from_numpy(v.reshape(-1)))
+    assert view.data_ptr() % 16 == 4 * shift
+    a = api.Archive.open_for_writing(1 << 16)
+    assert a.write("vertices", view, n) == 1, api.last_error()
+    got = a.tobytes()
+    a.close()
+    assert got == oracle_archive([("vertices", v.reshape(-1), n)])
