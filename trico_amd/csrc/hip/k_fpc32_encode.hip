@@ -600,30 +600,37 @@ __global__ void __launch_bounds__(1024) k_fpc32_offsets(const uint32_t* __restri
   }
 
 // ---- gather: segment slots -> contiguous payload -------------------------------------------------------
-// grid (S, arity); each workgroup moves one segment.  Destination dwords are written aligned; the source
-// is read as aligned dwords and re-aligned with v_alignbyte.
+// grid (S, arity); each workgroup moves one segment.  The destination is written as aligned 16-byte vectors;
+// the source (a 256-byte aligned slot) is read as 4 + 1 dwords per vector and re-aligned with v_alignbyte.
 __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap, uint32_t S,
                                                       const uint32_t* __restrict__ segbytes, const uint32_t* __restrict__ segoff,
                                                       uint8_t* __restrict__ out, size_t out_stride)
   {
   const uint32_t g = blockIdx.x, c = blockIdx.y;
   const uint32_t len = segbytes[(size_t)c * S + g];
-  const uint8_t* s = slots + (size_t)c * slot_stride + (size_t)g * segcap;       // 4-byte aligned
+  const uint8_t* s = slots + (size_t)c * slot_stride + (size_t)g * segcap;       // 256-byte aligned, segcap has 280 bytes of slack
   uint8_t* d = out + (size_t)c * out_stride + segoff[(size_t)c * S + g];
-  const uint32_t head = (uint32_t)((4u - ((uintptr_t)d & 3u)) & 3u);              // bytes until d is aligned
+  const uint32_t head = (uint32_t)((16u - ((uintptr_t)d & 15u)) & 15u);           // bytes until d is 16-byte aligned
   const uint32_t h = head < len ? head : len;
   if (threadIdx.x < h)
     d[threadIdx.x] = s[threadIdx.x];
-  const uint32_t body = (len - h) >> 2;                                           // aligned destination dwords
-  uint32_t* dd = (uint32_t*)(d + h);
-  const uint32_t* ss = (const uint32_t*)s;
-  // destination dword t holds source bytes h + 4t .. h + 4t + 3  (h < 4)
+  const uint32_t body = (len - h) >> 4;                                           // aligned destination vectors
+  u32x4* dd = (u32x4*)(d + h);
+  const uint32_t* ss = (const uint32_t*)s + (h >> 2);
+  const uint32_t sh = h & 3u;
+  // destination vector t holds source bytes h + 16t .. h + 16t + 15
   for (uint32_t t = threadIdx.x; t < body; t += 256u)
     {
-    const uint32_t lo = ss[t], hi = ss[t + 1u];
-    dd[t] = h ? __builtin_amdgcn_alignbyte(hi, lo, h) : lo;
+    const u32x4 lo = *(const u32x4*)(ss + 4u * t);                                // 4-byte aligned 16-byte load
+    const uint32_t hi = ss[4u * t + 4u];
+    u32x4 o;
+    o[0] = __builtin_amdgcn_alignbyte(lo[1], lo[0], sh);
+    o[1] = __builtin_amdgcn_alignbyte(lo[2], lo[1], sh);
+    o[2] = __builtin_amdgcn_alignbyte(lo[3], lo[2], sh);
+    o[3] = __builtin_amdgcn_alignbyte(hi, lo[3], sh);
+    dd[t] = o;
     }
-  const uint32_t done = h + 4u * body;
+  const uint32_t done = h + 16u * body;
   if (threadIdx.x < len - done)
     d[done + threadIdx.x] = s[done + threadIdx.x];
   }
