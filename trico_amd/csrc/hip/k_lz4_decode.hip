@@ -42,6 +42,31 @@ struct Job
 
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
+// inclusive prefix maximum over the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_prefix_max(uint32_t v)
+  {
+  uint32_t t;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); v = v > t ? v : t;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true); v = v > t ? v : t;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true); v = v > t ? v : t;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true); v = v > t ? v : t;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); v = v > t ? v : t;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); v = v > t ? v : t;
+  return v;
+  }
+
+// inclusive prefix sum over the 64 lanes of a wave (DPP row shifts + row broadcasts)
+__device__ __forceinline__ uint32_t wave_prefix_add(uint32_t v)
+  {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);                   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);                   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);                   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);                   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);                  // row_bcast:15 into rows 1, 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);                  // row_bcast:31 into rows 2, 3
+  return v;
+  }
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(1))) u128u { u32x4 v; };
 
@@ -121,6 +146,7 @@ __global__ void __launch_bounds__(WG) k_lz4_decode_lds(Lz4DecArgs a, uint8_t* __
   uint8_t* ring = lds;                       // ORING bytes
   uint8_t* cw = lds + ORING;                 // CWIN bytes
   __shared__ Job job;
+  __shared__ uint32_t own[64];                // short-sequence batches: owner (lane + 1) of each output byte of a pass
   const int tid = threadIdx.x;
   const uint8_t* src = a.pay[blockIdx.x];
   const uint32_t n = a.size[blockIdx.x];
@@ -142,8 +168,107 @@ __global__ void __launch_bounds__(WG) k_lz4_decode_lds(Lz4DecArgs a, uint8_t* __
     };
   refill(0);
   bool bad = (n == 0);
+  uint32_t skip = 0;
   while (!bad)
     {
+    // ---- short sequences: the tokens inside the next 64 compressed bytes are parsed at once ---------------------
+    // Every lane reads the byte at ip + lane as if it were a token; hopping from token to token (v_readlane of the
+    // per-lane "next token" distance) marks the real ones.  Offsets, output positions (wave prefix sum) and the
+    // validity checks are then done for all of them together, and each sequence is one vector copy: lanes below
+    // the literal length read the compressed window, the others the output ring (or the sequence's own literals
+    // when the match reaches into them).  Tokens with extended lengths end the batch and take the path below.
+    if (skip)
+      --skip;                                // the last tokens had extended lengths: long sequences, straight to the path below
+    else if (ip + 82u <= n)                  // no sequence starting in the batch can be the final, literal-only one
+      {
+      if (ip + 96u > cw0 + CWIN)
+        refill(ip);
+      const uint32_t rel = ip - cw0;
+      const uint32_t t = cw[rel + (uint32_t)lane];
+      const uint32_t lit = t >> 4, mlc = t & 15u;
+      const uint64_t cx = __ballot(lit == 15u || mlc == 15u);
+      const uint32_t nxt = (uint32_t)lane + 3u + lit;
+      uint64_t R = 0;
+      uint32_t pos = 0, consumed = 0;
+      for (;;)
+        {
+        if ((cx >> pos) & 1ull) { consumed = pos; break; }
+        R |= 1ull << pos;
+        const uint32_t nx = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)pos);
+        if (nx >= 64u) { consumed = nx; break; }
+        pos = nx;
+        }
+      if (R)
+        {
+        const bool in_r = ((R >> lane) & 1ull) != 0ull;
+        const uint32_t offp = rel + (uint32_t)lane + 1u + lit;
+        const uint32_t off = in_r ? ((uint32_t)cw[offp] | ((uint32_t)cw[offp + 1u] << 8)) : 1u;
+        const uint32_t outlen = in_r ? lit + mlc + 4u : 0u;
+        const uint32_t incl = wave_prefix_add(outlen);
+        const uint32_t o = incl - outlen;                                     // output offset of the sequence inside the batch
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (total > cap - op || __ballot(in_r && (off == 0u || off > op + o + lit)))
+          {
+          bad = true;
+          break;
+          }
+        // The batch is copied 64 output bytes at a time, all its sequences together.  The owner of an output byte
+        // is the last sequence that starts at or before it (sequence lanes drop their lane number at their first
+        // byte, prefix maximum over the lanes).  A literal byte comes from the compressed window; a match byte is
+        // the output byte `offset` positions earlier.  When that byte belongs to the same pass, its lane's source
+        // is taken over instead (pointer jumping: at most 6 rounds for 64 lanes), which also covers overlapping
+        // matches; in the end every lane holds the LDS address of a byte that existed before the pass.
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < total; base += 64u)
+          {
+          own[lane] = 0u;
+          if (in_r && o - base < 64u)
+            own[o - base] = (uint32_t)lane + 1u;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          uint32_t w = wave_prefix_max(own[lane]);
+          w = w > carry ? w : carry;
+          carry = (uint32_t)__builtin_amdgcn_readlane((int)w, 63);
+          const uint32_t ow = w - 1u;
+          const uint32_t oo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ow << 2), (int)o);
+          const uint32_t ol = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ow << 2), (int)lit);
+          const uint32_t of = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ow << 2), (int)off);
+          const uint32_t b = base + (uint32_t)lane, k = b - oo;
+          const bool live = b < total;
+          uint32_t addr = ORING + rel + ow + 1u + k;            // literal: LDS index of its byte in the window
+          int from = -1;                                         // lane of this pass that produces my source byte, -1: none
+          if (k >= ol)
+            {
+            const uint32_t src = op + b - of;                     // output position of the source byte
+            addr = src & OMASK;
+            if (src >= op + base)
+              from = (int)(src - (op + base));
+            }
+          if (!live)
+            from = -1;
+          while (__ballot(from >= 0))
+            {
+            const uint32_t ta = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)addr);
+            const int tf = __builtin_amdgcn_ds_bpermute(from << 2, from);
+            if (from >= 0)
+              {
+              addr = ta;
+              from = tf;
+              }
+            }
+          if (live)
+            {
+            const uint8_t v = lds[addr];
+            ring[(op + b) & OMASK] = v;
+            dst[op + b] = v;
+            }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          }
+        ip += consumed;
+        op += total;
+        continue;
+        }
+      skip = 8;
+      }
     if (ip + 64u > cw0 + CWIN)               // token + extension bytes + offset stay inside the window
       refill(ip);
     if (ip >= n) { bad = true; break; }
