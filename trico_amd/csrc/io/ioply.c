@@ -261,6 +261,23 @@ int trico_read_ply(uint32_t* nr_of_vertices, float** vertices, float** vertex_no
     else if (c.p < c.end)
       c.p += 1;
     }
+  /* element counts the rest of the file cannot hold are an error before anything is allocated for them */
+  if (ok)
+    {
+    double need = 0.0;
+    for (int ei = 0; ei < nelems; ++ei)
+      {
+      double per = 0.0;
+      for (int pi = 0; pi < elems[ei].nprops; ++pi)
+        {
+        const prop_t* pr = &elems[ei].props[pi];
+        per += body_mode == M_ASCII ? 2.0 : (double)type_size[pr->is_list ? pr->len_type : pr->type];
+        }
+      need += per * (double)elems[ei].count;
+      }
+    if (need > (double)(c.end - c.p) + 1.0)
+      ok = 0;
+    }
   if (!ok)
     {
     free_elems(elems, nelems);

@@ -159,6 +159,15 @@ static int read_impl(uint32_t* nr_of_vertices, float** vertices, uint32_t* nr_of
   uint32_t ntri;
   memcpy(&ntri, head + 80, 4);
   const size_t body = (size_t)ntri * 50;
+  /* a count the file cannot hold is an error before anything is allocated for it */
+  long here = ftell(f), end = -1;
+  if (here >= 0 && fseek(f, 0, SEEK_END) == 0)
+    end = ftell(f);
+  if (here < 0 || end < 0 || (size_t)(end - here) < body || fseek(f, here, SEEK_SET) != 0)
+    {
+    fclose(f);
+    return 0;
+    }
   unsigned char* raw = (unsigned char*)malloc(body ? body : 1);
   float* v = (float*)malloc((size_t)ntri * 9 * sizeof(float) + 1);
   uint32_t* t = (uint32_t*)malloc((size_t)ntri * 3 * sizeof(uint32_t) + 1);
