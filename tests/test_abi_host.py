@@ -90,3 +90,45 @@ def test_writers_fail_loudly_without_gpu(native_libs):
     assert "no CPU fallback" in native_libs.last_error()
     assert a.get_size() == 8
     a.close()
+
+
+def test_container_walk_under_sanitizers_on_mutated_archives(tmp_path, gold_dir):
+    """archive.c (container framing, peeks, skip) built with ASan + UBSan against stubbed device entry points
+    (tests/archive_fuzz_driver.c), fed truncated / bit-flipped / padded copies of the golden archives."""
+    import glob
+    import random
+    import subprocess
+    exe = str(tmp_path / "arch_fuzz")
+    cc = subprocess.run(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                         "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "archive_fuzz_driver.c"),
+                         os.path.join(ROOT, "trico_amd", "csrc", "host", "archive.c"), "-o", exe], capture_output=True, text=True)
+    if cc.returncode != 0:
+        pytest.skip("no sanitizer-capable gcc: " + cc.stderr[-200:])
+    rnd = random.Random(7)
+    src = sorted(glob.glob(os.path.join(gold_dir, "*.trc")) + glob.glob(os.path.join(gold_dir, "cli", "*.trc")))
+    files = list(src)
+    for f in src:
+        blob = open(f, "rb").read()
+        for j in range(30):
+            m = bytearray(blob)
+            mode = rnd.randrange(4)
+            if mode == 0:
+                m = m[:rnd.randrange(len(m))]
+            elif mode == 1:
+                for _ in range(rnd.randrange(1, 4)):
+                    m[rnd.randrange(min(len(m), 64))] = rnd.randrange(256)      # headers and the first size fields
+            elif mode == 2:
+                for _ in range(rnd.randrange(1, 6)):
+                    m[rnd.randrange(len(m))] = rnd.randrange(256)
+            else:
+                i = rnd.randrange(len(m))
+                m[i:i + 4] = (0xffffffff if rnd.randrange(2) else rnd.randrange(1 << 32)).to_bytes(4, "little")
+            p = str(tmp_path / ("a%d_%d.trc" % (len(files), j)))
+            open(p, "wb").write(m)
+            files.append(p)
+    opened = 0
+    for i in range(0, len(files), 80):
+        r = subprocess.run([exe] + files[i:i + 80], capture_output=True, text=True)
+        assert r.returncode == 0 and "ERROR" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
+        opened += r.stdout.count("opened=1")
+    assert opened >= len(src)
