@@ -336,3 +336,45 @@ def test_fp32_encoder_unaligned_device_pointer(api, shift):
     got = a.tobytes()
     a.close()
     assert got == oracle_archive([("vertices", v.reshape(-1), n)])
+
+
+def test_mutated_archives_never_crash(api, gold_dir):
+    """every reader either fails cleanly (0, cursor unchanged) or returns data; nothing may fault on corrupt input"""
+    import random
+    rnd = random.Random(99)
+    names = ["grid_16x8.trc", "walk_16x8.trc", "multi_16x8.trc", "allstreams.trc"]
+    reads = fails = 0
+    for name in names:
+        blob = open(os.path.join(gold_dir, name), "rb").read()
+        for j in range(24):
+            m = bytearray(blob)
+            for _ in range(rnd.randrange(1, 5)):
+                m[rnd.randrange(8, len(m))] = rnd.randrange(256)
+            if j % 6 == 5:
+                m = m[:rnd.randrange(16, len(m))]
+            r = api.Archive.open_for_reading(bytes(m))
+            assert r is not None
+            for _ in range(40):
+                st = r.get_next_stream_type()
+                if st == api.trico_empty:
+                    break
+                name_of = [k for k, v in STREAM_TAG.items() if v == st]
+                if not name_of or name_of[0] in ("attributes_float", "attributes_double"):
+                    if r.skip_next_stream() != 1:
+                        break
+                    continue
+                # generously sized destination: the (possibly corrupted) count field decides how much is written
+                cnt = max(r.get_number_of(w) for w in ("vertices", "triangles", "uvs", "normals", "colors", "attributes"))
+                if cnt > 1 << 16:
+                    if r.skip_next_stream() != 1:
+                        break
+                    continue
+                out = np.empty(cnt * 9 + 64, np.uint64)
+                if r.read(name_of[0], out) == 1:
+                    reads += 1
+                else:
+                    fails += 1
+                    if r.skip_next_stream() != 1:
+                        break
+            r.close()
+    assert reads > 0 and fails > 0
