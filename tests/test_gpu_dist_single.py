@@ -1,0 +1,44 @@
+"""The RCCL leg of the multi-GPU path as far as one GPU can exercise it: process group over the nccl backend with
+world size 1, the device-pointer wrapper around a device-resident archive, all_gather of sizes and the root's
+assembly in trico_amd.parallel.gather_archives.  (The point-to-point part is covered on gloo, world 2 and 3.)"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, hashlib
+sys.path.insert(0, %r)
+import numpy as np, torch
+import torch.distributed as dist
+from trico_amd import api, meshgen
+from trico_amd.parallel import gather_archives, wrap_device_bytes, split_archives
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+torch.cuda.set_device(0)
+v, t = meshgen.grid(64, 32)
+a = api.Archive.open_for_writing(1 << 16, device=True)
+assert a.write("vertices", torch.from_numpy(v).cuda(), 64 * 32) == 1
+assert a.write("triangles", torch.from_numpy(t.view(np.int32)).cuda(), 2 * 64 * 32) == 1
+size = a.get_size()
+w = wrap_device_bytes(a.get_buffer_pointer(), size, torch.device("cuda", 0))
+assert w.is_cuda and w.numel() == size and w.data_ptr() == a.get_buffer_pointer()
+out, sizes = gather_archives(dist, w, dst=0)
+dist.barrier()
+torch.cuda.synchronize()
+assert sizes == [size]
+parts = split_archives(out, sizes)
+assert bytes(parts[0].cpu().numpy().tobytes()) == a.tobytes()
+a.close()
+dist.destroy_process_group()
+print("OK", size)
+'''
+
+
+def test_nccl_world1_gather(tmp_path):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, "-c", WORKER % ROOT], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
