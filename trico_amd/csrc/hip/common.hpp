@@ -107,11 +107,10 @@ int launch_fpc64_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
 int launch_fpc64_decode(const uint8_t* const d_payloads[3], const uint32_t sizes[3], int arity, uint32_t n, void* d_dst,
                         uint64_t* d_tables, uint32_t* d_status);
 
-// wave-cooperative LZ4 (k_lz4.hip): one wave per plane, wide match counting / copies
+// workgroup-per-plane LZ4 compressor for small planes (k_lz4.hip)
 int launch_lz4_encode_wave(const uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, int nplanes, uint8_t* d_out,
                            size_t out_stride, uint32_t* d_sizes);
-int launch_lz4_decode_wave(const uint8_t* const d_payloads[8], const uint32_t sizes[8], int nplanes,
-                           uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, uint32_t* d_status);
+
 
 // LDS-window LZ4 decompressor (k_lz4_decode.hip): one workgroup per plane
 int launch_lz4_decode_lds(const uint8_t* const d_payloads[8], const uint32_t sizes[8], int nplanes,

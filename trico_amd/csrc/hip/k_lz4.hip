@@ -1,4 +1,5 @@
-// k_lz4.hip — LZ4 block compressor / decompressor, one 1024-thread workgroup per byte plane.
+// k_lz4.hip — LZ4 block compressor for planes below 4 MiB, one 1024-thread workgroup per byte plane
+// (larger planes: k_lz4_chunked.hip; decompressor: k_lz4_decode.hip).
 //
 // Compressor: byte-exact with LZ4 1.9.2's LZ4_compress_default as Trico calls it (trico.c:343-368 ->
 // lz4.c:1271 -> 1184 -> LZ4_compress_generic lz4.c:793-1181, notLimited, byU16 below 65547 input
@@ -10,8 +11,6 @@
 //   * long ones (>= BULK_MIN bytes) are posted as a job to the 15 helper waves parked on a barrier and
 //     done by all 1024 threads, 64 KiB per iteration (LZ4_count, lz4.c:539-563, is a first-mismatch
 //     search: per-wave ballot + LDS atomicMin).
-// Decompressor: LZ4_decompress_safe semantics (lz4.c:1657-2072) with the same job scheme for literal
-// copies and for (period-aware, doubling) match copies.
 //
 // Roofline: HBM-bound only on long matches / long literal runs; otherwise latency-bound on the
 // dependent chain.  Algorithmic bytes per plane byte: 1 read + its share of the block written.
@@ -365,84 +364,6 @@ __global__ void __launch_bounds__(WG) k_lz4_encode(const uint8_t* __restrict__ p
 #undef LZ_SET
   }
 
-// ---- decompressor ---------------------------------------------------------------------------------------
-struct Lz4DecArgs
-  {
-  const uint8_t* pay[8];
-  uint32_t size[8];
-  };
-
-// dst[0..n) = dst[-off..), the LZ77 overlap-aware copy.  With overlap (off < n) the result is periodic
-// with period `off`: copy one period from before dst, then the already written prefix (a whole number
-// of periods) is replicated by doubling: dst[w .. w+c) = dst[0 .. c), c <= w, non-overlapping copies that
-// go to the whole workgroup once they are long.
-__device__ __forceinline__ void match_copy(Job* job, uint8_t* __restrict__ dst, uint32_t off, uint32_t n, int tid)
-  {
-  uint32_t w = off < n ? off : n;
-  any_copy(job, dst, dst - off, w, tid);
-  while (w < n)
-    {
-    __builtin_amdgcn_s_waitcnt(0);                  // the prefix must have landed before it is re-read
-    const uint32_t c = n - w < w ? n - w : w;
-    any_copy(job, dst + w, dst, c, tid);
-    w += c;
-    }
-  }
-
-__global__ void __launch_bounds__(WG) k_lz4_decode(Lz4DecArgs a, uint8_t* __restrict__ planes, size_t plane_stride, uint32_t cap,
-                                                   uint32_t* __restrict__ status)
-  {
-  __shared__ Job job;
-  const int tid = threadIdx.x;
-  if (tid >= 64)
-    {
-    helper_loop(&job, tid);
-    return;
-    }
-  const int lane = tid;
-  const uint8_t* src = a.pay[blockIdx.x];
-  const uint32_t n = a.size[blockIdx.x];
-  uint8_t* dst = planes + (size_t)blockIdx.x * plane_stride;
-  uint32_t ip = 0, op = 0;
-  bool bad = (n == 0);
-  while (!bad)
-    {
-    if (ip >= n) { bad = true; break; }
-    const uint32_t tok = uni(src[ip]);
-    ++ip;
-    uint32_t lit = tok >> 4;
-    if (lit == 15u)
-      {
-      uint32_t bb;
-      do { if (ip >= n) { bad = true; break; } bb = uni(src[ip]); ++ip; lit += bb; } while (bb == 255u);
-      if (bad) break;
-      }
-    if (lit > n - ip || lit > cap - op) { bad = true; break; }
-    any_copy(&job, dst + op, src + ip, lit, tid);
-    ip += lit; op += lit;
-    if (ip == n) break;                                   // last sequence: literals only
-    if (n - ip < 2u) { bad = true; break; }
-    const uint32_t off = uni((uint32_t)src[ip] | ((uint32_t)src[ip + 1] << 8));
-    ip += 2;
-    if (off == 0u || off > op) { bad = true; break; }
-    uint32_t ml = tok & 15u;
-    if (ml == 15u)
-      {
-      uint32_t bb;
-      do { if (ip >= n) { bad = true; break; } bb = uni(src[ip]); ++ip; ml += bb; } while (bb == 255u);
-      if (bad) break;
-      }
-    ml += 4u;
-    if (ml > cap - op) { bad = true; break; }
-    __builtin_amdgcn_s_waitcnt(0);                        // earlier stores of this wave must land before they are re-read
-    match_copy(&job, dst + op, off, ml, tid);
-    op += ml;
-    }
-  if ((bad || op != cap) && lane == 0)
-    atomicOr(status, 8u);
-  run_exit(&job, tid);
-  }
-
 } // namespace
 
 int launch_lz4_encode_wave(const uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, int nplanes, uint8_t* d_out,
@@ -451,20 +372,6 @@ int launch_lz4_encode_wave(const uint8_t* d_planes, size_t plane_stride, uint32_
   hipLaunchKernelGGL(k_lz4_encode, dim3(nplanes), dim3(WG), 0, current_stream(),
                      d_planes, plane_stride, plane_bytes, d_out, out_stride, d_sizes);
   return hip_ok(hipGetLastError(), "k_lz4_encode") ? 1 : 0;
-  }
-
-int launch_lz4_decode_wave(const uint8_t* const d_payloads[8], const uint32_t sizes[8], int nplanes,
-                           uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, uint32_t* d_status)
-  {
-  Lz4DecArgs a;
-  for (int c = 0; c < 8; ++c)
-    {
-    a.pay[c] = c < nplanes ? d_payloads[c] : nullptr;
-    a.size[c] = c < nplanes ? sizes[c] : 0;
-    }
-  hipLaunchKernelGGL(k_lz4_decode, dim3(nplanes), dim3(WG), 0, current_stream(),
-                     a, d_planes, plane_stride, plane_bytes, d_status);
-  return hip_ok(hipGetLastError(), "k_lz4_decode") ? 1 : 0;
   }
 
 } // namespace trico
