@@ -58,71 +58,76 @@ enum trico_stream_type
   trico_attribute_uint64_stream = 20
   };
 
-/* reference: trico/trico.h:36-38, trico.c:126-189 */
-TRICO_API void* trico_open_archive_for_writing(uint64_t initial_buffer_size);
-TRICO_API void* trico_open_archive_for_reading(const uint8_t* data, uint64_t data_size);
-TRICO_API void trico_close_archive(void* archive);
+/* ---- archives (reference: trico/trico.h:36-38, trico.c:126-189) ----------------------------------
+ * A write archive owns a growing buffer (initial capacity in bytes); a read archive borrows `bytes`. */
+TRICO_API void* trico_open_archive_for_writing(uint64_t initial_capacity);
+TRICO_API void* trico_open_archive_for_reading(const uint8_t* bytes, uint64_t byte_count);
+TRICO_API void  trico_close_archive(void* arc);
 
-/* reference: trico/trico.h:40-60, trico.c:215-858 */
-TRICO_API int trico_write_vertices(void* archive, const float* vertices, uint32_t nr_of_vertices);
-TRICO_API int trico_write_vertices_double(void* archive, const double* vertices, uint32_t nr_of_vertices);
-TRICO_API int trico_write_triangles(void* archive, const uint32_t* tria_indices, uint32_t nr_of_triangles);
-TRICO_API int trico_write_triangles_long(void* archive, const uint64_t* tria_indices, uint32_t nr_of_triangles);
-TRICO_API int trico_write_uv_per_vertex(void* archive, const float* uv, uint32_t nr_of_uv_positions);
-TRICO_API int trico_write_uv_per_vertex_double(void* archive, const double* uv, uint32_t nr_of_uv_positions);
-TRICO_API int trico_write_uv_per_triangle(void* archive, const float* uv, uint32_t nr_of_uv_positions);
-TRICO_API int trico_write_uv_per_triangle_double(void* archive, const double* uv, uint32_t nr_of_uv_positions);
-TRICO_API int trico_write_vertex_normals(void* archive, const float* normals, uint32_t nr_of_normals);
-TRICO_API int trico_write_vertex_normals_double(void* archive, const double* normals, uint32_t nr_of_normals);
-TRICO_API int trico_write_triangle_normals(void* archive, const float* normals, uint32_t nr_of_normals);
-TRICO_API int trico_write_triangle_normals_double(void* archive, const double* normals, uint32_t nr_of_normals);
-TRICO_API int trico_write_vertex_colors(void* archive, const uint32_t* color, uint32_t nr_of_colors);
-TRICO_API int trico_write_triangle_colors(void* archive, const uint32_t* color, uint32_t nr_of_colors);
-TRICO_API int trico_write_attributes_float(void* archive, const float* attrib, uint32_t nr_of_attribs);
-TRICO_API int trico_write_attributes_double(void* archive, const double* attrib, uint32_t nr_of_attribs);
-TRICO_API int trico_write_attributes_uint8(void* archive, const uint8_t* attrib, uint32_t nr_of_attribs);
-TRICO_API int trico_write_attributes_uint16(void* archive, const uint16_t* attrib, uint32_t nr_of_attribs);
-TRICO_API int trico_write_attributes_uint32(void* archive, const uint32_t* attrib, uint32_t nr_of_attribs);
-TRICO_API int trico_write_attributes_uint64(void* archive, const uint64_t* attrib, uint32_t nr_of_attribs);
+/* ---- writers (reference: trico/trico.h:40-60, trico.c:215-858) ----------------------------------
+ * Each call appends one stream.  `n` counts elements of the stream's natural unit: vertices (3 reals),
+ * triangles (3 indices), uv positions (2 reals; the per-triangle float writer stores 3 * n of them,
+ * trico.c:579), normals (3 reals), colours (1 uint32), attributes (1 scalar). */
+TRICO_API int trico_write_vertices                (void* arc, const float*    xyz,     uint32_t n);
+TRICO_API int trico_write_vertices_double         (void* arc, const double*   xyz,     uint32_t n);
+TRICO_API int trico_write_triangles               (void* arc, const uint32_t* corners, uint32_t n);
+TRICO_API int trico_write_triangles_long          (void* arc, const uint64_t* corners, uint32_t n);
+TRICO_API int trico_write_uv_per_vertex           (void* arc, const float*    uv,      uint32_t n);
+TRICO_API int trico_write_uv_per_vertex_double    (void* arc, const double*   uv,      uint32_t n);
+TRICO_API int trico_write_uv_per_triangle         (void* arc, const float*    uv,      uint32_t n);
+TRICO_API int trico_write_uv_per_triangle_double  (void* arc, const double*   uv,      uint32_t n);
+TRICO_API int trico_write_vertex_normals          (void* arc, const float*    nxyz,    uint32_t n);
+TRICO_API int trico_write_vertex_normals_double   (void* arc, const double*   nxyz,    uint32_t n);
+TRICO_API int trico_write_triangle_normals        (void* arc, const float*    nxyz,    uint32_t n);
+TRICO_API int trico_write_triangle_normals_double (void* arc, const double*   nxyz,    uint32_t n);
+TRICO_API int trico_write_vertex_colors           (void* arc, const uint32_t* rgba,    uint32_t n);
+TRICO_API int trico_write_triangle_colors         (void* arc, const uint32_t* rgba,    uint32_t n);
+TRICO_API int trico_write_attributes_float        (void* arc, const float*    values,  uint32_t n);
+TRICO_API int trico_write_attributes_double       (void* arc, const double*   values,  uint32_t n);
+TRICO_API int trico_write_attributes_uint8        (void* arc, const uint8_t*  values,  uint32_t n);
+TRICO_API int trico_write_attributes_uint16       (void* arc, const uint16_t* values,  uint32_t n);
+TRICO_API int trico_write_attributes_uint32       (void* arc, const uint32_t* values,  uint32_t n);
+TRICO_API int trico_write_attributes_uint64       (void* arc, const uint64_t* values,  uint32_t n);
 
-/* reference: trico/trico.h:62-63, trico.c:191-201 */
-TRICO_API uint8_t* trico_get_buffer_pointer(void* archive);
-TRICO_API uint64_t trico_get_size(void* archive);
+/* ---- the encoded bytes (reference: trico/trico.h:62-63, trico.c:191-201) ------------------------- */
+TRICO_API uint8_t* trico_get_buffer_pointer(void* arc);     /* invalidated by the next write */
+TRICO_API uint64_t trico_get_size(void* arc);
 
-/* reference: trico/trico.h:65-66, trico.c:203-213 */
-TRICO_API uint32_t trico_get_version(void* archive);
-TRICO_API enum trico_stream_type trico_get_next_stream_type(void* archive);
+/* ---- cursor (reference: trico/trico.h:65-73, trico.c:203-213, 860-941) ---------------------------
+ * The count peeks return 0 unless the next stream is of the matching kind; they do not advance. */
+TRICO_API uint32_t               trico_get_version(void* arc);
+TRICO_API enum trico_stream_type trico_get_next_stream_type(void* arc);
+TRICO_API uint32_t trico_get_number_of_vertices  (void* arc);
+TRICO_API uint32_t trico_get_number_of_triangles (void* arc);
+TRICO_API uint32_t trico_get_number_of_uvs       (void* arc);
+TRICO_API uint32_t trico_get_number_of_normals   (void* arc);
+TRICO_API uint32_t trico_get_number_of_colors    (void* arc);
+TRICO_API uint32_t trico_get_number_of_attributes(void* arc);
 
-/* reference: trico/trico.h:68-73, trico.c:860-941 (peek, no advance) */
-TRICO_API uint32_t trico_get_number_of_vertices(void* archive);
-TRICO_API uint32_t trico_get_number_of_triangles(void* archive);
-TRICO_API uint32_t trico_get_number_of_uvs(void* archive);
-TRICO_API uint32_t trico_get_number_of_normals(void* archive);
-TRICO_API uint32_t trico_get_number_of_colors(void* archive);
-TRICO_API uint32_t trico_get_number_of_attributes(void* archive);
-
-/* reference: trico/trico.h:75-95, trico.c:943-1698 */
-TRICO_API int trico_read_vertices(void* archive, float** vertices);
-TRICO_API int trico_read_vertices_double(void* archive, double** vertices);
-TRICO_API int trico_read_triangles(void* archive, uint32_t** triangles);
-TRICO_API int trico_read_triangles_long(void* archive, uint64_t** triangles);
-TRICO_API int trico_read_uv_per_vertex(void* archive, float** uv);
-TRICO_API int trico_read_uv_per_vertex_double(void* archive, double** uv);
-TRICO_API int trico_read_uv_per_triangle(void* archive, float** uv);
-TRICO_API int trico_read_uv_per_triangle_double(void* archive, double** uv);
-TRICO_API int trico_read_vertex_normals(void* archive, float** normals);
-TRICO_API int trico_read_vertex_normals_double(void* archive, double** normals);
-TRICO_API int trico_read_triangle_normals(void* archive, float** normals);
-TRICO_API int trico_read_triangle_normals_double(void* archive, double** normals);
-TRICO_API int trico_read_vertex_colors(void* archive, uint32_t** color);
-TRICO_API int trico_read_triangle_colors(void* archive, uint32_t** color);
-TRICO_API int trico_read_attributes_float(void* archive, float** attrib);
-TRICO_API int trico_read_attributes_double(void* archive, double** attrib);
-TRICO_API int trico_read_attributes_uint8(void* archive, uint8_t** attrib);
-TRICO_API int trico_read_attributes_uint16(void* archive, uint16_t** attrib);
-TRICO_API int trico_read_attributes_uint32(void* archive, uint32_t** attrib);
-TRICO_API int trico_read_attributes_uint64(void* archive, uint64_t** attrib);
-TRICO_API int trico_skip_next_stream(void* archive);
+/* ---- readers (reference: trico/trico.h:75-95, trico.c:943-1698) ----------------------------------
+ * `*out` is caller-allocated for the count the peek announced (attributes_float / _double: allocated by
+ * the library with malloc, caller frees); out == NULL skips the stream, as does trico_skip_next_stream. */
+TRICO_API int trico_read_vertices                (void* arc, float**    out);
+TRICO_API int trico_read_vertices_double         (void* arc, double**   out);
+TRICO_API int trico_read_triangles               (void* arc, uint32_t** out);
+TRICO_API int trico_read_triangles_long          (void* arc, uint64_t** out);
+TRICO_API int trico_read_uv_per_vertex           (void* arc, float**    out);
+TRICO_API int trico_read_uv_per_vertex_double    (void* arc, double**   out);
+TRICO_API int trico_read_uv_per_triangle         (void* arc, float**    out);
+TRICO_API int trico_read_uv_per_triangle_double  (void* arc, double**   out);
+TRICO_API int trico_read_vertex_normals          (void* arc, float**    out);
+TRICO_API int trico_read_vertex_normals_double   (void* arc, double**   out);
+TRICO_API int trico_read_triangle_normals        (void* arc, float**    out);
+TRICO_API int trico_read_triangle_normals_double (void* arc, double**   out);
+TRICO_API int trico_read_vertex_colors           (void* arc, uint32_t** out);
+TRICO_API int trico_read_triangle_colors         (void* arc, uint32_t** out);
+TRICO_API int trico_read_attributes_float        (void* arc, float**    out);
+TRICO_API int trico_read_attributes_double       (void* arc, double**   out);
+TRICO_API int trico_read_attributes_uint8        (void* arc, uint8_t**  out);
+TRICO_API int trico_read_attributes_uint16       (void* arc, uint16_t** out);
+TRICO_API int trico_read_attributes_uint32       (void* arc, uint32_t** out);
+TRICO_API int trico_read_attributes_uint64       (void* arc, uint64_t** out);
+TRICO_API int trico_skip_next_stream             (void* arc);
 
 #if defined(__cplusplus)
 }
