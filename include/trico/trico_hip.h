@@ -48,6 +48,17 @@ TRICO_API int   trico_hip_copy(void* dst, const void* src, size_t bytes);   /* a
  * the next encode and are copied out with trico_hip_fetch_payload. */
 TRICO_API int trico_hip_fpc_encode(trico_hip_ctx* ctx, const void* src, uint32_t n, int arity, int width, uint32_t sizes[3]);
 
+/* Same with explicit table size exponents (the arguments of trico_compress, fpsc.c:86): even values, 2..4 / 2..10
+ * for width 4 and 2..20 / 2..20 for width 8 (larger tables than the archive API ever writes are not supported). */
+TRICO_API int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int arity, int width,
+                                      uint32_t e1, uint32_t e2, uint32_t sizes[3]);
+
+/* Stand-alone transposes (transpose_aos_to_soa.c:8-147), for the low-level API in
+ * include/trico/transpose_aos_to_soa.h.  width 4 / 8: `arity` components of interleaved reals; width 1: the `arity`
+ * byte planes of n `arity`-byte integers.  comps[c] and aos may be host or device pointers. */
+TRICO_API int trico_hip_split_components(trico_hip_ctx* ctx, const void* aos, uint32_t n, int arity, int width, void* const* comps);
+TRICO_API int trico_hip_merge_components(trico_hip_ctx* ctx, const void* const* comps, uint32_t n, int arity, int width, void* aos);
+
 /* Inverse: trico_decompress / trico_decompress_double_precision (fpsc.c:212-417 / 803-1164) per
  * component, then trico_transpose_*_soa_to_aos.  Every payload must announce exactly `n` values.
  * dst == NULL decodes and discards. */

@@ -204,15 +204,17 @@ _libc = ctypes.CDLL(None)
 _libc.free.argtypes = [ctypes.c_void_p]
 
 
-def ref_fpc_encode(values):
+def ref_fpc_encode(values, e1=None, e2=None):
     a = np.ascontiguousarray(values)
     L = ref()
     nb = ctypes.c_uint32(0)
     out = ctypes.c_void_p(None)
+    if e1 is None:
+        e1, e2 = (4, 10) if a.dtype.itemsize == 4 else (20, 20)
     if a.dtype.itemsize == 4:
-        L.trico_compress(ctypes.byref(nb), ctypes.byref(out), a.ctypes.data, a.size, 4, 10)
+        L.trico_compress(ctypes.byref(nb), ctypes.byref(out), a.ctypes.data, a.size, ctypes.c_uint32(e1), ctypes.c_uint32(e2))
     else:
-        L.trico_compress_double_precision(ctypes.byref(nb), ctypes.byref(out), a.ctypes.data, a.size, 20, 20)
+        L.trico_compress_double_precision(ctypes.byref(nb), ctypes.byref(out), a.ctypes.data, a.size, ctypes.c_uint64(e1), ctypes.c_uint64(e2))
     b = ctypes.string_at(out, nb.value)
     _libc.free(out)
     return b

@@ -12,12 +12,24 @@ from streams import ALL_ORDER, STREAM_TAG
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
+def declared_symbols(headers=("trico.h", "trico_hip.h")):
     names = []
-    for h in ("trico.h", "trico_hip.h"):
+    for h in headers:
         text = open(os.path.join(ROOT, "include", "trico", h)).read()
         names += re.findall(r"TRICO_API[^;(]*?\b(trico_\w+)\s*\(", text)
     return names
+
+
+def test_exports_the_low_level_api(native_libs):
+    """floating_point_stream_compression.h:11-17 and transpose_aos_to_soa.h:12-38 of the reference: 4 + 14 functions"""
+    L = ctypes.CDLL(native_libs.LIB_PATH)
+    names = declared_symbols(("floating_point_stream_compression.h", "transpose_aos_to_soa.h"))
+    assert len(names) == 18 and len(set(names)) == 18
+    for n in names:
+        assert hasattr(L, n), n
+    io = ctypes.CDLL(os.path.join(ROOT, "trico_amd", "lib", "libtrico_io.so"))
+    for n in ("trico_read_stl", "trico_read_stl_full", "trico_write_stl", "trico_read_ply", "trico_write_ply"):
+        assert hasattr(io, n), n
 
 
 def test_exports_every_declared_symbol(native_libs):

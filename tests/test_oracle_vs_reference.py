@@ -37,6 +37,19 @@ def test_fp_streams_match_reference():
     assert checked > 40
 
 
+@pytest.mark.parametrize("dt,e", [(np.float32, (2, 2)), (np.float32, (2, 10)), (np.float32, (4, 6)), (np.float32, (4, 8)),
+                                  (np.float64, (2, 2)), (np.float64, (10, 12)), (np.float64, (16, 20)), (np.float64, (20, 18))])
+def test_fp_streams_other_table_exponents(dt, e):
+    """the exponent pairs the low-level API tests use on the GPU (tests/test_gpu_lowlevel.py), pinned here"""
+    rng = np.random.default_rng(3)
+    for n in (17, 1000, 5003):
+        a = (np.cumsum(rng.integers(-128, 128, n)) / 1024.0).astype(dt)
+        o = O.fpc_encode(a, *e)
+        if _ref_safe(a, len(o)):
+            assert O.ref_fpc_encode(a, *e) == o, (n, e)
+        assert O.fpc_decode(o, dt).tobytes() == a.tobytes()
+
+
 def test_lz4_matches_reference():
     rng = np.random.default_rng(12)
     for n in [0, 1, 4, 12, 13, 14, 20, 64, 100, 4096, 65535, 65546, 65547, 65548, 70000, 300000]:

@@ -22,7 +22,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CC = os.environ.get("CC", "gcc")
 ARCH = "gfx950"
 
-HOST_C = ["host/archive.c"]
+HOST_C = ["host/archive.c", "host/lowlevel.c"]
 HIP_SRC = sorted(f for f in os.listdir(os.path.join(CSRC, "hip")) if f.endswith(".hip"))
 HIP_HDR = sorted(f for f in os.listdir(os.path.join(CSRC, "hip")) if f.endswith(".hpp"))
 

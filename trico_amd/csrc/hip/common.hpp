@@ -82,7 +82,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // serial reference-order kernels (k_serial.hip): one workgroup per component stream / plane.
 int launch_fpc_encode_serial(const void* d_src, uint32_t n, int arity, int width, uint8_t* d_out, size_t out_stride,
-                             uint32_t* d_sizes, uint64_t* d_tables);
+                             uint32_t* d_sizes, uint64_t* d_tables, unsigned e1, unsigned e2);
 int launch_fpc_decode_serial(const uint8_t* const d_payloads[3], const uint32_t sizes[3], int arity, int width,
                              uint32_t n, void* d_dst, uint64_t* d_tables, uint32_t* d_status);
 int launch_lz4_encode_serial(const uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, int nplanes, uint8_t* d_out,
@@ -121,6 +121,10 @@ uint32_t lz4_chunked_threshold();
 size_t lz4_chunked_workspace(uint32_t n, int nplanes, size_t plane_stride);
 int launch_lz4_encode_chunked(const uint8_t* d_planes, size_t plane_stride, uint32_t n, int nplanes, uint8_t* d_out, size_t out_stride,
                               uint32_t* d_sizes, uint8_t* d_ws, size_t ws_bytes, uint32_t* d_status);
+
+// component split / merge of interleaved reals (k_planes.hip): comp c of element i <-> d_soa + c * comp_stride bytes
+int launch_deinterleave(const void* d_aos, uint32_t n, int arity, int width, uint8_t* d_soa, size_t comp_stride);
+int launch_interleave(const uint8_t* d_soa, size_t comp_stride, uint32_t n, int arity, int width, void* d_aos);
 
 // byte-plane split / merge (k_planes.hip)
 int launch_planes_split(const void* d_src, uint32_t count, int width, uint8_t* d_planes, size_t plane_stride);

@@ -158,4 +158,46 @@ int launch_planes_merge(const uint8_t* d_planes, size_t plane_stride, uint32_t c
   return hip_ok(hipGetLastError(), "k_planes_merge") ? 1 : 0;
   }
 
+// ---- components of interleaved reals (stand-alone transposes of the reference's low-level API) --------------
+// Bit copies of 4- or 8-byte elements; one thread per element, component stores coalesced, interleaved side strided.
+template <typename T>
+__global__ void __launch_bounds__(256) k_deinterleave(const T* __restrict__ aos, uint32_t n, int arity, uint8_t* __restrict__ soa, size_t comp_stride)
+  {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n)
+    return;
+  for (int c = 0; c < arity; ++c)
+    ((T*)(soa + (size_t)c * comp_stride))[i] = aos[(size_t)i * arity + c];
+  }
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_interleave(const uint8_t* __restrict__ soa, size_t comp_stride, uint32_t n, int arity, T* __restrict__ aos)
+  {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n)
+    return;
+  for (int c = 0; c < arity; ++c)
+    aos[(size_t)i * arity + c] = ((const T*)(soa + (size_t)c * comp_stride))[i];
+  }
+
+int launch_deinterleave(const void* d_aos, uint32_t n, int arity, int width, uint8_t* d_soa, size_t comp_stride)
+  {
+  const unsigned blocks = (n + 255u) / 256u;
+  if (width == 4)
+    hipLaunchKernelGGL(k_deinterleave<uint32_t>, dim3(blocks), dim3(256), 0, current_stream(), (const uint32_t*)d_aos, n, arity, d_soa, comp_stride);
+  else
+    hipLaunchKernelGGL(k_deinterleave<uint64_t>, dim3(blocks), dim3(256), 0, current_stream(), (const uint64_t*)d_aos, n, arity, d_soa, comp_stride);
+  return hip_ok(hipGetLastError(), "k_deinterleave") ? 1 : 0;
+  }
+
+int launch_interleave(const uint8_t* d_soa, size_t comp_stride, uint32_t n, int arity, int width, void* d_aos)
+  {
+  const unsigned blocks = (n + 255u) / 256u;
+  if (width == 4)
+    hipLaunchKernelGGL(k_interleave<uint32_t>, dim3(blocks), dim3(256), 0, current_stream(), d_soa, comp_stride, n, arity, (uint32_t*)d_aos);
+  else
+    hipLaunchKernelGGL(k_interleave<uint64_t>, dim3(blocks), dim3(256), 0, current_stream(), d_soa, comp_stride, n, arity, (uint64_t*)d_aos);
+  return hip_ok(hipGetLastError(), "k_interleave") ? 1 : 0;
+  }
+
 } // namespace trico

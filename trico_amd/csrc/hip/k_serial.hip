@@ -37,10 +37,10 @@ template <typename T> __device__ __forceinline__ uint8_t* put_be(uint8_t* o, T x
 template <int W>
 __global__ void __launch_bounds__(64) k_fpc_encode_serial(const typename word<W>::type* __restrict__ src, uint32_t n, int arity,
                                                           uint8_t* out_base, size_t out_stride, uint32_t* sizes,
-                                                          uint64_t* gtables)
+                                                          uint64_t* gtables, unsigned E1, unsigned E2)
   {
+  // E1 / E2: table size exponents (even; at most 4 / 10 for W = 32 where the tables live in LDS, 20 / 20 for W = 64)
   typedef typename word<W>::type T;
-  constexpr unsigned E1 = (W == 32) ? 4 : 20, E2 = (W == 32) ? 10 : 20;
   constexpr unsigned G = (W == 32) ? 8 : 2, WB = W / 8;
   __shared__ T lds_tab[(W == 32) ? (16 + 1024) : 1];
   const int c = blockIdx.x;
@@ -364,14 +364,14 @@ __global__ void __launch_bounds__(64) k_lz4_decode_serial(Lz4DecArgs a, uint8_t*
 // ---- launchers --------------------------------------------------------------------------------------
 
 int launch_fpc_encode_serial(const void* d_src, uint32_t n, int arity, int width, uint8_t* d_out, size_t out_stride,
-                             uint32_t* d_sizes, uint64_t* d_tables)
+                             uint32_t* d_sizes, uint64_t* d_tables, unsigned e1, unsigned e2)
   {
   if (width == 4)
     hipLaunchKernelGGL(k_fpc_encode_serial<32>, dim3(arity), dim3(64), 0, current_stream(),
-                       (const uint32_t*)d_src, n, arity, d_out, out_stride, d_sizes, d_tables);
+                       (const uint32_t*)d_src, n, arity, d_out, out_stride, d_sizes, d_tables, e1, e2);
   else
     hipLaunchKernelGGL(k_fpc_encode_serial<64>, dim3(arity), dim3(64), 0, current_stream(),
-                       (const uint64_t*)d_src, n, arity, d_out, out_stride, d_sizes, d_tables);
+                       (const uint64_t*)d_src, n, arity, d_out, out_stride, d_sizes, d_tables, e1, e2);
   return hip_ok(hipGetLastError(), "k_fpc_encode_serial") ? 1 : 0;
   }
 

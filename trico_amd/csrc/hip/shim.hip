@@ -331,6 +331,12 @@ int trico_hip_copy(void* dst, const void* src, size_t bytes)
 
 int trico_hip_fpc_encode(trico_hip_ctx* ctx, const void* src, uint32_t n, int arity, int width, uint32_t sizes[3])
   {
+  return trico_hip_fpc_encode_ex(ctx, src, n, arity, width, width == 4 ? 4u : 20u, width == 4 ? 10u : 20u, sizes);
+  }
+
+int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int arity, int width, uint32_t e1, uint32_t e2,
+                            uint32_t sizes[3])
+  {
   if (!ctx || !device_ready())
     return 0;
   if (arity < 1 || arity > 3 || (width != 4 && width != 8) || (n != 0 && !src))
@@ -338,6 +344,13 @@ int trico_hip_fpc_encode(trico_hip_ctx* ctx, const void* src, uint32_t n, int ar
     set_error("trico_hip_fpc_encode: bad arguments");
     return 0;
     }
+  const uint32_t emax1 = width == 4 ? 4u : 20u, emax2 = width == 4 ? 10u : 20u;
+  if (e1 == 0 || e2 == 0 || (e1 & 1u) || (e2 & 1u) || e1 > emax1 || e2 > emax2)
+    {
+    set_error("trico_hip_fpc_encode: table exponents must be even, 2..4 / 2..10 (float) or 2..20 (double)");
+    return 0;
+    }
+  const bool defaults = e1 == emax1 && e2 == emax2;
   const size_t in_bytes = (size_t)n * arity * width;
   const size_t stride = align_up(fpc_bound(n, width), 256);
   if (!ctx->in.reserve(in_bytes + 16) || !ctx->out.reserve(stride * arity))
@@ -361,7 +374,7 @@ int trico_hip_fpc_encode(trico_hip_ctx* ctx, const void* src, uint32_t n, int ar
     TRICO_HIP_TRY(hipMemsetAsync(ctx->tmp.p, 0, tb, current_stream()));
     d_tables = (uint64_t*)ctx->tmp.p;
     }
-  if (width == 4 && !force_serial_stage(1))
+  if (width == 4 && defaults && !force_serial_stage(1))
     {
     const size_t ws = fpc32_encode_workspace(n, arity);
     if (!ctx->tmp.reserve(ws))
@@ -374,12 +387,12 @@ int trico_hip_fpc_encode(trico_hip_ctx* ctx, const void* src, uint32_t n, int ar
     for (int c = 0; c < 3; ++c)
       ctx->out_materialized[c] = false;
     }
-  else if (width == 8 && !force_serial_stage(1))
+  else if (width == 8 && defaults && !force_serial_stage(1))
     {
     if (!launch_fpc64_encode(d_src, n, arity, ctx->out.p, stride, d_sizes, d_tables))
       return 0;
     }
-  else if (!launch_fpc_encode_serial(d_src, n, arity, width, ctx->out.p, stride, d_sizes, d_tables))
+  else if (!launch_fpc_encode_serial(d_src, n, arity, width, ctx->out.p, stride, d_sizes, d_tables, e1, e2))
     return 0;
   }
   if (!read_back_words(ctx, d_sizes, arity, ctx->out_sizes))
@@ -698,6 +711,60 @@ int trico_hip_decode_finish(trico_hip_ctx* ctx, void* dst)
     }
   g_stream = user;
   return ok;
+  }
+
+// ---- stand-alone transposes (the reference's transpose_aos_to_soa.h) ------------------------------
+// The coders above fuse the transposes; these exist for callers of the reference's low-level API.
+
+int trico_hip_split_components(trico_hip_ctx* ctx, const void* aos, uint32_t n, int arity, int width, void* const* comps)
+  {
+  if (!ctx || !device_ready() || arity < 1 || arity > 8 || (width != 1 && width != 4 && width != 8) || (n && !aos))
+    return 0;
+  // width 1: `arity` byte planes of n arity-byte integers; width 4 / 8: components of interleaved reals
+  const size_t elem = width == 1 ? (size_t)arity : (size_t)arity * width;
+  const size_t comp_bytes = (size_t)n * (width == 1 ? 1 : width);
+  const size_t stride = align_up(comp_bytes + 16, 256);
+  if (!ctx->in.reserve((size_t)n * elem + 16) || !ctx->tmp.reserve(stride * arity))
+    return 0;
+  if (n == 0)
+    return 1;
+  const void* d_src = stage_in(ctx->in, aos, (size_t)n * elem);
+  if (!d_src)
+    return 0;
+  const int ok = width == 1 ? launch_planes_split(d_src, n, arity, ctx->tmp.p, stride)
+                            : launch_deinterleave(d_src, n, arity, width, ctx->tmp.p, stride);
+  if (!ok)
+    return 0;
+  for (int c = 0; c < arity; ++c)
+    TRICO_HIP_TRY(hipMemcpyAsync(comps[c], ctx->tmp.p + (size_t)c * stride, comp_bytes, hipMemcpyDefault, current_stream()));
+  TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
+  return 1;
+  }
+
+int trico_hip_merge_components(trico_hip_ctx* ctx, const void* const* comps, uint32_t n, int arity, int width, void* aos)
+  {
+  if (!ctx || !device_ready() || arity < 1 || arity > 8 || (width != 1 && width != 4 && width != 8) || (n && !aos))
+    return 0;
+  const size_t elem = width == 1 ? (size_t)arity : (size_t)arity * width;
+  const size_t comp_bytes = (size_t)n * (width == 1 ? 1 : width);
+  const size_t stride = align_up(comp_bytes + 16, 256);
+  if (!ctx->tmp.reserve(stride * arity) || !ctx->out.reserve((size_t)n * elem + 16))
+    return 0;
+  ctx->out_count = 0;
+  if (n == 0)
+    return 1;
+  for (int c = 0; c < arity; ++c)
+    TRICO_HIP_TRY(hipMemcpyAsync(ctx->tmp.p + (size_t)c * stride, comps[c], comp_bytes, hipMemcpyDefault, current_stream()));
+  const bool dst_dev = trico_hip_pointer_is_device(aos) != 0;
+  void* d_dst = dst_dev ? aos : (void*)ctx->out.p;
+  const int ok = width == 1 ? launch_planes_merge(ctx->tmp.p, stride, n, arity, d_dst)
+                            : launch_interleave(ctx->tmp.p, stride, n, arity, width, d_dst);
+  if (!ok)
+    return 0;
+  if (!dst_dev)
+    TRICO_HIP_TRY(hipMemcpyAsync(aos, d_dst, (size_t)n * elem, hipMemcpyDeviceToHost, current_stream()));
+  TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
+  return 1;
   }
 
 // float payloads of the throughput encoder live in segment slots: gather component c into ctx->out
