@@ -1,0 +1,65 @@
+"""BASELINE config 5 on one GPU: K .trc archives (config-2 meshes, different seeds) decoded concurrently, one host
+thread per archive (ctypes releases the GIL; every archive handle owns its contexts and HIP streams).
+Prints aggregate decode throughput (decoded bytes / wall time) for K = 1, 2, 4, 8.
+
+    python tools/bench_concurrent_decode.py [W H]"""
+import json
+import os
+import sys
+import threading
+import time
+
+# ROCm maps HIP streams onto 4 hardware queues by default; kernels that share a queue run one after the other, and a
+# float decode occupies its queue for seconds.  libtrico asks for 16 when it makes the first HIP call of a process;
+# here torch may get there first, so it is set explicitly (before the HIP runtime initialises).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from trico_amd import api, meshgen
+
+W, H = (10000, 5000) if len(sys.argv) < 3 else (int(sys.argv[1]), int(sys.argv[2]))
+KMAX = 8
+L = api.lib()
+dev = torch.device("cuda", 0)
+nv, nt = W * H, 2 * W * H
+
+archives, raws = [], []
+for k in range(KMAX):
+    v, t = meshgen.grid(W, H, meshgen.GRID_SEED + k)
+    d_v, d_t = torch.from_numpy(v).to(dev), torch.from_numpy(t.view(np.int32)).to(dev)
+    a = api.Archive.open_for_writing((v.nbytes + t.nbytes) // 4, device=True)
+    assert a.write("vertices", d_v, nv) == 1 and a.write("triangles", d_t, nt) == 1
+    archives.append(a)
+    raws.append((d_v, d_t))
+    print("encoded archive", k, a.get_size(), "bytes", flush=True)
+outs = [(torch.empty_like(r[0]), torch.empty_like(r[1])) for r in raws]
+raw_bytes = nv * 12 + nt * 12
+
+
+def decode(k, errs):
+    r = api.Archive.open_for_reading(archives[k].get_buffer_pointer(), archives[k].get_size())
+    ok = r.read("vertices", outs[k][0]) == 1 and r.read("triangles", outs[k][1]) == 1
+    r.close()
+    if not ok:
+        errs.append(k)
+
+
+results = []
+for K in (1, 2, 4, 8):
+    errs = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=decode, args=(k, errs)) for k in range(K)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert not errs, errs
+    for k in range(K):
+        assert torch.equal(outs[k][0].view(torch.int32), raws[k][0].view(torch.int32)) and torch.equal(outs[k][1], raws[k][1])
+    results.append({"archives": K, "seconds": round(dt, 3), "decode_GBps": round(K * raw_bytes / dt / 1e9, 3)})
+    print(json.dumps(results[-1]), flush=True)
+print(json.dumps({"workload": "grid(%d,%d) archives, decode only, one GPU" % (W, H), "results": results}))

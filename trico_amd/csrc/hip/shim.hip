@@ -165,6 +165,10 @@ static bool device_ready()
   {
   if (g_device_state == 0)
     {
+    // ROCm multiplexes HIP streams onto 4 hardware queues by default, and kernels sharing a queue run one after the
+    // other.  The decoders run one long kernel per stream of an archive (read-ahead) and per archive, so more
+    // queues are asked for — effective when this is the first HIP call of the process, never overriding the user.
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
       {
