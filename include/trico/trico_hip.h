@@ -86,6 +86,9 @@ TRICO_API int trico_hip_decode_finish(trico_hip_ctx* ctx, void* dst);
 
 /* copy payload `c` of the last encode on this context to dst (host or device) */
 TRICO_API int trico_hip_fetch_payload(trico_hip_ctx* ctx, int c, void* dst);
+/* all `count` payloads of the last encode, payload c to dsts[c]; float payloads going to device memory take one
+ * fused gather launch (what the archive writers use) */
+TRICO_API int trico_hip_fetch_payloads(trico_hip_ctx* ctx, int count, void* const* dsts);
 /* device address of payload `c` of the last encode (valid until the next encode on ctx) */
 TRICO_API const uint8_t* trico_hip_payload_device_pointer(trico_hip_ctx* ctx, int c);
 

@@ -20,6 +20,7 @@ int trico_hip_fpc_decode(trico_hip_ctx* c, const uint8_t* const p[3], const uint
 int trico_hip_int_encode(trico_hip_ctx* c, const void* s, uint32_t n, int w, uint32_t z[8]) { (void)c; (void)s; (void)n; (void)w; (void)z; return 0; }
 int trico_hip_int_decode(trico_hip_ctx* c, const uint8_t* const p[8], const uint32_t z[8], int w, uint32_t n, void* d) { (void)c; (void)p; (void)z; (void)w; (void)n; (void)d; return 0; }
 int trico_hip_fetch_payload(trico_hip_ctx* c, int i, void* d) { (void)c; (void)i; (void)d; return 0; }
+int trico_hip_fetch_payloads(trico_hip_ctx* c, int n, void* const* d) { (void)c; (void)n; (void)d; return 0; }
 int trico_hip_decode_begin(trico_hip_ctx* c, int k, const uint8_t* const* p, const uint32_t* z, int a, int w, uint32_t n) { (void)c; (void)k; (void)p; (void)z; (void)a; (void)w; (void)n; return 0; }
 int trico_hip_decode_finish(trico_hip_ctx* c, void* d) { (void)c; (void)d; return 0; }
 

@@ -54,7 +54,7 @@ HIP_SYMBOLS = [
     "trico_hip_available", "trico_hip_last_error", "trico_hip_ctx_create", "trico_hip_ctx_destroy",
     "trico_hip_set_stream", "trico_hip_synchronize", "trico_hip_pointer_is_device", "trico_hip_device_alloc",
     "trico_hip_device_free", "trico_hip_copy", "trico_hip_fpc_encode", "trico_hip_fpc_decode",
-    "trico_hip_int_encode", "trico_hip_int_decode", "trico_hip_fetch_payload", "trico_hip_payload_device_pointer",
+    "trico_hip_int_encode", "trico_hip_int_decode", "trico_hip_fetch_payload", "trico_hip_fetch_payloads", "trico_hip_payload_device_pointer",
     "trico_hip_open_archive_for_writing_device", "trico_hip_profile_enable", "trico_hip_profile_reset",
     "trico_hip_profile_ms", "trico_hip_last_stats",
 ]

@@ -95,6 +95,7 @@ size_t fpc32_encode_workspace(uint32_t n, int arity);
 int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
                         uint8_t* d_ws, size_t ws_bytes);
 int launch_fpc32_gather(uint32_t n, int arity, int c, const uint8_t* d_ws, uint8_t* d_dst);
+int launch_fpc32_gather_all(uint32_t n, int arity, const uint8_t* d_ws, uint8_t* const d_dst[3]);
 bool force_serial();              // TRICO_HIP_SERIAL: see shim.hip
 bool force_serial_stage(int bit);
 

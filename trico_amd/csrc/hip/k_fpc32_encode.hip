@@ -602,14 +602,16 @@ __global__ void __launch_bounds__(1024) k_fpc32_offsets(const uint32_t* __restri
 // ---- gather: segment slots -> contiguous payload -------------------------------------------------------
 // grid (S, arity); each workgroup moves one segment.  The destination is written as aligned 16-byte vectors;
 // the source (a 256-byte aligned slot) is read as 4 + 1 dwords per vector and re-aligned with v_alignbyte.
+struct GatherDst { uint8_t* p[3]; };             // destination of every component (grid.y)
+
 __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap, uint32_t S,
                                                       const uint32_t* __restrict__ segbytes, const uint32_t* __restrict__ segoff,
-                                                      uint8_t* __restrict__ out, size_t out_stride)
+                                                      GatherDst dst)
   {
   const uint32_t g = blockIdx.x, c = blockIdx.y;
   const uint32_t len = segbytes[(size_t)c * S + g];
   const uint8_t* s = slots + (size_t)c * slot_stride + (size_t)g * segcap;       // 256-byte aligned, segcap has 280 bytes of slack
-  uint8_t* d = out + (size_t)c * out_stride + segoff[(size_t)c * S + g];
+  uint8_t* d = dst.p[c] + segoff[(size_t)c * S + g];
   const uint32_t head = (uint32_t)((16u - ((uintptr_t)d & 15u)) & 15u);           // bytes until d is 16-byte aligned
   const uint32_t h = head < len ? head : len;
   if (threadIdx.x < h)
@@ -734,8 +736,23 @@ int launch_fpc32_gather(uint32_t n, int arity, int c, const uint8_t* d_ws, uint8
   const uint32_t* segbytes = (const uint32_t*)(d_ws + p.off_segbytes);
   const uint32_t* segoff = (const uint32_t*)(d_ws + p.off_segoff);
   const uint8_t* slots = d_ws + p.off_slots;
+  GatherDst dst = { { d_dst, nullptr, nullptr } };
   hipLaunchKernelGGL(k_fpc32_gather, dim3(p.S, 1), dim3(256), 0, current_stream(), slots + (size_t)c * p.slot_stride, (size_t)0,
-                     p.segcap, p.S, segbytes + (size_t)c * p.S, segoff + (size_t)c * p.S, d_dst, (size_t)0);
+                     p.segcap, p.S, segbytes + (size_t)c * p.S, segoff + (size_t)c * p.S, dst);
+  return hip_ok(hipGetLastError(), "k_fpc32_gather") ? 1 : 0;
+  }
+
+// All components in one launch, each to its own destination (the archive writer knows all of them up front).
+int launch_fpc32_gather_all(uint32_t n, int arity, const uint8_t* d_ws, uint8_t* const d_dst[3])
+  {
+  if (n == 0)
+    return 1;
+  const Plan p = make_plan(n, arity);
+  const uint32_t* segbytes = (const uint32_t*)(d_ws + p.off_segbytes);
+  const uint32_t* segoff = (const uint32_t*)(d_ws + p.off_segoff);
+  GatherDst dst = { { d_dst[0], arity > 1 ? d_dst[1] : nullptr, arity > 2 ? d_dst[2] : nullptr } };
+  hipLaunchKernelGGL(k_fpc32_gather, dim3(p.S, arity), dim3(256), 0, current_stream(), d_ws + p.off_slots, p.slot_stride,
+                     p.segcap, p.S, segbytes, segoff, dst);
   return hip_ok(hipGetLastError(), "k_fpc32_gather") ? 1 : 0;
   }
 

@@ -803,6 +803,29 @@ int trico_hip_fetch_payload(trico_hip_ctx* ctx, int c, void* dst)
   return trico_hip_copy(dst, ctx->out.p + (size_t)c * ctx->out_stride, ctx->out_sizes[c]);
   }
 
+int trico_hip_fetch_payloads(trico_hip_ctx* ctx, int count, void* const* dsts)
+  {
+  if (!ctx || count != ctx->out_count || count < 1 || count > 8)
+    {
+    set_error("trico_hip_fetch_payloads: payload count mismatch");
+    return 0;
+    }
+  bool fused = ctx->out_in_slots && count <= 3;
+  for (int c = 0; c < count && fused; ++c)
+    fused = !ctx->out_materialized[c] && trico_hip_pointer_is_device(dsts[c]);
+  if (fused)
+    {
+    // float payloads still in their segment slots, device destinations: one gather launch for all components
+    uint8_t* d[3] = { (uint8_t*)dsts[0], count > 1 ? (uint8_t*)dsts[1] : nullptr, count > 2 ? (uint8_t*)dsts[2] : nullptr };
+    ProfSpan span(TRICO_HIP_K_FPC32_ENCODE, false);
+    return launch_fpc32_gather_all(ctx->slots_n, ctx->slots_arity, ctx->tmp.p, d);
+    }
+  for (int c = 0; c < count; ++c)
+    if (!trico_hip_fetch_payload(ctx, c, dsts[c]))
+      return 0;
+  return 1;
+  }
+
 const uint8_t* trico_hip_payload_device_pointer(trico_hip_ctx* ctx, int c)
   {
   if (!ctx || c < 0 || c >= ctx->out_count)

@@ -292,16 +292,24 @@ static int append_stream(struct trico_archive* a, enum trico_stream_type st, uin
     a->used = rollback;
     return 0;
     }
+  /* size fields first, then all payloads at once (one gather launch for float streams in a device buffer) */
+  void* dsts[8];
   for (int c = 0; c < ncomp; ++c)
     {
     uint8_t nb[4];
     store_le32(nb, sizes[c]);
-    if (!put_host(a, nb, 4) || !trico_hip_fetch_payload(a->ctx, c, a->buffer + a->used))
+    if (!put_host(a, nb, 4))
       {
       a->used = rollback;
       return 0;
       }
+    dsts[c] = a->buffer + a->used;
     a->used += sizes[c];
+    }
+  if (!trico_hip_fetch_payloads(a->ctx, ncomp, dsts))
+    {
+    a->used = rollback;
+    return 0;
     }
   return 1;
   }
