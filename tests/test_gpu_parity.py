@@ -378,3 +378,34 @@ def test_mutated_archives_never_crash(api, gold_dir):
                         break
             r.close()
     assert reads > 0 and fails > 0
+
+
+def test_concurrent_archives_from_threads(api, gold_dir):
+    """one handle per thread (SURVEY 8(b) threading rule): encode + decode of different meshes at the same time"""
+    import threading
+    want = {k: open(os.path.join(gold_dir, "%s_16x8.trc" % k), "rb").read() for k in ("grid", "walk", "multi")}
+    big = mesh_streams("walk", 300, 200)
+    big_want = oracle_archive(big)
+    errors = []
+
+    def work(i):
+        try:
+            for rep in range(6):
+                kind = ("grid", "walk", "multi")[(i + rep) % 3]
+                streams = mesh_streams(kind, 16, 8)
+                if write_archive(api, streams) != want[kind]:
+                    errors.append((i, rep, kind, "encode"))
+                read_back(api, want[kind], streams)
+                if rep % 3 == 0:
+                    if write_archive(api, big, device=(i % 2 == 0)) != big_want:
+                        errors.append((i, rep, "big", "encode"))
+                    read_back(api, big_want, big)
+        except Exception as e:          # noqa: BLE001 - collected and asserted below
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
