@@ -409,3 +409,38 @@ def test_concurrent_archives_from_threads(api, gold_dir):
     for t in threads:
         t.join()
     assert not errors, errors[:5]
+
+
+@pytest.mark.parametrize("kind", ["alphabet2", "alphabet4", "period_noise", "runs", "markov"])
+@pytest.mark.parametrize("n", [70001, 1500000])
+def test_lz4_short_sequence_regimes(api, kind, n):
+    """byte streams that compress into very many short sequences with small offsets and overlapping matches: the
+    regime of the batch-parsed LZ4 decoder path (k_lz4_decode.hip) and of the chunked compressor's stitch"""
+    rng = np.random.default_rng(len(kind) * 1000 + n % 997)
+    if kind == "alphabet2":
+        data = rng.integers(0, 2, n, dtype=np.uint8) * 37
+    elif kind == "alphabet4":
+        data = rng.integers(0, 4, n, dtype=np.uint8)
+    elif kind == "period_noise":
+        p = np.tile(np.array([1, 2, 3, 1, 2, 7, 9], np.uint8), n // 7 + 1)[:n].copy()
+        hit = rng.random(n) < 0.03
+        p[hit] = rng.integers(0, 256, int(hit.sum()), dtype=np.uint8)
+        data = p
+    elif kind == "runs":
+        lens = rng.integers(1, 40, n // 8 + 8)
+        vals = rng.integers(0, 256, lens.size, dtype=np.uint8)
+        data = np.repeat(vals, lens)[:n].astype(np.uint8)
+    else:
+        steps = rng.integers(-1, 2, n)
+        data = (np.cumsum(steps) & 15).astype(np.uint8)
+    data = np.ascontiguousarray(data)
+    a = api.Archive.open_for_writing(1 << 16)
+    assert a.write("attributes_uint8", data, n) == 1, api.last_error()
+    got = a.tobytes()
+    a.close()
+    assert got == oracle_archive([("attributes_uint8", data, n)])
+    r = api.Archive.open_for_reading(got)
+    back = np.empty_like(data)
+    assert r.read("attributes_uint8", back) == 1, api.last_error()
+    r.close()
+    assert back.tobytes() == data.tobytes()
