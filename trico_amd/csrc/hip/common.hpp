@@ -108,6 +108,12 @@ int launch_fpc64_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
 int launch_fpc64_decode(const uint8_t* const d_payloads[3], const uint32_t sizes[3], int arity, uint32_t n, void* d_dst,
                         uint64_t* d_tables, uint32_t* d_status);
 
+// sort-based throughput encoder for doubles (k_fpc64_sort.hip): table lookups as stable sorts by hash
+uint32_t fpc64_sorted_threshold();
+size_t fpc64_sorted_workspace(uint32_t n);
+int launch_fpc64_encode_sorted(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
+                               uint8_t* d_ws, size_t ws_bytes);
+
 // workgroup-per-plane LZ4 compressor for small planes (k_lz4.hip)
 int launch_lz4_encode_wave(const uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, int nplanes, uint8_t* d_out,
                            size_t out_stride, uint32_t* d_sizes);

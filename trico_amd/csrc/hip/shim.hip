@@ -369,7 +369,8 @@ int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int
   {
   ProfSpan span(width == 4 ? TRICO_HIP_K_FPC32_ENCODE : TRICO_HIP_K_FPC64_ENCODE);
   uint64_t* d_tables = nullptr;
-  if (width == 8)
+  const bool sorted64 = width == 8 && defaults && !force_serial_stage(1) && n >= fpc64_sorted_threshold() && n <= 0x7fffffffu;
+  if (width == 8 && !sorted64)
     {
     // two 2^20-entry u64 tables per component (fpsc.c:592-593), zeroed per call
     const size_t tb = (size_t)arity * 2 * ((size_t)1 << 20) * 8;
@@ -390,6 +391,15 @@ int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int
     ctx->slots_arity = arity;
     for (int c = 0; c < 3; ++c)
       ctx->out_materialized[c] = false;
+    }
+  else if (sorted64)
+    {
+    // large streams: the table lookups become sorts (k_fpc64_sort.hip); the tables themselves are not needed
+    const size_t ws = fpc64_sorted_workspace(n);
+    if (!ctx->ws.reserve(ws))
+      return 0;
+    if (!launch_fpc64_encode_sorted(d_src, n, arity, ctx->out.p, stride, d_sizes, ctx->ws.p, ctx->ws.cap))
+      return 0;
     }
   else if (width == 8 && defaults && !force_serial_stage(1))
     {
