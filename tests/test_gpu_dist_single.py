@@ -39,6 +39,10 @@ print("OK", size)
 
 
 def test_nccl_world1_gather(tmp_path):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    import socket
+    with socket.socket() as sk:                 # a port that is free right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r = subprocess.run([sys.executable, "-c", WORKER % ROOT], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
