@@ -86,6 +86,13 @@ TRICO_API int trico_hip_decode_finish(trico_hip_ctx* ctx, void* dst);
 
 /* copy payload `c` of the last encode on this context to dst (host or device) */
 TRICO_API int trico_hip_fetch_payload(trico_hip_ctx* ctx, int c, void* dst);
+/* Vertex welding for the binary STL reader (trico_io/iostl.c:69-134): `corners` holds 3 * ntri positions (xyz floats, host
+ * or device).  1: `vertices` (capacity 3 * ntri positions) receives the *nr_of_vertices unique positions in (x, y, z)
+ * order and `triangles` the 3 * ntri re-indexed corners; 2: the input contains -0.0 or NaN, where the reference's result
+ * depends on its quicksort's tie order — nothing was written, weld on the host; 0: error. */
+TRICO_API int trico_hip_weld_vertices(trico_hip_ctx* ctx, const float* corners, uint32_t ntri, float* vertices, uint32_t* triangles,
+                                      uint32_t* nr_of_vertices);
+
 /* all `count` payloads of the last encode, payload c to dsts[c]; float payloads going to device memory take one
  * fused gather launch (what the archive writers use) */
 TRICO_API int trico_hip_fetch_payloads(trico_hip_ctx* ctx, int count, void* const* dsts);

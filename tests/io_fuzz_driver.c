@@ -3,6 +3,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+/* test-only stand-ins for the device entry points the STL reader may call: "no device" */
+struct trico_hip_ctx;
+int trico_hip_available(void) { return 0; }
+struct trico_hip_ctx* trico_hip_ctx_create(void) { return NULL; }
+void trico_hip_ctx_destroy(struct trico_hip_ctx* c) { (void)c; }
+int trico_hip_weld_vertices(struct trico_hip_ctx* c, const float* a, uint32_t n, float* v, uint32_t* t, uint32_t* nv) { (void)c; (void)a; (void)n; (void)v; (void)t; (void)nv; return 0; }
 int main(int argc, char** argv)
   {
   for (int i = 2; i < argc; ++i)   /* argv[1]: scratch output file */

@@ -74,9 +74,10 @@ def build(force=False, verbose=True):
     # STL / PLY readers and the two command line tools around the path
     io_src = [os.path.join(CSRC, "io", f) for f in ("iostl.c", "ioply.c")]
     io_hdr = [os.path.join(INCLUDE, "trico_io", h) for h in ("iostl.h", "ioply.h", "trico_io_api.h")]
-    if force or _stale(LIBIO, io_src + io_hdr):
+    if force or _stale(LIBIO, io_src + io_hdr + [LIBTRICO]):
+        # links libtrico.so: the STL reader hands big welds to the device (trico_hip_weld_vertices)
         _run([CC, "-O2", "-std=c11", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wextra", "-shared",
-              "-I" + INCLUDE] + io_src + ["-o", LIBIO])
+              "-I" + INCLUDE] + io_src + ["-o", LIBIO, "-L" + LIBDIR, "-ltrico", "-Wl,-rpath,$ORIGIN"])
     os.makedirs(BINDIR, exist_ok=True)
     for tool in TOOLS:
         src = os.path.join(CSRC, "tools", tool + ".c")

@@ -114,6 +114,10 @@ size_t fpc64_sorted_workspace(uint32_t n);
 int launch_fpc64_encode_sorted(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
                                uint8_t* d_ws, size_t ws_bytes);
 
+// vertex welding for the STL reader (k_weld.hip): sort + unique of corner positions
+size_t weld_workspace(uint32_t n);
+int launch_weld(const uint32_t* d_pos, uint32_t n, uint32_t* d_out_pos, uint32_t* d_out_tri, uint8_t* d_ws, size_t ws_bytes, uint32_t* d_result);
+
 // workgroup-per-plane LZ4 compressor for small planes (k_lz4.hip)
 int launch_lz4_encode_wave(const uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, int nplanes, uint8_t* d_out,
                            size_t out_stride, uint32_t* d_sizes);

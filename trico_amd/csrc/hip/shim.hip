@@ -781,6 +781,42 @@ int trico_hip_merge_components(trico_hip_ctx* ctx, const void* const* comps, uin
   return 1;
   }
 
+// ---- vertex welding for the STL reader ---------------------------------------------------------------
+// corners: 3 * ntri positions (xyz floats, host or device).  On success returns 1: *nr_of_vertices unique positions in
+// vertices (capacity 3 * ntri positions) in lexicographic order and 3 * ntri indices in triangles.  Returns 2 when the
+// input holds -0.0 or NaN (the tie rule of the reference's quicksort then matters; the caller welds on the host), 0 on
+// error.
+int trico_hip_weld_vertices(trico_hip_ctx* ctx, const float* corners, uint32_t ntri, float* vertices, uint32_t* triangles,
+                            uint32_t* nr_of_vertices)
+  {
+  if (!ctx || !device_ready() || !corners || !vertices || !triangles || !nr_of_vertices || ntri == 0 || ntri > 0x2aaaaaaau)
+    return 0;
+  const uint32_t n = 3u * ntri;
+  const size_t pos_bytes = (size_t)n * 12;
+  const size_t ws = weld_workspace(n);
+  if (!ctx->in.reserve(pos_bytes + 16) || !ctx->out.reserve(pos_bytes + (size_t)n * 4 + 512) || !ctx->ws.reserve(ws))
+    return 0;
+  ctx->out_count = 0;
+  const void* d_pos = stage_in(ctx->in, corners, pos_bytes);
+  if (!d_pos)
+    return 0;
+  uint32_t* d_out_pos = (uint32_t*)ctx->out.p;
+  uint32_t* d_out_tri = (uint32_t*)(ctx->out.p + align_up(pos_bytes, 256));
+  uint32_t* d_result = (uint32_t*)ctx->aux.p;
+  if (!launch_weld((const uint32_t*)d_pos, n, d_out_pos, d_out_tri, ctx->ws.p, ctx->ws.cap, d_result))
+    return 0;
+  uint32_t res[2] = { 0, 0 };
+  if (!read_back_words(ctx, d_result, 2, res))
+    return 0;
+  if (res[1] != 0)
+    return 2;
+  *nr_of_vertices = res[0];
+  TRICO_HIP_TRY(hipMemcpyAsync(vertices, d_out_pos, (size_t)res[0] * 12, hipMemcpyDefault, current_stream()));
+  TRICO_HIP_TRY(hipMemcpyAsync(triangles, d_out_tri, (size_t)n * 4, hipMemcpyDefault, current_stream()));
+  TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
+  return 1;
+  }
+
 // float payloads of the throughput encoder live in segment slots: gather component c into ctx->out
 static int materialize(trico_hip_ctx* ctx, int c)
   {

@@ -12,6 +12,7 @@
  * scheme is used here; only the bookkeeping differs (whole-file read, explicit stack instead of recursion
  * on the larger side, records as structs). */
 #include "trico_io/iostl.h"
+#include "trico/trico_hip.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -138,6 +139,30 @@ static int weld(uint32_t ntri, float* vertices, uint32_t* triangles, uint32_t* n
   return 1;
   }
 
+/* Large files: sort + unique on the MI355X (k_weld.hip).  Declines (0) when there is no device, the mesh is small, or
+ * the positions contain -0.0 / NaN, where the outcome depends on the tie order of the reference's quicksort that weld()
+ * above reproduces.  corners: 9 floats per triangle, rewritten in place like weld(). */
+static int weld_on_device(uint32_t ntri, float* vertices, uint32_t* triangles, uint32_t* nr_of_vertices)
+  {
+  const char* e = getenv("TRICO_IO_WELD_GPU_MIN");
+  const unsigned long min_tri = e ? strtoul(e, NULL, 10) : 50000ul;
+  if (ntri < min_tri || !trico_hip_available())
+    return 0;
+  trico_hip_ctx* ctx = trico_hip_ctx_create();
+  if (!ctx)
+    return 0;
+  float* uniq = (float*)malloc((size_t)ntri * 9 * sizeof(float) + 1);
+  int done = 0;
+  if (uniq && trico_hip_weld_vertices(ctx, vertices, ntri, uniq, triangles, nr_of_vertices) == 1)
+    {
+    memcpy(vertices, uniq, (size_t)*nr_of_vertices * 3 * sizeof(float));
+    done = 1;
+    }
+  free(uniq);
+  trico_hip_ctx_destroy(ctx);
+  return done;
+  }
+
 static int read_impl(uint32_t* nr_of_vertices, float** vertices, uint32_t* nr_of_triangles, uint32_t** triangles,
                      float** normals, uint16_t** attributes, const char* filename)
   {
@@ -188,7 +213,7 @@ static int read_impl(uint32_t* nr_of_vertices, float** vertices, uint32_t* nr_of
       t[3 * i] = (uint32_t)(3 * i); t[3 * i + 1] = (uint32_t)(3 * i + 1); t[3 * i + 2] = (uint32_t)(3 * i + 2);
       }
     uint32_t nv = 3 * ntri;
-    ok = weld(ntri, v, t, &nv);
+    ok = weld_on_device(ntri, v, t, &nv) || weld(ntri, v, t, &nv);
     if (ok)
       {
       float* shrunk = (float*)realloc(v, (size_t)nv * 3 * sizeof(float) + 1);
