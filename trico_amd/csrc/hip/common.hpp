@@ -100,8 +100,10 @@ bool force_serial();              // TRICO_HIP_SERIAL: see shim.hip
 bool force_serial_stage(int bit);
 
 // latency-optimised float decoder (k_fpc32_decode.hip): one wave per component stream
+// d_tables: 8 KiB of scratch per component (the predictor tables, reached through the scalar data cache)
+constexpr size_t FPC32_DECODE_TABLE_BYTES = 8192;
 int launch_fpc32_decode(const uint8_t* const d_payloads[3], const uint32_t sizes[3], int arity, uint32_t n, void* d_dst,
-                        uint32_t* d_status);
+                        uint32_t* d_status, uint32_t* d_tables);
 
 // double-precision coder (k_fpc64.hip): one wave per component stream, 2 x 2^20-entry tables per stream in d_tables (zeroed)
 int launch_fpc64_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes, uint64_t* d_tables);

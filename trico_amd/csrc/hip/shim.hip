@@ -470,7 +470,9 @@ static int fpc_decode_launch(trico_hip_ctx* ctx, const uint8_t* const payloads[3
     }
   if (width == 4 && !force_serial_stage(2))
     {
-    if (!launch_fpc32_decode(d_pay, sizes, arity, n, d_dst, d_status))
+    if (!ctx->tmp.reserve(3 * FPC32_DECODE_TABLE_BYTES))
+      return 0;
+    if (!launch_fpc32_decode(d_pay, sizes, arity, n, d_dst, d_status, (uint32_t*)ctx->tmp.p))
       return 0;
     }
   else if (width == 8 && !force_serial_stage(2))
