@@ -502,61 +502,98 @@ template <int N, int ABL> struct Unroll3<N, N, ABL>
 // scalar load issued right after a scalar store to the same address is NOT reliably ordered behind it when the line
 // misses (smem2.hip under cache pressure; a parity test caught it too); every other store is complete before the
 // next value starts, because each value begins with s_waitcnt lgkmcnt(0).
+// v_readlane costs ~21 cycles in a scalar instruction stream (tools/ubench/chain4.hip), so the residuals do not come from
+// a VGPR: the parser wave puts them into global memory with scalar stores (same scalar cache, same CU) and the chain
+// loads eight at a time with s_load_dwordx8.  Fixed registers (clobbered by the statement):
+//   s[52:53] = {stride, value} of the previous value on even steps, s[54:55] on odd steps
+//   s[56:57] = {T1 entry of the current hash, 0}    s[58:59] = {cand, lm}: one s_cselect_b64 picks {stride, value} or {T1 entry, 0}
+//   s[60:67], s[68:75] residuals of the current / next eight values      s[84:99] the FCM table (s_movrels / s_movreld, M0 = hash)
 //   D: mask word of value K, DN: mask word of value K + 1
-#define CH4_STEP(K, D, DN, LAST, V, SP, S, AO, AN)                    \
+#define CH4_XLOAD(K) "s_load_dwordx8 s[60 + (((" #K ") + 8) & 15) : 67 + (((" #K ") + 8) & 15)], %[Xb], 4 * ((" #K ") + 8)\n"
+#define CH4_NOX(K) ""
+#define CH4_STEP(K, D, DN, PIN, PINV, POUTS, POUTV, AO, AN, XL)       \
   "s_bitcmp1_b32 %[" D "], (" #K ") & 31\n"                          \
-  "s_cselect_b32 %[lm], %[" LAST "], 0\n"                            \
-  "s_cselect_b32 %[cand], %[" SP "], %[t1]\n"                        \
+  "s_cselect_b64 s[58:59], " PIN ", s[56:57]\n"                      \
   "s_bitcmp1_b32 %[g], (" #K ") & 31\n"                              \
   "s_waitcnt lgkmcnt(0)\n"                                           \
-  "s_cselect_b32 %[q], %[t2], %[cand]\n"                             \
-  "s_add_u32 %[q], %[q], %[lm]\n"                                    \
-  "s_xor_b32 %[" V "], %[x], %[q]\n"                                 \
-  "s_sub_u32 %[" S "], %[" V "], %[" LAST "]\n"                      \
-  "s_and_b32 %[h], %[" S "], 0xffc00000\n"                           \
+  "s_cselect_b32 %[q], %[t2], s58\n"                                 \
+  "s_add_u32 %[q], %[q], s59\n"                                      \
+  "s_xor_b32 " POUTV ", s[60 + ((" #K ") & 15)], %[q]\n"             \
+  "s_sub_u32 " POUTS ", " POUTV ", " PINV "\n"                       \
+  "s_and_b32 %[h], " POUTS ", 0xffc00000\n"                          \
   "s_xor_b32 %[q], %[h], %[P]\n"                                     \
   "s_lshr_b32 %[" AN "], %[q], 20\n"                                 \
   "s_load_dword %[t2], %[T2b], %[" AN "]\n"                          \
-  "s_store_dword %[" S "], %[T2b], %[" AO "]\n"                      \
-  "s_movreld_b32 s84, %[" V "]\n"                                    \
-  "s_lshr_b32 m0, %[" V "], 28\n"                                    \
+  "s_store_dword " POUTS ", %[T2b], %[" AO "]\n"                     \
+  XL(K)                                                               \
+  "s_movreld_b32 s84, " POUTV "\n"                                   \
+  "s_lshr_b32 m0, " POUTV ", 28\n"                                   \
   "s_lshl_b32 %[P], %[h], 5\n"                                       \
-  "s_movrels_b32 %[t1], s84\n"                                       \
+  "s_movrels_b32 s56, s84\n"                                         \
   "s_cmp_lg_u32 %[" AN "], %[" AO "]\n"                              \
   "s_cselect_b32 %[g], %[" DN "], 0\n"                               \
-  "v_writelane_b32 %[outv], %[" V "], " #K "\n"                      \
-  "v_readlane_b32 %[x], %[vx], ((" #K ") + 1) & 63\n"
-#define CH4_PAIR(K0, K1, D, DN1) CH4_STEP(K0, D, D, "va", "vb", "sa", "sb", "a2a", "a2b") CH4_STEP(K1, D, DN1, "vb", "va", "sb", "sa", "a2b", "a2a")
-#define CH4_OCT(B, D, DN) CH4_PAIR(B + 0, B + 1, D, D) CH4_PAIR(B + 2, B + 3, D, D) CH4_PAIR(B + 4, B + 5, D, D) CH4_PAIR(B + 6, B + 7, D, DN)
-#define CH4_T1_IN(I) "v_readlane_b32 s" #I ", %[T1v], " #I " - 84\n"
-#define CH4_T1_OUT(I) "v_writelane_b32 %[T1v], s" #I ", " #I " - 84\n"
-#define CH4_T1_ALL(M) M(84) M(85) M(86) M(87) M(88) M(89) M(90) M(91) M(92) M(93) M(94) M(95) M(96) M(97) M(98) M(99)
+  "v_writelane_b32 %[outv], " POUTV ", " #K "\n"
+#define CH4_EVEN(K, D, DN, XL) CH4_STEP(K, D, DN, "s[52:53]", "s53", "s54", "s55", "a2a", "a2b", XL)
+#define CH4_ODD(K, D, DN, XL) CH4_STEP(K, D, DN, "s[54:55]", "s55", "s52", "s53", "a2b", "a2a", XL)
+#define CH4_OCT(B, D, DN, XL) CH4_EVEN(B + 0, D, D, XL) CH4_ODD(B + 1, D, D, CH4_NOX) CH4_EVEN(B + 2, D, D, CH4_NOX) CH4_ODD(B + 3, D, D, CH4_NOX) \
+                              CH4_EVEN(B + 4, D, D, CH4_NOX) CH4_ODD(B + 5, D, D, CH4_NOX) CH4_EVEN(B + 6, D, D, CH4_NOX) CH4_ODD(B + 7, D, DN, CH4_NOX)
 
-// wave-uniform chain state (SGPRs) + the FCM table parked in lanes 0..15 of a VGPR between batches
+// wave-uniform chain state (SGPRs); the FCM table is parked in the stream's scratch between batches
 struct Chain4 { uint32_t last, sprev, a2, P, t2, fwd; };
 
-// one batch of 64 values; T2b: the stream's DFCM table in global memory.  Returns the 64 values (lane K = value K).
-__device__ __forceinline__ uint32_t chain4_batch(Chain4& c, uint32_t& T1v, uint32_t vx, uint32_t dlo, uint32_t dhi, const uint32_t* T2b)
+// one batch of 64 values; T2b: the stream's scratch in global memory (DFCM table, then 64 B for the FCM table); Xb: the 64
+// residuals of the batch (written by the parser wave with scalar stores).  Returns the 64 values (lane K = value K).
+__device__ __forceinline__ uint32_t chain4_batch(Chain4& c, uint32_t dlo, uint32_t dhi, const uint32_t* T2b, const uint32_t* Xb)
   {
-  uint32_t outv = 0, vb, sb, a2b, lm, cand, q, h, x, t1, g;
+  uint32_t outv = 0, a2b, q, h, g;
   asm volatile(
-    CH4_T1_ALL(CH4_T1_IN)
-    "v_readlane_b32 %[x], %[vx], 0\n"
-    "s_lshr_b32 m0, %[va], 28\n"
+    "s_load_dwordx8 s[60:67], %[Xb], 0x0\n"
+    "s_load_dwordx4 s[84:87], %[T2b], 0x1000\n"
+    "s_load_dwordx4 s[88:91], %[T2b], 0x1010\n"
+    "s_load_dwordx4 s[92:95], %[T2b], 0x1020\n"
+    "s_load_dwordx4 s[96:99], %[T2b], 0x1030\n"
+    "s_mov_b32 s52, %[sprev]\n"
+    "s_mov_b32 s53, %[last]\n"
+    "s_mov_b32 s57, 0\n"
+    "s_lshr_b32 m0, %[last], 28\n"
     "s_cmp_eq_u32 %[fwd], 0\n"
     "s_cselect_b32 %[g], %[dlo], 0\n"
-    "s_movrels_b32 %[t1], s84\n"
-    CH4_OCT(0, "dlo", "dlo") CH4_OCT(8, "dlo", "dlo") CH4_OCT(16, "dlo", "dlo") CH4_OCT(24, "dlo", "dhi")
-    CH4_OCT(32, "dhi", "dhi") CH4_OCT(40, "dhi", "dhi") CH4_OCT(48, "dhi", "dhi") CH4_OCT(56, "dhi", "dhi")
-    "s_cselect_b32 %[fwd], 0, 1\n"                     /* SCC still says whether the last load address differed from the last store address */
     "s_waitcnt lgkmcnt(0)\n"
-    CH4_T1_ALL(CH4_T1_OUT)
-    : [va] "+s"(c.last), [vb] "=&s"(vb), [sa] "+s"(c.sprev), [sb] "=&s"(sb), [a2a] "+s"(c.a2), [a2b] "=&s"(a2b), [P] "+s"(c.P),
-      [t2] "+s"(c.t2), [fwd] "+s"(c.fwd), [T1v] "+v"(T1v), [outv] "+v"(outv), [lm] "=&s"(lm), [cand] "=&s"(cand), [q] "=&s"(q),
-      [h] "=&s"(h), [x] "=&s"(x), [t1] "=&s"(t1), [g] "=&s"(g)
-    : [T2b] "s"(T2b), [dlo] "s"(dlo), [dhi] "s"(dhi), [vx] "v"(vx)
-    : "scc", "memory", "m0", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+    "s_movrels_b32 s56, s84\n"
+    CH4_OCT(0, "dlo", "dlo", CH4_XLOAD) CH4_OCT(8, "dlo", "dlo", CH4_XLOAD) CH4_OCT(16, "dlo", "dlo", CH4_XLOAD) CH4_OCT(24, "dlo", "dhi", CH4_XLOAD)
+    CH4_OCT(32, "dhi", "dhi", CH4_XLOAD) CH4_OCT(40, "dhi", "dhi", CH4_XLOAD) CH4_OCT(48, "dhi", "dhi", CH4_XLOAD) CH4_OCT(56, "dhi", "dhi", CH4_NOX)
+    "s_cselect_b32 %[fwd], 0, 1\n"                     /* SCC still says whether the last load address differed from the last store address */
+    "s_mov_b32 %[sprev], s52\n"
+    "s_mov_b32 %[last], s53\n"
+    "s_store_dwordx4 s[84:87], %[T2b], 0x1000\n"
+    "s_store_dwordx4 s[88:91], %[T2b], 0x1010\n"
+    "s_store_dwordx4 s[92:95], %[T2b], 0x1020\n"
+    "s_store_dwordx4 s[96:99], %[T2b], 0x1030\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    : [last] "+s"(c.last), [sprev] "+s"(c.sprev), [a2a] "+s"(c.a2), [a2b] "=&s"(a2b), [P] "+s"(c.P), [t2] "+s"(c.t2), [fwd] "+s"(c.fwd),
+      [outv] "+v"(outv), [q] "=&s"(q), [h] "=&s"(h), [g] "=&s"(g)
+    : [T2b] "s"(T2b), [Xb] "s"(Xb), [dlo] "s"(dlo), [dhi] "s"(dhi)
+    : "scc", "memory", "m0", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
+      "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94",
+      "s95", "s96", "s97", "s98", "s99");
   return outv;
+  }
+
+// parser wave: the 64 residuals of a batch (lane K = residual K) go to `Xb` with scalar stores, through the scalar cache the chain reads
+__device__ __forceinline__ void chain4_put_residuals(uint32_t xr, const uint32_t* Xb)
+  {
+#define CH4_PUT4(J, R0, R1, R2, R3) \
+  "v_readlane_b32 s" #R0 ", %[xr], 4 * " #J "\n v_readlane_b32 s" #R1 ", %[xr], 4 * " #J " + 1\n" \
+  "v_readlane_b32 s" #R2 ", %[xr], 4 * " #J " + 2\n v_readlane_b32 s" #R3 ", %[xr], 4 * " #J " + 3\n" \
+  "s_nop 0\n s_store_dwordx4 s[" #R0 ":" #R3 "], %[Xb], 16 * " #J "\n"
+  asm volatile(
+    CH4_PUT4(0, 52, 53, 54, 55) CH4_PUT4(1, 56, 57, 58, 59) CH4_PUT4(2, 60, 61, 62, 63) CH4_PUT4(3, 64, 65, 66, 67)
+    CH4_PUT4(4, 52, 53, 54, 55) CH4_PUT4(5, 56, 57, 58, 59) CH4_PUT4(6, 60, 61, 62, 63) CH4_PUT4(7, 64, 65, 66, 67)
+    CH4_PUT4(8, 52, 53, 54, 55) CH4_PUT4(9, 56, 57, 58, 59) CH4_PUT4(10, 60, 61, 62, 63) CH4_PUT4(11, 64, 65, 66, 67)
+    CH4_PUT4(12, 52, 53, 54, 55) CH4_PUT4(13, 56, 57, 58, 59) CH4_PUT4(14, 60, 61, 62, 63) CH4_PUT4(15, 64, 65, 66, 67)
+    "s_waitcnt lgkmcnt(0)\n"
+    :: [xr] "v"(xr), [Xb] "s"(Xb)
+    : "memory", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67");
   }
 
 // reference-order loop of one lane over LDS tables: stream tails (< 64 values) and table exponents below the API's (4,10)
@@ -638,11 +675,11 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
   Chain3 c3 = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, true, (uint32_t)lane < 4u };
   const uint32_t L26 = (uint32_t)lane << 26;
   Chain4 c4 = { 0u, 0u, 0u, 0u, 0u, 1u };
-  uint32_t T1v = 0;                                      // v4: FCM table, entry h in lane h
-  const uint32_t* T2g = tables + 2048u * (uint32_t)comp;   // 8 KiB per stream: T2 (4 KiB), then T1 (64 B)
+  const uint32_t* T2g = tables + 2048u * (uint32_t)comp;   // 8 KiB per stream: T2 (4 KiB), T1 (64 B), at 4352: two slots of 64 residuals
+  const uint32_t* Xg = T2g + 1088;
   if (V == 4 && wave == 0 && nb)
     {
-    for (uint32_t off = 0; off < 4096u; off += 16u)
+    for (uint32_t off = 0; off < 4096u + 64u; off += 16u)
       asm volatile("s_mov_b64 s[40:41], 0\n s_mov_b64 s[42:43], 0\n s_store_dwordx4 s[40:43], %0, %1" :: "s"(T2g), "s"(off) : "s40", "s41", "s42", "s43", "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -705,7 +742,10 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
           const uint32_t xr = nbytes ? __builtin_bswap32(raw) >> (8u * (4u - nbytes)) : 0u;
           const uint64_t dfcm = __ballot(code > 4u);
           Slot2& sl = slot[t & 1u];
-          sl.xr[lane] = xr;
+          if (V == 4)
+            chain4_put_residuals(xr, Xg + 64u * (t & 1u));
+          else
+            sl.xr[lane] = xr;
           if (lane == 0)
             {
             sl.dlo = (uint32_t)dfcm;
@@ -724,7 +764,7 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
       const uint32_t dlo = rfl(sl.dlo), dhi = rfl(sl.dhi);
       uint32_t* ob = outb[(t - 1u) & 1u];
       if (V == 4)
-        ob[lane] = chain4_batch(c4, T1v, vx, dlo, dhi, T2g);
+        ob[lane] = chain4_batch(c4, dlo, dhi, T2g, Xg + 64u * ((t - 1u) & 1u));
       else if (V == 3)
         Unroll3<0, 64, ABL>::run(c3, vx, dlo, dhi, L26, (uint8_t*)T2, ob);
       else
@@ -761,7 +801,7 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
       for (int i = threadIdx.x; i < 1024; i += 128)
         T2[i] = __builtin_nontemporal_load(T2g + i);
       if (threadIdx.x < 16)
-        T1[threadIdx.x] = T1v;
+        T1[threadIdx.x] = __builtin_nontemporal_load(T2g + 1024 + threadIdx.x);
       }
     __syncthreads();
     }
