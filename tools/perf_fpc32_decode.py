@@ -29,15 +29,6 @@ for c in range(3):
     L.trico_hip_synchronize()
     t1 = time.perf_counter()
     ok = bool((out.view(torch.int32) == col.view(torch.int32)).all())
-    if hasattr(L, "trico_hip_debug_dec_prof") or True:
-        try:
-            pr = (ctypes.c_ulonglong * 16)()
-            L.trico_hip_debug_dec_prof(pr)
-            nbv = max(1, pr[6])
-            print("   prof: parser work %.0f wait %.0f | chain work %.0f wait %.0f cycles/batch | clock %.0f MHz" % (
-                pr[0] / nbv, pr[1] / nbv, pr[2] / nbv, pr[3] / nbv, pr[5] / max(1, pr[4]) * 100.0))
-        except Exception as e:
-            print("   (no prof: %s)" % e)
     print("comp %d payload %d B (%.2f B/value)  decode %.1f ms  %.1f ns/value  ok=%s" % (
         c, sizes[0], sizes[0] / n, (t1 - t0) * 1e3, (t1 - t0) * 1e9 / n, ok), flush=True)
 L.trico_hip_ctx_destroy(ctx)
