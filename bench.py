@@ -14,18 +14,56 @@ value = raw input bytes of all ranks / wall time of (encode + gather + decode), 
 roofline  = the float-vertex encoder (north_star's target kernel): algorithmic bytes (raw vertex bytes
             + their payload bytes) / average device time of its launch sequence, vs 8 TB/s HBM3E.
 cpu_baseline = the reference itself (oracle/_ref, built from /root/reference) when that library is
-            present, else the oracle port, 1 thread, on a bounded sample of the same generator.
+            present, else the oracle port, on the SAME mesh, on this box's host cores: 1 thread (the reference's
+            execution model) and one thread per independent stream; `nproc` states the cores of the box.
+other_mesh / pcie_inclusive / decode_concurrent: the same step on the walk mesh, through host pointers, and
+            BASELINE configs[4]'s shape on one GPU (N = 1 only, outside the timed region).
+`python bench.py --gpus N` starts its N ranks itself (torch.distributed.run, RCCL) when no launcher did.
 """
 import argparse
 import ctypes
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# ROCm maps HIP streams onto 4 hardware queues by default and kernels sharing a queue run one after the other; every stream of
+# an archive decodes on its own HIP stream, so the process asks for more BEFORE anything initialises HIP (torch gets there
+# before libtrico does, which only sets this when it makes the first HIP call itself).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def _spawn_ranks_if_needed():
+    """`python bench.py --gpus N` without a launcher: start N ranks (fresh processes, one per GPU, RCCL rendezvous on
+    127.0.0.1) through torch.distributed.run BEFORE this process touches the GPU, relay their output and exit with their
+    code.  Under a launcher (WORLD_SIZE set) this is a no-op."""
+    if "WORLD_SIZE" in os.environ:
+        return
+    n = 1
+    for i, a in enumerate(sys.argv):
+        if a == "--gpus" and i + 1 < len(sys.argv):
+            n = int(sys.argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1:
+        return
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd).returncode)
+
+
+if __name__ == "__main__":
+    _spawn_ranks_if_needed()
 
 import numpy as np
 import torch
@@ -71,7 +109,9 @@ def parse():
     ap.add_argument("--W", type=int, default=10000)
     ap.add_argument("--H", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="10000x1250")
+    ap.add_argument("--cpu-sample", default="full", help="WxH of the CPU baseline's mesh; 'full' = the GPU's own mesh")
+    ap.add_argument("--concurrent", type=int, default=8, help="archives decoded at once in the decode_concurrent block (0: skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the walk mesh, PCIe-inclusive and concurrent-decode blocks")
     return ap.parse_args()
 
 
@@ -122,17 +162,16 @@ def _reference_streams_parallel(L, v, t, raw):
         libc.free(fp_out[c])
         libc.free(back_fp[c])
     assert ok
-    return {"value": round(raw / (enc + dec) / 1e9, 4), "unit": "GB/s", "cores": 7, "encode_GBps": round(raw / enc / 1e9, 4),
+    return {"value": round(raw / (enc + dec) / 1e9, 4), "unit": "GB/s", "cores": min(7, os.cpu_count() or 1), "threads": 7,
+            "encode_GBps": round(raw / enc / 1e9, 4),
             "decode_GBps": round(raw / dec / 1e9, 4),
             "what": "same sample, one thread per independent stream (x, y, z, b1..b4) calling the reference's coder"}
 
 
-def cpu_baseline(mesh, sample):
-    """Times the CPU path (1 thread) on a bounded sample: encode + decode through the reference's API."""
+def cpu_baseline(mesh, W, H, v, t):
+    """Times the CPU path on the host cores of this box: encode + decode through the reference's API, 1 thread (the
+    reference's own execution model), and one thread per independent stream (the only parallelism the format offers)."""
     from oracle import oracle as O
-    from trico_amd import meshgen
-    W, H = (int(x) for x in sample.split("x"))
-    v, t = (meshgen.grid if mesh == "grid" else meshgen.walk)(W, H)
     nv, nt = W * H, 2 * W * H
     raw = v.nbytes + t.nbytes
     if O.have_ref():
@@ -183,11 +222,109 @@ def cpu_baseline(mesh, sample):
         t3 = time.perf_counter()
         enc, dec = t1 - t0, t3 - t2s
         par = None
-    return {"streams_parallel": par,
+    return {"streams_parallel": par, "nproc": os.cpu_count(),
             "value": round(raw / (enc + dec) / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
             "sample": "%s(%d,%d): %d float vertices + %d u32 triangles, %.0f MB raw; encode %.2f s, decode %.2f s"
                       % (mesh, W, H, nv, nt, raw / 1e6, enc, dec),
             "encode_GBps": round(raw / enc / 1e9, 4), "decode_GBps": round(raw / dec / 1e9, 4)}
+
+
+def extras(args, api, meshgen, dev, d_v, d_t, nv, nt, raw_bytes):
+    """Blocks reported beside the headline (rank 0, N = 1, outside the timed region): the same step on the other synthetic mesh,
+    the step through HOST pointers (PCIe staging included; never `value`), and BASELINE config 5's shape on one GPU: several
+    archives decoded at once from host threads, GB/s of decoded bytes."""
+    import threading
+    out = {}
+    W, H = args.W, args.H
+
+    def one_step(dv, dt):
+        t0 = time.perf_counter()
+        a = api.Archive.open_for_writing(raw_bytes // 4, device=True)
+        assert a.write("vertices", dv, nv) == 1 and a.write("triangles", dt, nt) == 1, api.last_error()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        o_v, o_t = torch.empty_like(dv), torch.empty_like(dt)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        r = api.Archive.open_for_reading(a.get_buffer_pointer(), a.get_size())
+        assert r.read("vertices", o_v) == 1 and r.read("triangles", o_t) == 1, api.last_error()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        ok = bool(torch.equal(o_v.view(torch.int32), dv.view(torch.int32)) and torch.equal(o_t, dt))
+        size = a.get_size()
+        r.close()
+        a.close()
+        return t1 - t0, t3 - t2, size, ok
+
+    # ---- the other mesh -------------------------------------------------------------------------------------------
+    other = "walk" if args.mesh == "grid" else "grid"
+    ov, ot = (meshgen.walk if other == "walk" else meshgen.grid)(W, H)
+    d_ov, d_ot = torch.from_numpy(ov).to(dev), torch.from_numpy(ot.view(np.int32)).to(dev)
+    one_step(d_ov, d_ot)
+    e, d, size, ok = one_step(d_ov, d_ot)
+    assert ok
+    out["other_mesh"] = {"workload": "%s(%d,%d), same sizes" % (other, W, H), "archive_bytes": size, "ratio": round(raw_bytes / size, 2),
+                         "value": round(raw_bytes / (e + d) / 1e9, 4), "encode_GBps": round(raw_bytes / e / 1e9, 4),
+                         "decode_GBps": round(raw_bytes / d / 1e9, 4)}
+    del d_ov, d_ot
+    # ---- host pointers through the plain C API (H2D of the raw arrays, D2H of archive and results included) ---------------
+    hv, ht = d_v.cpu().numpy(), d_t.cpu().numpy().view(np.uint32)
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        a = api.Archive.open_for_writing(raw_bytes // 4)
+        assert a.write("vertices", hv, nv) == 1 and a.write("triangles", ht, nt) == 1, api.last_error()
+        t1 = time.perf_counter()
+        blob = a.tobytes()
+        a.close()
+        v2, t2 = np.empty_like(hv), np.empty_like(ht)
+        t2s = time.perf_counter()
+        r = api.Archive.open_for_reading(blob)
+        assert r.read("vertices", v2) == 1 and r.read("triangles", t2) == 1, api.last_error()
+        r.close()
+        t3 = time.perf_counter()
+        if best is None or (t1 - t0) + (t3 - t2s) < best[0] + best[1]:
+            best = (t1 - t0, t3 - t2s)
+    assert v2.tobytes() == hv.tobytes() and t2.tobytes() == ht.tobytes()
+    out["pcie_inclusive"] = {"what": "same mesh through the plain C API with host pointers (pageable numpy arrays)",
+                             "value": round(raw_bytes / (best[0] + best[1]) / 1e9, 4), "encode_GBps": round(raw_bytes / best[0] / 1e9, 4),
+                             "decode_GBps": round(raw_bytes / best[1] / 1e9, 4)}
+    del blob, v2, t2
+    # ---- several archives decoded at once (BASELINE configs[4] on one GPU) ----------------------------------------------
+    K = args.concurrent
+    if K > 0:
+        a = api.Archive.open_for_writing(raw_bytes // 4, device=True)
+        assert a.write("vertices", d_v, nv) == 1 and a.write("triangles", d_t, nt) == 1, api.last_error()
+        outs = [(torch.empty_like(d_v), torch.empty_like(d_t)) for _ in range(K)]
+        errs = []
+
+        def decode(k):
+            r = api.Archive.open_for_reading(a.get_buffer_pointer(), a.get_size())
+            if not (r.read("vertices", outs[k][0]) == 1 and r.read("triangles", outs[k][1]) == 1):
+                errs.append(k)
+            r.close()
+
+        res = []
+        for kk in sorted(set([1, K])):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            th = [threading.Thread(target=decode, args=(k,)) for k in range(kk)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            assert not errs, errs
+            for k in range(kk):
+                assert torch.equal(outs[k][0].view(torch.int32), d_v.view(torch.int32)) and torch.equal(outs[k][1], d_t)
+            res.append({"archives": kk, "seconds": round(dt, 3), "decode_GBps": round(kk * raw_bytes / dt / 1e9, 3)})
+        a.close()
+        out["decode_concurrent"] = {"what": "%d readers of the %s(%d,%d) archive decoding at once on one GPU, one host thread each; "
+                                            "GB/s of decoded bytes, outputs compared bit for bit" % (K, args.mesh, W, H),
+                                    "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "results": res,
+                                    "decode_GBps": res[-1]["decode_GBps"]}
+    return out
 
 
 def main():
@@ -334,8 +471,15 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fe["avg_ms"]},
             "kernels": kms,
         }
+        if world == 1 and not args.no_extras:
+            out.update(extras(args, api, meshgen, dev, d_v, d_t, nv, nt, raw_bytes))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.mesh, args.cpu_sample)
+            if args.cpu_sample == "full":
+                out["cpu_baseline"] = cpu_baseline(args.mesh, W, H, v, t)
+            else:
+                cw, ch = (int(x) for x in args.cpu_sample.split("x"))
+                cv, ct = gen(cw, ch)
+                out["cpu_baseline"] = cpu_baseline(args.mesh, cw, ch, cv, ct)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
