@@ -16,8 +16,9 @@
 //     One global round trip per step bounds it: ~1 us per 64 values per stream.
 //   decoder: compressed bytes staged through LDS; batches of 64 values: a scalar walk over the 32 header
 //     bytes finds the group positions, all lanes fetch/align/byte-swap their residual, then the dependent
-//     chain runs wave-uniform.  A table read is skipped when the key did not change (then the entry is the
-//     value just written) — the common case on smooth data; otherwise it is a dependent L2 access.
+//     chain runs wave-uniform on the scalar unit with the tables behind the scalar data cache.  A table read is
+//     skipped when the key did not change (then the entry is the value just written) — the common case on
+//     smooth data — and only the table the value's code asks for is read; otherwise it is a dependent miss.
 // Latency-bound by construction; algorithmic bytes per value: 8 + its payload share.
 #include "common.hpp"
 
@@ -249,7 +250,6 @@ __global__ void __launch_bounds__(64) k_fpc64_encode(const u64* __restrict__ src
 // ---- decoder -------------------------------------------------------------------------------------------
 constexpr int WINW = 4096;                 // staging window, dwords (16 KiB)
 constexpr uint32_t BATCH_BYTES = 32 * 17;  // 32 groups of at most 1 + 16 bytes
-constexpr int CACHE = 4096;                // entries per table cache (2 x 48 KiB of LDS; one wave per CU anyway)
 
 struct DecodeArgs
   {
@@ -260,20 +260,29 @@ struct DecodeArgs
 __device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ uint32_t nib_len(uint32_t c) { return c <= 8u ? c : c - 8u; }
 
+// Table accesses of the chain go through the SCALAR data cache (s_load / s_store; see k_fpc32_decode.hip for what was
+// measured about them on gfx950): a scalar load costs ~6 cycles of issue against the ~16 of a vector load plus the
+// VGPR -> SGPR hop, it leaves the result where the wave-uniform chain wants it, and a store is fire-and-forget.  Every
+// access is preceded by s_waitcnt lgkmcnt(0), so a load is never in flight together with a store (a scalar load is not
+// reliably ordered behind an earlier scalar store to the same address while that store is still in flight).
+__device__ __forceinline__ u64 table_load(const u64* base, uint32_t byte_offset)
+  {
+  u64 r;
+  asm volatile("s_waitcnt lgkmcnt(0)\n s_load_dwordx2 %0, %1, %2\n s_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(base), "s"(byte_offset) : "memory");
+  return r;
+  }
+__device__ __forceinline__ void table_store(const u64* base, uint32_t byte_offset, u64 v)
+  {
+  asm volatile("s_store_dwordx2 %0, %1, %2" :: "s"(v), "s"(base), "s"(byte_offset) : "memory");
+  }
+
 __global__ void __launch_bounds__(64) k_fpc64_decode(DecodeArgs args, int arity, uint32_t n, u64* __restrict__ dst, u64* __restrict__ tables,
                                                      uint32_t* __restrict__ status)
   {
   __shared__ uint32_t win[WINW + 8];
-  __shared__ uint32_t ctag1[CACHE], ctag2[CACHE];      // direct-mapped write-through cache of the two tables
-  __shared__ u64 cval1[CACHE], cval2[CACHE];
   const int lane = threadIdx.x;
   const int comp = blockIdx.x;
   const uint8_t* in = args.pay[comp];
-  for (int i = lane; i < CACHE; i += 64)
-    {
-    ctag1[i] = 0xffffffffu;                            // no key equals this (keys have at most 20 bits)
-    ctag2[i] = 0xffffffffu;
-    }
   const uint32_t len = args.size[comp];
   if (len < 5u)
     {
@@ -287,8 +296,8 @@ __global__ void __launch_bounds__(64) k_fpc64_decode(DecodeArgs args, int arity,
     if (lane == 0) atomicOr(status, 2u);
     return;
     }
-  u64* T1 = tables + (size_t)comp * 2 * TSIZE;
-  u64* T2 = T1 + TSIZE;
+  const u64* T1 = tables + (size_t)comp * 2 * TSIZE;      // zeroed by the launcher (fpsc.c:822-833)
+  const u64* T2 = T1 + TSIZE;
   const u64 m1 = (1ull << e1) - 1ull, m2 = (1ull << e2) - 1ull;
   const uint32_t sh1 = 64u - e1, sh2 = 64u - e2, e2h = e2 >> 1;
   const uint32_t al = (uint32_t)((uintptr_t)in & 3u);
@@ -306,8 +315,11 @@ __global__ void __launch_bounds__(64) k_fpc64_decode(DecodeArgs args, int arity,
     };
   refill(q);
   const uint8_t* wb = (const uint8_t*)win;
-  u64 h1 = 0, h2 = 0, p1 = 0, last = 0, t2v = 0;      // wave-uniform; p1 / t2v = entries of the current hashes when ok1 / ok2
-  bool ok1 = true, ok2 = true;                        // zeroed tables: the entries of hash 0 are 0
+  // wave-uniform chain state.  fwd1 / fwd2: the hash did not change with the last value, so the entry of the current hash
+  // is the value / stride just stored and is taken from the register (p1 / t2v) instead of being loaded
+  uint32_t h1 = 0, h2 = 0;
+  u64 p1 = 0, last = 0, t2v = 0;
+  bool fwd1 = true, fwd2 = true;                      // zeroed tables: the entries of hash 0 are 0
   bool bad = false;
   for (uint32_t i0 = 0; i0 < n; i0 += 64u)
     {
@@ -344,15 +356,11 @@ __global__ void __launch_bounds__(64) k_fpc64_decode(DecodeArgs args, int arity,
     const u64 be = ((u64)__builtin_bswap32(lo) << 32) | __builtin_bswap32(hi);      // first stream byte on top
     const u64 xr = nb ? be >> (8u * (8u - nb)) : 0ull;
     const uint64_t dfcm = __ballot(code > 8u);
-    // ---- the dependent chain (wave-uniform) ---------------------------------------------------------------
-    // The entry of the current hash of each table is cached in registers (p1 / t2v): while a value's hash equals
-    // its predecessor's, the table update is a register move and nothing touches memory.  A hash change writes
-    // the entry back (global store, fire and forget, plus a direct-mapped LDS cache of recent entries) and only
-    // marks the cached entry stale: it is fetched when a value actually needs it — an FCM-coded value needs the
-    // FCM entry, a DFCM-coded one the DFCM entry, so on streams whose hashes change with every value one of the
-    // two dependent loads per value disappears (measured on noisy doubles: 0.5-0.6 instead of 1.0 table misses
-    // per value).  A fetch looks in the LDS cache first.  Lane 0 performs every global store and load itself, so
-    // per-thread same-address ordering makes the loads see the earlier stores without draining the store queue.
+    // ---- the dependent chain (wave-uniform, scalar unit) ---------------------------------------------------
+    // Per value ONE table entry is needed: the DFCM entry if the value is DFCM-coded, else the FCM entry
+    // (fpsc.c:977-978), and only if the hash changed with the previous value; both tables are written for every value
+    // (fpsc.c:980-995), fire and forget.  On noisy doubles that is one dependent miss into an 8 MiB table (Infinity
+    // Cache, ~230 ns) for the DFCM-coded values and a scalar-cache / L2 hit for the others.
     u64 outv = 0;
     for (uint32_t k = 0; k < nvals; ++k)
       {
@@ -360,66 +368,28 @@ __global__ void __launch_bounds__(64) k_fpc64_decode(DecodeArgs args, int arity,
       u64 p;
       if ((dfcm >> k) & 1ull)
         {
-        if (!ok2)
-          {
-          const uint32_t cr = (uint32_t)h2 & (CACHE - 1);
-          u64 b = 0;
-          if (rfl(ctag2[cr]) == (uint32_t)h2)
-            b = cval2[cr];
-          else if (lane == 0)
-            b = tab_load(&T2[h2]);
-          t2v = ((u64)rfl((uint32_t)(b >> 32)) << 32) | rfl((uint32_t)b);
-          ok2 = true;
-          }
-        p = last + t2v;                                           // fpsc.c:977-978 with prediction2 = value + table
+        if (!fwd2)
+          t2v = table_load(T2, h2 << 3);
+        p = last + t2v;                                           // prediction2 = value + table entry
         }
       else
         {
-        if (!ok1)
-          {
-          const uint32_t cr = (uint32_t)h1 & (CACHE - 1);
-          u64 a = 0;
-          if (rfl(ctag1[cr]) == (uint32_t)h1)
-            a = cval1[cr];
-          else if (lane == 0)
-            a = tab_load(&T1[h1]);
-          p1 = ((u64)rfl((uint32_t)(a >> 32)) << 32) | rfl((uint32_t)a);
-          ok1 = true;
-          }
+        if (!fwd1)
+          p1 = table_load(T1, h1 << 3);
         p = p1;
         }
       const u64 v = x ^ p;
       const u64 s = v - last;
-      const u64 nh1 = ((h1 << e1) ^ (v >> sh1)) & m1;
-      const u64 nh2 = ((h2 << e2h) ^ (s >> sh2)) & m2;
-      if (nh1 != h1)
-        {
-        if (lane == 0) tab_store(&T1[h1], v);                     // hash_table_1[hash1] = value
-        const uint32_t cw = (uint32_t)h1 & (CACHE - 1);
-        ctag1[cw] = (uint32_t)h1;
-        cval1[cw] = v;
-        h1 = nh1;
-        ok1 = false;
-        }
-      else
-        {
-        p1 = v;                                                   // same hash: the entry is the value just decoded
-        ok1 = true;
-        }
-      if (nh2 != h2)
-        {
-        if (lane == 0) tab_store(&T2[h2], s);                     // hash_table_2[hash2] = stride
-        const uint32_t cw = (uint32_t)h2 & (CACHE - 1);
-        ctag2[cw] = (uint32_t)h2;
-        cval2[cw] = s;
-        h2 = nh2;
-        ok2 = false;
-        }
-      else
-        {
-        t2v = s;
-        ok2 = true;
-        }
+      table_store(T1, h1 << 3, v);                                // hash_table_1[hash1] = value
+      table_store(T2, h2 << 3, s);                                // hash_table_2[hash2] = stride
+      const uint32_t nh1 = (uint32_t)((((u64)h1 << e1) ^ (v >> sh1)) & m1);
+      const uint32_t nh2 = (uint32_t)((((u64)h2 << e2h) ^ (s >> sh2)) & m2);
+      fwd1 = nh1 == h1;
+      fwd2 = nh2 == h2;
+      h1 = nh1;
+      h2 = nh2;
+      p1 = v;
+      t2v = s;
       last = v;
       outv = ((uint32_t)lane == k) ? v : outv;
       }
@@ -427,6 +397,8 @@ __global__ void __launch_bounds__(64) k_fpc64_decode(DecodeArgs args, int arity,
     if (idx < n)
       dst[(size_t)idx * arity + comp] = outv;
     }
+  // no dirty line of the scalar cache may outlive the table buffer
+  asm volatile("s_dcache_wb\n s_waitcnt lgkmcnt(0)" ::: "memory");
   if (bad && lane == 0)
     atomicOr(status, 4u);
   }
