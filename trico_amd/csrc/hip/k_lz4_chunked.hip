@@ -23,6 +23,7 @@
 // The descriptor form also takes literal copying off the parsing waves.
 #include "common.hpp"
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace trico {
 
@@ -54,8 +55,37 @@ struct Meta
   uint32_t reparsed;
   };
 
+// first differing byte among Q x 1 KiB of a[] and b[] starting at lane offset o0 (0xffffffff: none for this lane); all 2Q loads
+// are issued before the first comparison
+template <int Q>
+__device__ __forceinline__ uint32_t batch_count(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint32_t o0)
+  {
+  u32x4 xs[Q], ys[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+    {
+    xs[q] = ld128(a + o0 + 1024u * (uint32_t)q);
+    ys[q] = ld128(b + o0 + 1024u * (uint32_t)q);
+    }
+  uint32_t first = 0xffffffffu;
+#pragma unroll
+  for (int q = Q - 1; q >= 0; --q)
+    {
+    const u32x4 x = xs[q], y = ys[q];
+    const uint64_t d0 = ((uint64_t)(x.y ^ y.y) << 32) | (x.x ^ y.x), d1 = ((uint64_t)(x.w ^ y.w) << 32) | (x.z ^ y.z);
+    if (d0 | d1)
+      first = o0 + 1024u * (uint32_t)q + (d0 ? (uint32_t)__builtin_ctzll(d0) >> 3 : 8u + ((uint32_t)__builtin_ctzll(d1) >> 3));
+    }
+  return first;
+  }
+
 // number of equal bytes of a[] and b[], at most `limit`; 4 KiB per iteration
-__device__ __forceinline__ uint32_t wave_count(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint32_t limit, int lane)
+// NW > 1: NW waves of a workgroup run the SAME parse redundantly (every wave its own table) and share the work of counting a
+// long match: wave w takes slice w of every round and the waves exchange their results through `xch` (every wave calls
+// this function with the same arguments, so the barriers match).
+template <int NW>
+__device__ __forceinline__ uint32_t wave_count(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint32_t limit, int lane, int wave,
+                                               uint32_t* xch)
   {
   uint32_t done = 0;
   // short probe first: most matches are short
@@ -81,13 +111,21 @@ __device__ __forceinline__ uint32_t wave_count(const uint8_t* __restrict__ a, co
     }
   done = 512u;
   }
-  while (done < limit)
+  // long matches: 4 KiB first, then 16 KiB per iteration and wave (the loop is bound by the latency of one round of loads,
+  // and periodic byte planes consist of matches of tens of KiB)
+  for (int Q = 4; done < limit; Q = 16)
     {
     uint32_t first = 0xffffffffu;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
+    if (done + 16384u * NW > limit)
+      Q = 4;
+    const uint32_t base = done + 1024u * (uint32_t)(Q * wave);          // my wave's slice of this round
+    if (base + 1024u * (uint32_t)Q <= limit)
+      first = Q == 16 ? batch_count<16>(a, b, base + 16u * (uint32_t)lane) : batch_count<4>(a, b, base + 16u * (uint32_t)lane);
+    else
+#pragma unroll 4
+    for (int q = 0; q < Q; ++q)
       {
-      const uint32_t o = done + 1024u * (uint32_t)q + 16u * (uint32_t)lane;
+      const uint32_t o = base + 1024u * (uint32_t)q + 16u * (uint32_t)lane;
       if (o + 16u <= limit)
         {
         const u32x4 x = ld128(a + o), y = ld128(b + o);
@@ -108,9 +146,19 @@ __device__ __forceinline__ uint32_t wave_count(const uint8_t* __restrict__ a, co
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1)
       first = min(first, (uint32_t)__shfl_xor((int)first, s));
+    if (NW > 1)
+      {
+      if (lane == 0) xch[wave] = first;
+      __syncthreads();
+      first = xch[lane < NW ? lane : 0];
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1)
+        first = min(first, (uint32_t)__shfl_xor((int)first, s));
+      __syncthreads();
+      }
     if (first != 0xffffffffu)
       return first < limit ? first : limit;
-    done += 4096u;
+    done += 1024u * (uint32_t)(Q * NW);
     }
   return limit;
   }
@@ -122,17 +170,19 @@ __device__ __forceinline__ uint32_t wave_count(const uint8_t* __restrict__ a, co
 //   emit_from_start: record descriptors from the first sequence on (chunk 0, re-parse); otherwise wait for
 //                    the first match end >= c_lo, snapshot there, then record
 // Stops at the first match end >= c_hi (END_MATCH) or at the end of the block (END_FINAL).
-__device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t* tab, uint32_t ip0, bool start_match_end, bool fresh,
+template <int NW>
+__device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t* tab, uint8_t* dup, uint32_t ip0, bool start_match_end, bool fresh,
                           bool emit_from_start, uint32_t c_lo, uint32_t c_hi, Desc* __restrict__ desc, uint32_t dcap,
-                          Meta* __restrict__ meta, uint32_t* __restrict__ snapT, uint32_t* __restrict__ endT, int lane)
+                          Meta* __restrict__ meta, uint32_t* __restrict__ snapT, uint32_t* __restrict__ endT, int lane, int wave = 0,
+                          uint32_t* xch = nullptr)
   {
+  const bool writer = lane == 0 && wave == 0;            // descriptors and chunk meta: one writer (NW > 1: all waves hold the same values)
   const uint32_t mfl1 = n - 11u, mlim = n - 5u;                                    // lz4.c:825-826 (n >= 13 here)
   bool emit = emit_from_start;
   uint32_t nd = 0;
   uint32_t ip = ip0, anchor = ip0;
   uint32_t end_kind = END_NONE, end_ip = 0;
   uint32_t first_in = ip0;
-  uint32_t fh = 0;
   bool at_match_end = start_match_end;
   if (fresh)
     {
@@ -140,11 +190,8 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
     ip = 1;
     anchor = 0;
     first_in = 0;
-    fh = uni(hash5(src + 1));
     at_match_end = false;
     }
-  else if (!start_match_end)
-    fh = uni(hash5(src + ip));
   bool overflow = false;
   for (;;)
     {
@@ -177,7 +224,7 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
         // final literals follow
         if (emit)
           {
-          if (nd < dcap) { if (lane == 0) { desc[nd].lit = n - anchor; desc[nd].ml = 0; desc[nd].off = 0; } ++nd; }
+          if (nd < dcap) { if (writer) { desc[nd].lit = n - anchor; desc[nd].ml = 0; desc[nd].off = 0; } ++nd; }
           else overflow = true;
           end_kind = END_FINAL;
           end_ip = n;
@@ -193,36 +240,82 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
       if (cand + MAXD >= ip && uni(ld32(src + cand)) == uni(ld32(src + ip)))
         have_match = true;                                                         // lz4.c:1101-1138: literal length 0, no catch-up
       else
-        {
         ++ip;
-        fh = uni(hash5(src + ip));
-        }
       at_match_end = false;
       }
     if (!have_match)
       {
-      // ---- search loop (lz4.c:898-956) ----
-      uint32_t fwd = ip, step = 1, nb = 64;
+      // ---- search loop (lz4.c:898-956), 64 attempts at a time ----
+      // Attempt t of a search looks at start + off(t), off(0) = 0, off(t) = 1 + sum_{m < 63 + t} (m >> 6): the positions do not
+      // depend on what is found (lz4.c:907-913: step = searchMatchNb++ >> LZ4_skipTrigger).  One attempt costs the reference a
+      // hash of 8 source bytes, a table read and write and, if the candidate is in range, a 4-byte comparison; one wave pays
+      // a global round trip of ~1 us for each of them, which is what bounded both the parse of planes that compress badly
+      // and the re-parses of the stitch pass.  Here lane l evaluates attempt t0 + l: all hashes and candidate comparisons
+      // are one round trip each.  Sequential semantics (attempt l sees the table writes of attempts < l) hold if the 64
+      // hashes are distinct, which a byte-sized LDS scoreboard checks; otherwise one attempt is taken the serial way.
+      // The first lane that ends the search (match, or the next position beyond mflimitPlusOne) decides; the table
+      // writes of the attempts before it (and its own, for a match) are committed.
+      const uint32_t start = ip;
+      uint32_t t0 = 0;
       bool final = false;
       for (;;)
         {
-        const uint32_t h = fh, cur = fwd;
-        cand = uni(tab[h]);
-        ip = fwd;
-        fwd += step;
-        step = nb++ >> 6;
-        if (fwd > mfl1) { final = true; break; }
-        fh = uni(hash5(src + fwd));
+        const uint32_t ta = t0 + (uint32_t)lane, tb = ta + 1u;
+        const uint32_t xa = 63u + ta, xb = 63u + tb;
+        const uint32_t offa = ta ? 1u + 32u * (xa >> 6) * ((xa >> 6) - 1u) + (xa >> 6) * (xa & 63u) : 0u;
+        const uint32_t offb = 1u + 32u * (xb >> 6) * ((xb >> 6) - 1u) + (xb >> 6) * (xb & 63u);
+        const uint32_t pos = start + offa, nxt = start + offb;
+        const bool active = pos <= mfl1;                                           // else an earlier lane ends the search
+        const bool fin = active && nxt > mfl1;
+        uint64_t w = 0;
+        if (active)
+          w = ld64(src + pos);
+        const uint32_t h = (uint32_t)(((w << 24) * 889523592379ull) >> 52);        // hash5 (lz4.c:643-648)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (lane == 0) tab[h] = cur;
-        if (cand + MAXD < cur) continue;
-        if (uni(ld32(src + cand)) == uni(ld32(src + ip))) break;
+        if (active)
+          dup[h] = (uint8_t)lane;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const bool clash = active && dup[h] != (uint8_t)lane;
+        const uint32_t cnd = active ? tab[h] : 0u;
+        if (__ballot(clash))
+          {
+          // two attempts of this batch share a hash: take ONE attempt exactly as the reference does, then batch again
+          const uint32_t h0 = uni(h), cur = uni(pos);
+          cand = uni(cnd);
+          ip = cur;
+          if (uni(nxt) > mfl1) { final = true; break; }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          if (lane == 0) tab[h0] = cur;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          if (cand + MAXD >= cur && uni(ld32(src + cand)) == (uint32_t)uni((uint32_t)w)) break;
+          t0 += 1u;
+          continue;
+          }
+        bool hit = false;
+        if (active && !fin && cnd + MAXD >= pos)
+          hit = ld32(src + cnd) == (uint32_t)w;
+        const uint64_t stop = __ballot(fin || hit);
+        const int first = stop ? __builtin_ctzll(stop) : 64;
+        const bool first_fin = stop && ((__ballot(fin) >> first) & 1ull);
+        // table writes: every attempt before the deciding one, and the deciding one too unless it is the final one
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (active && (lane < first || (lane == first && !first_fin)))
+          tab[h] = pos;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (stop)
+          {
+          ip = (uint32_t)__builtin_amdgcn_readlane((int)pos, first);
+          cand = (uint32_t)__builtin_amdgcn_readlane((int)cnd, first);
+          final = first_fin;
+          break;
+          }
+        t0 += 64u;
         }
       if (final)
         {
         if (emit)
           {
-          if (nd < dcap) { if (lane == 0) { desc[nd].lit = n - anchor; desc[nd].ml = 0; desc[nd].off = 0; } ++nd; }
+          if (nd < dcap) { if (writer) { desc[nd].lit = n - anchor; desc[nd].ml = 0; desc[nd].off = 0; } ++nd; }
           else overflow = true;
           end_kind = END_FINAL;
           end_ip = n;
@@ -259,12 +352,12 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
       const uint32_t cap = c_hi - (ip + 4u);
       if (cap < limit) limit = cap;
       }
-    const uint32_t m = wave_count(src + ip + 4u, src + cand + 4u, limit, lane);
+    const uint32_t m = wave_count<NW>(src + ip + 4u, src + cand + 4u, limit, lane, wave, xch);
     if (!emit && limit < room && m >= limit)
       break;                                                                       // ran past c_hi during warm-up
     if (emit)
       {
-      if (nd < dcap) { if (lane == 0) { desc[nd].lit = ip - anchor; desc[nd].ml = m + 4u; desc[nd].off = ip - cand; } ++nd; }
+      if (nd < dcap) { if (writer) { desc[nd].lit = ip - anchor; desc[nd].ml = m + 4u; desc[nd].off = ip - cand; } ++nd; }
       else { overflow = true; break; }
       }
     ip += m + 4u;
@@ -290,6 +383,7 @@ __global__ void __launch_bounds__(64) k_lz4_parse(const uint8_t* __restrict__ pl
                                                   uint32_t* __restrict__ snapTs, uint32_t* __restrict__ endTs)
   {
   __shared__ uint32_t tab[4096];
+  __shared__ uint8_t dup[4096];                  // scoreboard of the batched search loop
   const int lane = threadIdx.x;
   const uint32_t k = blockIdx.x, p = blockIdx.y;
   for (int i = lane; i < 4096; i += 64)
@@ -305,37 +399,50 @@ __global__ void __launch_bounds__(64) k_lz4_parse(const uint8_t* __restrict__ pl
   const uint8_t* src = planes + (size_t)p * g.plane_stride;
   const uint32_t c_lo = k * g.chunk;
   const uint32_t c_hi = (k + 1u == g.K) ? 0xffffffffu : c_lo + g.chunk;
-  lz4_parse(src, g.n, tab, k == 0 ? 0u : c_lo - g.warm, false, k == 0, k == 0, c_lo, c_hi, descs + ck * g.dcap, g.dcap, meta,
+  lz4_parse<1>(src, g.n, tab, dup, k == 0 ? 0u : c_lo - g.warm, false, k == 0, k == 0, c_lo, c_hi, descs + ck * g.dcap, g.dcap, meta,
             snapTs + ck * 4096, endTs + ck * 4096, lane);
   }
 
-// one wave per plane: accept speculative chunks whose snapshot is equivalent to the true state, re-parse the others
-__global__ void __launch_bounds__(64) k_lz4_stitch(const uint8_t* __restrict__ planes, Geom g, Desc* __restrict__ descs, Meta* __restrict__ metas,
-                                                   uint32_t* __restrict__ snapTs, uint32_t* __restrict__ endTs, uint32_t* __restrict__ status)
+// One workgroup per plane walks the chain: accept speculative chunks whose snapshot is equivalent to the true state, re-parse the
+// others.  Re-parsing is serial by nature (the next chunk needs this one's end state) and on periodic planes it consists of a
+// few dozen matches of tens of KiB per chunk, i.e. of counting equal bytes: STITCH_W waves run the same walk and the same
+// re-parse redundantly, each with a private copy of the table in LDS, and split every long count among themselves
+// (wave_count<NW>).  All decisions are functions of the same inputs, so the waves stay in step; the two barriers per
+// chain step keep a faster wave from rewriting a chunk's meta words before a slower one has read them.
+constexpr int STITCH_W = 1;
+
+__global__ void __launch_bounds__(64 * STITCH_W) k_lz4_stitch(const uint8_t* __restrict__ planes, Geom g, Desc* __restrict__ descs,
+                                                              Meta* __restrict__ metas, uint32_t* __restrict__ snapTs,
+                                                              uint32_t* __restrict__ endTs, uint32_t* __restrict__ status)
   {
-  __shared__ uint32_t tab[4096];
-  const int lane = threadIdx.x;
+  __shared__ uint32_t tabs[STITCH_W][4096];
+  __shared__ uint8_t dups[STITCH_W][4096];
+  __shared__ uint32_t xch[64];
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)uni(threadIdx.x >> 6);
+  uint32_t* tab = tabs[wave];
   const uint32_t p = blockIdx.x;
   const uint8_t* src = planes + (size_t)p * g.plane_stride;
   Meta* pm = metas + (size_t)p * g.K;
   uint32_t cur = 0;                               // last accepted chunk
-  if (lane == 0) pm[0].accepted = 1u;
+  if (threadIdx.x == 0) pm[0].accepted = 1u;
   for (uint32_t guard = 0; guard < g.K + 2u; ++guard)
     {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    __syncthreads();
     const uint32_t kind = uni(pm[cur].end_kind), ip = uni(pm[cur].end_ip);
     if (kind == END_FINAL)
       return;
     if (kind != END_MATCH)
       {
-      if (lane == 0) atomicOr(status, 16u);      // descriptor overflow / parser did not finish: must not happen
+      if (threadIdx.x == 0) atomicOr(status, 16u);      // descriptor overflow / parser did not finish: must not happen
       return;
       }
     uint32_t j = ip / g.chunk;
     if (j >= g.K) j = g.K - 1u;
     if (j <= cur)
       {
-      if (lane == 0) atomicOr(status, 32u);      // no forward progress: must not happen
+      if (threadIdx.x == 0) atomicOr(status, 32u);      // no forward progress: must not happen
       return;
       }
     const uint32_t* curT = endTs + ((size_t)p * g.K + cur) * 4096;
@@ -351,20 +458,20 @@ __global__ void __launch_bounds__(64) k_lz4_stitch(const uint8_t* __restrict__ p
         }
       ok = __ballot(!same) == 0ull;
       }
+    __syncthreads();                               // every wave has read chunk j's words
     if (!ok)
       {
       // exact re-parse of chunk j from the true state
       for (int i = lane; i < 4096; i += 64)
         tab[i] = curT[i];
-      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       const uint32_t c_hi = (j + 1u == g.K) ? 0xffffffffu : (j + 1u) * g.chunk;
       const size_t cj = (size_t)p * g.K + j;
-      lz4_parse(src, g.n, tab, ip, true, false, true, j * g.chunk, c_hi, descs + cj * g.dcap, g.dcap, pm + j,
-                snapTs + cj * 4096, endTs + cj * 4096, lane);
-      if (lane == 0) pm[j].reparsed = 1u;
-      __syncthreads();
+      lz4_parse<STITCH_W>(src, g.n, tab, dups[wave], ip, true, false, true, j * g.chunk, c_hi, descs + cj * g.dcap, g.dcap, pm + j,
+                          snapTs + cj * 4096, endTs + cj * 4096, lane, wave, xch);
+      if (threadIdx.x == 0) pm[j].reparsed = 1u;
       }
-    if (lane == 0)
+    if (threadIdx.x == 0)
       {
       pm[j].accepted = 1u;
       atomicAdd(status + 1, 1u);                 // statistics: accepted chunks, re-parsed chunks
@@ -372,7 +479,7 @@ __global__ void __launch_bounds__(64) k_lz4_stitch(const uint8_t* __restrict__ p
       }
     cur = j;
     }
-  if (lane == 0) atomicOr(status, 64u);
+  if (threadIdx.x == 0) atomicOr(status, 64u);
   }
 
 __device__ __forceinline__ uint32_t ext_bytes(uint32_t len) { return len >= 15u ? (len - 15u) / 255u + 1u : 0u; }
@@ -638,7 +745,27 @@ int launch_lz4_encode_chunked(const uint8_t* d_planes, size_t plane_stride, uint
   uint32_t* cbytes = (uint32_t*)(d_ws + p.off_cbytes);
   uint32_t* coff = (uint32_t*)(d_ws + p.off_coff);
   hipLaunchKernelGGL(k_lz4_parse, dim3(p.g.K, nplanes), dim3(64), 0, st, d_planes, p.g, descs, metas, snapTs, endTs);
-  hipLaunchKernelGGL(k_lz4_stitch, dim3(nplanes), dim3(64), 0, st, d_planes, p.g, descs, metas, snapTs, endTs, d_status);
+  hipLaunchKernelGGL(k_lz4_stitch, dim3(nplanes), dim3(64 * STITCH_W), 0, st, d_planes, p.g, descs, metas, snapTs, endTs, d_status);
+  if (getenv("TRICO_LZ4_DEBUG"))
+    {
+    const size_t cells = (size_t)p.g.K * nplanes;
+    Meta* h = (Meta*)malloc(cells * sizeof(Meta));
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h, metas, cells * sizeof(Meta), hipMemcpyDeviceToHost);
+    for (int pl = 0; pl < nplanes; ++pl)
+      {
+      fprintf(stderr, "plane %d:", pl);
+      uint32_t acc = 0, rep = 0;
+      for (uint32_t k = 0; k < p.g.K; ++k)
+        {
+        const Meta& m = h[(size_t)pl * p.g.K + k];
+        acc += m.accepted; rep += m.reparsed;
+        if (m.reparsed && rep <= 40) fprintf(stderr, " %u(nd %u)", k, m.ndesc);
+        }
+      fprintf(stderr, "\n  accepted %u reparsed %u of %u\n", acc, rep, p.g.K);
+      }
+    free(h);
+    }
   hipLaunchKernelGGL(k_lz4_sizes, dim3(p.g.K, nplanes), dim3(256), 0, st, p.g, descs, metas, cbytes);
   hipLaunchKernelGGL(k_lz4_offsets, dim3(nplanes), dim3(1024), 0, st, p.g, cbytes, coff, d_sizes);
   hipLaunchKernelGGL(k_lz4_emit, dim3(p.g.K, nplanes), dim3(EMIT_T), 0, st, d_planes, p.g, descs, metas, coff, d_out, out_stride);
