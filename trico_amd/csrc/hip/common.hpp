@@ -116,6 +116,13 @@ size_t fpc64_sorted_workspace(uint32_t n);
 int launch_fpc64_encode_sorted(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
                                uint8_t* d_ws, size_t ws_bytes);
 
+// stable LSD radix sort of (u32 key, u32 value) pairs and exclusive u32 scan (k_sort.hip); workspaces in bytes
+size_t sort_workspace(uint32_t n);
+int radix_sort_pairs(const uint32_t* d_keys_in, const uint32_t* d_vals_in, uint32_t* d_keys_out, uint32_t* d_vals_out, uint32_t n,
+                     int key_bits, uint8_t* d_ws, size_t ws_bytes);
+size_t scan_workspace(uint32_t n);
+int exclusive_scan_u32(const uint32_t* d_in, uint32_t* d_out, uint32_t n, uint8_t* d_ws, size_t ws_bytes);
+
 // vertex welding for the STL reader (k_weld.hip): sort + unique of corner positions
 size_t weld_workspace(uint32_t n);
 int launch_weld(const uint32_t* d_pos, uint32_t n, uint32_t* d_out_pos, uint32_t* d_out_tri, uint8_t* d_ws, size_t ws_bytes, uint32_t* d_result);

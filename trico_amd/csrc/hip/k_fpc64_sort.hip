@@ -8,16 +8,15 @@
 // latest earlier value with the same hash, or 0.  "Latest earlier element with the same key" is the predecessor in a
 // stable sort by key:
 //   keys    (k64_keys):   both hashes of every value, and an index array
-//   sort    (rocPRIM radix sort through hipCUB, 20 key bits, stable): (hash, index) pairs, one sort per table
+//   sort    (k_sort.hip: stable LSD radix sort, two 10-bit passes): (hash, index) pairs, one sort per table
 //   preds   (k64_pred):   sorted neighbour with the same hash -> its payload, scattered back to the value's index
 //   sizes   (k64_sizes):  code selection (fpsc.c:640-700) -> bytes per group of two values (1 header byte + residuals)
-//   scan    (hipCUB exclusive sum): byte offset of every group
+//   scan    (k_sort.hip: exclusive sum): byte offset of every group
 //   emit    (k64_emit):   tiles of 1024 groups are packed in LDS and written out with aligned dword stores
 // Everything is data-parallel; HBM traffic is ~25 passes over 4-8 byte arrays per value (sort-dominated), which on
 // this machine is two orders of magnitude cheaper than walking the 16 MiB tables value by value.
 #include "common.hpp"
-
-#include <hipcub/hipcub.hpp>
+#include <stdlib.h>
 
 namespace trico {
 
@@ -35,7 +34,7 @@ __device__ __forceinline__ u64 val_at(const u64* __restrict__ src, int64_t i, in
   }
 
 __global__ void __launch_bounds__(256) k64_keys(const u64* __restrict__ src, uint32_t n, int arity, int c,
-                                                uint32_t* __restrict__ k1, uint32_t* __restrict__ k2, uint32_t* __restrict__ iota)
+                                                uint32_t* __restrict__ k1, uint32_t* __restrict__ k2)
   {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n)
@@ -44,7 +43,6 @@ __global__ void __launch_bounds__(256) k64_keys(const u64* __restrict__ src, uin
   const u64 s1 = v1 - v2, s2 = v2 - v3;
   k1[i] = (uint32_t)(v1 >> 44);                                             // fpsc.c:565-568 with a 20-bit table
   k2[i] = (uint32_t)(((((s2 >> 44) & 1023ull) << 10) ^ (s1 >> 44)) & 0xfffffull);   // fpsc.c:570-573: two strides of history
-  iota[i] = i;
   }
 
 // sorted position p holds value index vs[p] with hash ks[p]; its table read is the payload of the previous
@@ -148,7 +146,7 @@ __global__ void __launch_bounds__(TILE_T) k64_emit(const u64* __restrict__ src, 
     *size_out = 5u + end;
   }
 
-struct SortPlan { size_t k1, k1s, k2, k2s, iota, v1s, v2s, pred1, pred2, gsz, goff, cub, cub_bytes, total; };
+struct SortPlan { size_t k1, k1s, k2, k2s, v1s, v2s, pred1, pred2, gsz, goff, tmp, tmp_bytes, total; };
 
 SortPlan plan_for(uint32_t n)
   {
@@ -157,15 +155,12 @@ SortPlan plan_for(uint32_t n)
   size_t o = 0;
   auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes + 16, 256); return at; };
   p.k1 = take(4 * (size_t)n); p.k1s = take(4 * (size_t)n); p.k2 = take(4 * (size_t)n); p.k2s = take(4 * (size_t)n);
-  p.iota = take(4 * (size_t)n); p.v1s = take(4 * (size_t)n); p.v2s = take(4 * (size_t)n);
+  p.v1s = take(4 * (size_t)n); p.v2s = take(4 * (size_t)n);
   p.pred1 = take(8 * (size_t)n); p.pred2 = take(8 * (size_t)n);
   p.gsz = take(4 * ng); p.goff = take(4 * ng);
-  size_t sort_bytes = 0, scan_bytes = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                           (uint32_t*)nullptr, (int)n, 0, 20);
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)ng);
-  p.cub_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
-  p.cub = take(p.cub_bytes);
+  const size_t sort_bytes = sort_workspace(n), scan_bytes = scan_workspace((uint32_t)ng);
+  p.tmp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+  p.tmp = take(p.tmp_bytes);
   p.total = o;
   return p;
   }
@@ -209,24 +204,21 @@ int launch_fpc64_encode_sorted(const void* d_src, uint32_t n, int arity, uint8_t
   const unsigned vb = (n + 255u) / 256u, gb = (ng + 255u) / 256u, tiles = (ng + TILE_G - 1) / TILE_G;
   uint32_t* k1 = (uint32_t*)(d_ws + p.k1); uint32_t* k1s = (uint32_t*)(d_ws + p.k1s);
   uint32_t* k2 = (uint32_t*)(d_ws + p.k2); uint32_t* k2s = (uint32_t*)(d_ws + p.k2s);
-  uint32_t* iota = (uint32_t*)(d_ws + p.iota); uint32_t* v1s = (uint32_t*)(d_ws + p.v1s); uint32_t* v2s = (uint32_t*)(d_ws + p.v2s);
+  uint32_t* v1s = (uint32_t*)(d_ws + p.v1s); uint32_t* v2s = (uint32_t*)(d_ws + p.v2s);
   u64* pred1 = (u64*)(d_ws + p.pred1); u64* pred2 = (u64*)(d_ws + p.pred2);
   uint32_t* gsz = (uint32_t*)(d_ws + p.gsz); uint32_t* goff = (uint32_t*)(d_ws + p.goff);
   for (int c = 0; c < arity; ++c)
     {
-    hipLaunchKernelGGL(k64_keys, dim3(vb), dim3(256), 0, st, src, n, arity, c, k1, k2, iota);
-    size_t cb = p.cub_bytes;
-    if (hipcub::DeviceRadixSort::SortPairs(d_ws + p.cub, cb, k1, k1s, iota, v1s, (int)n, 0, 20, st) != hipSuccess)
-      return hip_ok(hipGetLastError(), "radix sort (FCM hashes)") ? 0 : 0;
-    cb = p.cub_bytes;
-    if (hipcub::DeviceRadixSort::SortPairs(d_ws + p.cub, cb, k2, k2s, iota, v2s, (int)n, 0, 20, st) != hipSuccess)
-      return hip_ok(hipGetLastError(), "radix sort (DFCM hashes)") ? 0 : 0;
+    hipLaunchKernelGGL(k64_keys, dim3(vb), dim3(256), 0, st, src, n, arity, c, k1, k2);
+    // values = identity: the sorted value of position p is the index of the p-th value in (hash, index) order
+    if (!radix_sort_pairs(k1, nullptr, k1s, v1s, n, 20, d_ws + p.tmp, p.tmp_bytes) ||
+        !radix_sort_pairs(k2, nullptr, k2s, v2s, n, 20, d_ws + p.tmp, p.tmp_bytes))
+      return 0;
     hipLaunchKernelGGL(k64_pred, dim3(vb), dim3(256), 0, st, k1s, v1s, src, n, arity, c, 0, pred1);
     hipLaunchKernelGGL(k64_pred, dim3(vb), dim3(256), 0, st, k2s, v2s, src, n, arity, c, 1, pred2);
     hipLaunchKernelGGL(k64_sizes, dim3(gb), dim3(256), 0, st, src, n, arity, c, pred1, pred2, ng, gsz);
-    cb = p.cub_bytes;
-    if (hipcub::DeviceScan::ExclusiveSum(d_ws + p.cub, cb, gsz, goff, (int)ng, st) != hipSuccess)
-      return hip_ok(hipGetLastError(), "group offset scan") ? 0 : 0;
+    if (!exclusive_scan_u32(gsz, goff, ng, d_ws + p.tmp, p.tmp_bytes))
+      return 0;
     hipLaunchKernelGGL(k64_emit, dim3(tiles), dim3(TILE_T), 0, st, src, n, arity, c, pred1, pred2, ng, goff, gsz,
                        d_out + (size_t)c * out_stride, d_sizes + c);
     }

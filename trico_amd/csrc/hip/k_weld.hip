@@ -7,11 +7,9 @@
 // equal but differ in bits: which one represents the vertex depends on the quicksort's swaps) or NaNs are present
 // (they never compare equal or less).  Those inputs are detected here and left to the host implementation, which
 // reproduces the reference's partition scheme; everything else is three stable radix sorts (z, then y, then x, on an
-// order-preserving integer image of the floats; rocPRIM through hipCUB), an adjacent compare, an exclusive scan and
+// order-preserving integer image of the floats; k_sort.hip), an adjacent compare, an exclusive scan and
 // a scatter.
 #include "common.hpp"
-
-#include <hipcub/hipcub.hpp>
 
 namespace trico {
 
@@ -86,11 +84,9 @@ int launch_weld(const uint32_t* d_pos, uint32_t n, uint32_t* d_out_pos, uint32_t
   uint32_t* keys2 = (uint32_t*)(d_ws + take(4 * (size_t)n));
   uint32_t* permA = (uint32_t*)(d_ws + take(4 * (size_t)n));
   uint32_t* permB = (uint32_t*)(d_ws + take(4 * (size_t)n));
-  size_t sort_bytes = 0, scan_bytes = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys, keys2, permA, permB, (int)n);
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, keys, keys2, (int)n);
-  const size_t cub_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
-  uint8_t* cub = d_ws + take(cub_bytes);
+  const size_t sort_bytes = sort_workspace(n), scan_bytes = scan_workspace(n);
+  const size_t tmp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+  uint8_t* tmp = d_ws + take(tmp_bytes);
   if (o > ws_bytes)
     {
     set_error("weld: workspace too small");
@@ -109,25 +105,20 @@ int launch_weld(const uint32_t* d_pos, uint32_t n, uint32_t* d_out_pos, uint32_t
     uint32_t* vals_out = (vals_in == bufs[0]) ? bufs[1] : bufs[0];
     hipLaunchKernelGGL(k_weld_keys, dim3(blocks), dim3(256), 0, st, d_pos, cur, n, comp, keys, pass == 0 ? bufs[0] : (uint32_t*)nullptr,
                        d_result + 1);
-    size_t cb = cub_bytes;
-    if (hipcub::DeviceRadixSort::SortPairs(cub, cb, keys, keys2, vals_in, vals_out, (int)n, 0, 32, st) != hipSuccess)
-      return hip_ok(hipGetLastError(), "weld radix sort") ? 0 : 0;
+    if (!radix_sort_pairs(keys, vals_in, keys2, vals_out, n, 32, tmp, tmp_bytes))
+      return 0;
     cur = vals_out;
     }
   hipLaunchKernelGGL(k_weld_first, dim3(blocks), dim3(256), 0, st, d_pos, cur, n, keys);
-  size_t cb = cub_bytes;
-  if (hipcub::DeviceScan::ExclusiveSum(cub, cb, keys, keys2, (int)n, st) != hipSuccess)
-    return hip_ok(hipGetLastError(), "weld scan") ? 0 : 0;
+  if (!exclusive_scan_u32(keys, keys2, n, tmp, tmp_bytes))
+    return 0;
   hipLaunchKernelGGL(k_weld_scatter, dim3(blocks), dim3(256), 0, st, d_pos, cur, keys, keys2, n, d_out_pos, d_out_tri, d_result);
   return hip_ok(hipGetLastError(), "weld kernels") ? 1 : 0;
   }
 
 size_t weld_workspace(uint32_t n)
   {
-  size_t sort_bytes = 0, scan_bytes = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                           (uint32_t*)nullptr, (int)n);
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+  const size_t sort_bytes = sort_workspace(n), scan_bytes = scan_workspace(n);
   return 4 * align_up(4 * (size_t)n + 16, 256) + align_up((sort_bytes > scan_bytes ? sort_bytes : scan_bytes) + 16, 256) + 256;
   }
 

@@ -89,6 +89,10 @@ void DevBuf::release()
   {
   if (p)
     {
+    // Another context (another thread, another stream) may take the buffer out of the pool right away, so no work of this
+    // thread's stream may still be using it: e.g. the gather of a float stream into a device archive returns with its
+    // kernel reading the segment slots.  Buffers only grow, so this wait is rare.
+    (void)hipStreamSynchronize(current_stream());
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     if (g_pool_n < (int)(sizeof(g_pool) / sizeof(g_pool[0])))
       g_pool[g_pool_n++] = PoolEntry{ p, cap };
