@@ -105,6 +105,39 @@ TRICO_API const uint8_t* trico_hip_payload_device_pointer(trico_hip_ctx* ctx, in
  * the .trc bytes are consumed on the GPU (RCCL gather, device-side decode) so nothing crosses PCIe. */
 TRICO_API void* trico_hip_open_archive_for_writing_device(uint64_t initial_buffer_size);
 
+
+/* ---- stream-sharded encoding (one big mesh over several GPUs) --------------------
+ * The independent units of a stream are its components (trico.c:229-260: x, y, z are compressed one after the other)
+ * and, for integer streams, its byte planes (trico.c:346-368).  A rank encodes the units it owns, the payloads travel
+ * to the root (trico_hip_comm_gather below), and the root frames them exactly as the writers do (type byte, count,
+ * then per unit a 4-byte size and the payload).
+ *
+ * _encode_component: component `comp` of n interleaved `arity`-vectors of `width`-byte reals; _encode_plane: byte plane
+ * `plane` of `count` integers of `width` bytes.  The payload is payload 0 of the context afterwards
+ * (trico_hip_fetch_payload / trico_hip_payload_device_pointer). */
+TRICO_API int trico_hip_fpc_encode_component(trico_hip_ctx* ctx, const void* src, uint32_t n, int arity, int width, int comp, uint32_t* size);
+TRICO_API int trico_hip_int_encode_plane(trico_hip_ctx* ctx, const void* src, uint32_t count, int width, int plane, uint32_t* size);
+/* Appends one stream to a writable archive from already encoded units: payloads[c] (host or device) of sizes[c] bytes,
+ * c < nunits (3 / 2 / 1 components, or `width` planes).  `count_field` is the count the matching trico_write_* stores
+ * (trico.c:215-858).  The archive bytes are those the writer itself would have produced. */
+TRICO_API int trico_hip_append_encoded_stream(void* archive, int stream_type, uint32_t count_field, int nunits,
+                                              const void* const* payloads, const uint32_t* sizes);
+
+/* ---- RCCL exchange (one process per GPU; xGMI inside a node) -----------------------------------------
+ * Thin wrapper over RCCL (loaded with dlopen when first used, so libtrico.so has no link-time dependency on it).
+ * Rank 0 obtains an id and hands its 128 bytes to the other ranks by any means (MPI, a file, torch.distributed...);
+ * every rank then creates its communicator with the GPU it will use made current. */
+typedef struct trico_hip_comm trico_hip_comm;
+TRICO_API int trico_hip_comm_unique_id(uint8_t id[128]);
+TRICO_API trico_hip_comm* trico_hip_comm_create(const uint8_t id[128], int rank, int world);
+TRICO_API void trico_hip_comm_destroy(trico_hip_comm* comm);
+/* Every rank contributes `local_bytes` device bytes at d_local.  sizes[r] (host, `world` entries, filled on every rank)
+ * receives the byte counts; on `root`, d_root receives the contributions back to back in rank order (capacity
+ * root_capacity bytes; too small -> 0 on every rank after the size exchange, nothing moved).  One all-gather of the
+ * sizes, then point-to-point transfers straight to their final offsets. */
+TRICO_API int trico_hip_comm_gather(trico_hip_comm* comm, const void* d_local, uint64_t local_bytes, int root, void* d_root,
+                                    uint64_t root_capacity, uint64_t* sizes);
+
 /* ---- kernel timing (bench instrumentation) ---------------------------------------------------
  * When enabled, every launch of a hot kernel is bracketed by hipEvents on the launch stream and
  * the durations are accumulated per kernel id (TRICO_HIP_K_*).  Costs a sync per query only. */

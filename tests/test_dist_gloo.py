@@ -72,3 +72,70 @@ def test_gather_archives_gloo(world, native_libs):
             a.close()
         assert sizes[r] == len(want)
         assert parts[r] == want
+
+
+# ---- one mesh sharded by stream units over the ranks, assembled into ONE archive on the root --------------------------------
+def _oracle_unit_encoder():
+    """CPU stand-in for the per-unit HIP encoders (test infrastructure): the oracle's coders on one component / plane."""
+    from oracle import oracle as O
+    from trico_amd.parallel import STREAM_SHAPES
+
+    def encode(name, data, count, unit):
+        _, arity, width, _, per = STREAM_SHAPES[name]
+        if arity is not None:
+            comp = np.ascontiguousarray(data.reshape(-1, arity)[:, unit])
+            pay = O.fpc_encode(comp)
+        else:
+            plane = np.ascontiguousarray(data.view(np.uint8).reshape(-1, width)[:, unit])
+            pay = O.lz4_compress(plane.tobytes())
+        return torch.from_numpy(np.frombuffer(bytes(pay), np.uint8).copy())
+    return encode
+
+
+def _streams_for(kind):
+    from streams import mesh_streams
+    return mesh_streams(kind, 40, 24)
+
+
+def _shard_worker(rank, world, port, kind, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from trico_amd import api
+    from trico_amd.parallel import sharded_write
+    a = sharded_write(dist, api, _streams_for(kind), _oracle_unit_encoder(), root=0)
+    if rank == 0:
+        q.put(a.tobytes())
+        a.close()
+    else:
+        assert a is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind", [(2, "grid"), (3, "grid"), (3, "multi")])
+def test_stream_sharded_archive_is_the_single_rank_archive(world, kind, native_libs):
+    """Rank r encodes units r, r + world, ... of ONE mesh (x, y, z, b1..b4; for `multi` 3 + 3 + 2 components and 8 planes);
+    the root frames the gathered payloads with trico_hip_append_encoded_stream.  The result must be the archive the
+    reference's writer sequence produces (here: the oracle's), byte for byte."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30500 + world * 11 + (os.getpid() % 500) + (7 if kind == "multi" else 0)
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    o = O.OracleArchive()
+    for name, data, count in _streams_for(kind):
+        o.write(name, data, count)
+    want = o.tobytes()
+    o.close()
+    assert got == want

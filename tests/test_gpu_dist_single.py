@@ -46,3 +46,48 @@ def test_nccl_world1_gather(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r = subprocess.run([sys.executable, "-c", WORKER % ROOT], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
+
+
+SHARD_WORKER = r'''
+import os, sys, hashlib, json
+sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, torch
+import torch.distributed as dist
+from trico_amd import api
+from trico_amd.parallel import sharded_write, hip_unit_encoder, CComm
+from streams import mesh_streams
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+torch.cuda.set_device(0)
+hashes = json.load(open(os.path.join(%r, "tests", "golden", "hashes.json")))
+enc = hip_unit_encoder(api)
+comm = CComm(api, 0, 1, lambda b: b)          # RCCL through the C-ABI (world 1: the id needs no broadcast)
+for kind in ("grid", "multi"):
+    streams = mesh_streams(kind, 1000, 1000)
+    dev = [(n, torch.from_numpy(a.view(np.uint8)).cuda(), c) for n, a, c in streams]
+    for transport in ("torch", "c"):
+        a = sharded_write(dist, api, dev, enc, root=0, device_archive=True, gather=(lambda t: comm.gather(t, 0)) if transport == "c" else None)
+        blob = a.tobytes()
+        a.close()
+        g = hashes["%%s_1000x1000" %% kind]
+        assert len(blob) == g["size"], (kind, transport, len(blob), g["size"])
+        assert hashlib.sha256(blob).hexdigest() == g["sha256"], (kind, transport)
+comm.close()
+enc.close()
+dist.destroy_process_group()
+print("OK")
+'''
+
+
+def test_stream_sharded_write_on_the_gpu_matches_the_reference_archive():
+    """The unit encoders (trico_hip_fpc_encode_component / _int_encode_plane), the assembly
+    (trico_hip_append_encoded_stream) and both exchanges (torch.distributed nccl, and RCCL behind trico_hip_comm_*) at
+    world size 1: the archive assembled from separately encoded units is the reference's (sha256 of config 1 and its
+    multi sibling)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, "-c", SHARD_WORKER % (ROOT, ROOT, ROOT)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-500:] + r.stderr[-2500:]

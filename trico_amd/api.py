@@ -148,6 +148,21 @@ def lib():
     L.trico_hip_profile_reset.restype = None
     L.trico_hip_profile_ms.argtypes = [ci, ctypes.POINTER(u64)]
     L.trico_hip_profile_ms.restype = ctypes.c_double
+    # stream-sharded encoding + RCCL exchange (dist.hip)
+    L.trico_hip_fpc_encode_component.argtypes = [vp, vp, u32, ci, ci, ci, ctypes.POINTER(u32)]
+    L.trico_hip_fpc_encode_component.restype = ci
+    L.trico_hip_int_encode_plane.argtypes = [vp, vp, u32, ci, ci, ctypes.POINTER(u32)]
+    L.trico_hip_int_encode_plane.restype = ci
+    L.trico_hip_append_encoded_stream.argtypes = [vp, ci, u32, ci, ctypes.POINTER(vp), ctypes.POINTER(u32)]
+    L.trico_hip_append_encoded_stream.restype = ci
+    L.trico_hip_comm_unique_id.argtypes = [vp]
+    L.trico_hip_comm_unique_id.restype = ci
+    L.trico_hip_comm_create.argtypes = [vp, ci, ci]
+    L.trico_hip_comm_create.restype = vp
+    L.trico_hip_comm_destroy.argtypes = [vp]
+    L.trico_hip_comm_destroy.restype = None
+    L.trico_hip_comm_gather.argtypes = [vp, vp, u64, ci, vp, u64, ctypes.POINTER(u64)]
+    L.trico_hip_comm_gather.restype = ci
     _lib = L
     return L
 
@@ -162,8 +177,10 @@ def ptr(x):
         return x.ctypes.data
     if hasattr(x, "data_ptr"):
         return x.data_ptr()
-    if isinstance(x, (bytes, bytearray)):
-        return ctypes.cast(ctypes.c_char_p(bytes(x)), ctypes.c_void_p).value
+    if isinstance(x, bytes):
+        return ctypes.cast(ctypes.c_char_p(x), ctypes.c_void_p).value      # the bytes object itself: the caller keeps it alive
+    if isinstance(x, bytearray):
+        return ctypes.addressof((ctypes.c_char * len(x)).from_buffer(x))    # in place, no temporary copy
     return ctypes.addressof(x)
 
 
@@ -220,6 +237,13 @@ class Archive:
     # write side
     def write(self, name, data, count):
         return getattr(lib(), "trico_write_" + name)(self.h, ptr(data), count)
+
+    def append_encoded_stream(self, stream_type, count_field, payloads, sizes):
+        """trico_hip_append_encoded_stream: payloads = addresses / tensors / arrays of already encoded units."""
+        n = len(payloads)
+        pp = (ctypes.c_void_p * n)(*[ptr(p) for p in payloads])
+        ss = (ctypes.c_uint32 * n)(*sizes)
+        return lib().trico_hip_append_encoded_stream(self.h, stream_type, count_field, n, pp, ss)
 
     def get_size(self):
         return lib().trico_get_size(self.h)

@@ -67,7 +67,7 @@ def build(force=False, verbose=True):
                   "-c", src, "-o", obj])
         objs.append(obj)
     if force or _stale(LIBTRICO, objs):
-        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIBTRICO] + objs)
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIBTRICO] + objs + ["-ldl"])
     mg = os.path.join(CSRC, "tools", "meshgen.c")
     if force or _stale(LIBMESHGEN, [mg]):
         _run([CC, "-O2", "-std=c11", "-fPIC", "-fvisibility=hidden", "-shared", mg, "-o", LIBMESHGEN])

@@ -38,6 +38,7 @@ struct trico_hip_ctx
   trico::DevBuf tmp;       // planes, SoA intermediates, predictor tables
   trico::DevBuf aux;       // small: sizes, status words, segment summaries
   trico::DevBuf ws;        // large kernel workspaces (chunked LZ4 descriptors / tables)
+  trico::DevBuf unit;      // de-interleaved components / planes of the unit encoders (dist.hip)
   size_t out_stride = 0;
   uint32_t out_sizes[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
   uint32_t out_sizes_raw[24] = { 0 };

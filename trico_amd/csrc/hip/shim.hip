@@ -250,6 +250,7 @@ void trico_hip_ctx_destroy(trico_hip_ctx* ctx)
   ctx->tmp.release();
   ctx->aux.release();
   ctx->ws.release();
+  ctx->unit.release();
   if (ctx->h_pinned)
     (void)hipHostFree(ctx->h_pinned);
   delete ctx;

@@ -314,6 +314,48 @@ static int append_stream(struct trico_archive* a, enum trico_stream_type st, uin
   return 1;
   }
 
+
+/* a stream framed from units that were encoded elsewhere (other contexts, other GPUs): same bytes as append_stream */
+int trico_hip_append_encoded_stream(void* archive, int stream_type, uint32_t count_field, int nunits,
+                                    const void* const* payloads, const uint32_t* sizes)
+  {
+  struct trico_archive* a = (struct trico_archive*)archive;
+  if (!a || !a->writable || nunits < 1 || nunits > 8 || stream_type < 1 || stream_type > 20 || !payloads || !sizes)
+    return 0;
+  uint64_t total = 5;
+  for (int c = 0; c < nunits; ++c)
+    {
+    if (!payloads[c] && sizes[c])
+      return 0;
+    total += 4 + (uint64_t)sizes[c];
+    }
+  if (!reserve(a, total))
+    return 0;
+  const uint64_t rollback = a->used;
+  uint8_t head[5];
+  head[0] = (uint8_t)stream_type;
+  store_le32(head + 1, count_field);
+  int ok = put_host(a, head, 5);
+  for (int c = 0; ok && c < nunits; ++c)
+    {
+    uint8_t nb[4];
+    store_le32(nb, sizes[c]);
+    ok = put_host(a, nb, 4);
+    if (ok && sizes[c])
+      {
+      /* host archive + host payload needs no device; every other combination is a HIP copy */
+      if (!a->buffer_on_device && !trico_hip_pointer_is_device(payloads[c]))
+        memcpy(a->buffer + a->used, payloads[c], sizes[c]);
+      else
+        ok = trico_hip_copy(a->buffer + a->used, payloads[c], sizes[c]);
+      a->used += sizes[c];
+      }
+    }
+  if (!ok)
+    a->used = rollback;
+  return ok;
+  }
+
 static int write_fp_stream(void* archive, enum trico_stream_type st, uint32_t count_field,
                            const void* data, uint32_t n, int arity, int width)
   {
