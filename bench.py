@@ -112,6 +112,11 @@ def parse():
     ap.add_argument("--cpu-sample", default="full", help="WxH of the CPU baseline's mesh; 'full' = the GPU's own mesh")
     ap.add_argument("--concurrent", type=int, default=8, help="archives decoded at once in the decode_concurrent block (0: skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the walk mesh, PCIe-inclusive and concurrent-decode blocks")
+    ap.add_argument("--shard", default="meshes", choices=["meshes", "streams"],
+                    help="N > 1: 'meshes' = one mesh per GPU (BASELINE configs[3], weak scaling); 'streams' = ONE mesh, its component "
+                         "streams and byte planes spread over the GPUs and assembled into one archive on rank 0 (strong scaling)")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "c"],
+                    help="transport of the gather: torch.distributed (nccl = RCCL) or the RCCL entry of the C-ABI (trico_hip_comm_*)")
     return ap.parse_args()
 
 
@@ -329,26 +334,33 @@ def extras(args, api, meshgen, dev, d_v, d_t, nv, nt, raw_bytes):
 
 def main():
     args = parse()
+    # RCCL prints a version banner on stdout when it initialises; the driver wants exactly one JSON line there.  Everything
+    # this process (and the libraries it loads) writes to fd 1 goes to stderr; the JSON line is written to the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or args.shard == "streams":
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     from trico_amd import api, meshgen
-    from trico_amd.parallel import gather_archives, wrap_device_bytes
+    from trico_amd.parallel import gather_archives, wrap_device_bytes, sharded_write, hip_unit_encoder, CComm
     L = api.lib()
     if not L.trico_hip_available():
         raise SystemExit("bench.py: no HIP device: " + api.last_error())
 
     W, H = args.W, args.H
     nv, nt = W * H, 2 * W * H
-    seed = (meshgen.GRID_SEED if args.mesh == "grid" else meshgen.WALK_SEED) + rank
+    sharded = args.shard == "streams"
+    seed = (meshgen.GRID_SEED if args.mesh == "grid" else meshgen.WALK_SEED) + (0 if sharded else rank)
     gen = meshgen.grid if args.mesh == "grid" else meshgen.walk
     v, t = gen(W, H, seed)
     d_v = torch.from_numpy(v).to(dev)
@@ -363,8 +375,51 @@ def main():
         torch.cuda.synchronize()
 
     state = {}
+    comm = None
+    if dist is not None and args.exchange == "c":
+        def share(b):
+            box = [b]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        comm = CComm(api, rank, world, share)
+    unit_encoder = hip_unit_encoder(api) if sharded else None
+
+    def step_sharded(check=False):
+        """ONE mesh: every rank encodes its share of the 7 units (x, y, z, b1..b4), one exchange, rank 0 frames the archive and
+        decodes it."""
+        te0 = time.perf_counter()
+        a = sharded_write(dist, api, [("vertices", d_v, nv), ("triangles", d_t, nt)], unit_encoder, root=0, device_archive=True,
+                          gather=(lambda t: comm.gather(t, 0)) if comm is not None else None)
+        torch.cuda.synchronize()
+        te1 = time.perf_counter()
+        td1 = te1
+        if rank == 0:
+            size = a.get_size()
+            r = api.Archive.open_for_reading(a.get_buffer_pointer(), size)
+            assert r.read("vertices", d_v2) == 1 and r.read("triangles", d_t2) == 1, api.last_error()
+            torch.cuda.synchronize()
+            td1 = time.perf_counter()
+            if check:
+                blob = a.tobytes()
+                state["archive_bytes"] = len(blob)
+                state["sha256"] = hashlib.sha256(blob).hexdigest()
+                state["roundtrip_ok"] = bool(torch.equal(d_v2.view(torch.int32), d_v.view(torch.int32)) and torch.equal(d_t2, d_t))
+                import struct
+                pos, vp = 8 + 5, 0
+                for _ in range(3):
+                    nb = struct.unpack_from("<I", blob, pos)[0]
+                    vp += nb
+                    pos += 4 + nb
+                state["vertex_payload_bytes"] = vp
+            r.close()
+            a.close()
+        elif check:
+            state.update(archive_bytes=0, sha256=None, roundtrip_ok=True, vertex_payload_bytes=0)
+        return te1 - te0, 0.0, td1 - te1
 
     def step(check=False):
+        if sharded:
+            return step_sharded(check)
         te0 = time.perf_counter()
         a = api.Archive.open_for_writing(raw_bytes // 4, device=True)      # caller-chosen initial size: no regrowth
         assert a.write("vertices", d_v, nv) == 1, api.last_error()
@@ -373,7 +428,8 @@ def main():
         te1 = time.perf_counter()
         size = a.get_size()
         if dist is not None:
-            gathered = gather_archives(dist, wrap_device_bytes(a.get_buffer_pointer(), size, dev), dst=0)
+            local = wrap_device_bytes(a.get_buffer_pointer(), size, dev)
+            gathered = comm.gather(local, 0) if comm is not None else gather_archives(dist, local, dst=0)
             torch.cuda.synchronize()
             state["gathered_bytes"] = gathered
         tg1 = time.perf_counter()
@@ -407,10 +463,10 @@ def main():
     golden = None
     hp = os.path.join(ROOT, "tests", "golden", "hashes.json")
     if os.path.exists(hp):
-        key = "%s_%dx%d" % (args.mesh, W, H) + ("" if rank == 0 else "_seed%08x" % seed)
+        key = "%s_%dx%d" % (args.mesh, W, H) + ("" if (rank == 0 or sharded) else "_seed%08x" % seed)
         golden = json.load(open(hp)).get(key)
     parity = "unchecked (no golden for this size)"
-    if golden is not None:
+    if golden is not None and state["sha256"] is not None:
         if golden["sha256"] != state["sha256"]:
             raise SystemExit("bench.py: archive sha256 differs from the reference's golden on rank %d" % rank)
         parity = "sha256 == reference golden"
@@ -443,7 +499,7 @@ def main():
     L.trico_hip_profile_enable(0)
 
     if rank == 0:
-        total_raw = raw_bytes * world
+        total_raw = raw_bytes * (1 if sharded else world)
         step_s = elapsed[0] / args.steps
         fe = kms.get("fpc32_encode", {"avg_ms": float("nan")})
         alg_bytes = v.nbytes + state["vertex_payload_bytes"]
@@ -455,13 +511,16 @@ def main():
             "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(step_s * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "%s(%d,%d): %d float xyz vertices + %d uint32 triangles per GPU (BASELINE configs[1]%s), "
                                    "device-resident raw arrays -> .trc archive in HBM -> decoded arrays in HBM"
                                    % (args.mesh, W, H, nv, nt, "" if world == 1 else "; one mesh per GPU, RCCL gather of archives to rank 0 (configs[3])"),
                        "raw_bytes_per_gpu": raw_bytes, "archive_bytes_rank0": state["archive_bytes"], "parity": parity,
-                       "parallelism": "1 process per GPU, %d independent meshes" % world},
+                       "parallelism": ("1 process per GPU, ONE mesh: 7 stream units (x, y, z, b1..b4) round-robin over %d ranks, payload gather, "
+                                       "archive assembled and decoded on rank 0" % world) if sharded
+                                      else "1 process per GPU, %d independent meshes" % world,
+                       "exchange": "RCCL through the C-ABI (trico_hip_comm_gather)" if comm is not None else "torch.distributed (nccl = RCCL)"},
             "encode_GBps": round(total_raw / (elapsed[1] / args.steps) / 1e9, 4),
             "decode_GBps": round(total_raw / (elapsed[3] / args.steps) / 1e9, 4),
             "gather_ms": round(elapsed[2] / args.steps * 1e3, 3),
@@ -480,7 +539,12 @@ def main():
                 cw, ch = (int(x) for x in args.cpu_sample.split("x"))
                 cv, ct = gen(cw, ch)
                 out["cpu_baseline"] = cpu_baseline(args.mesh, cw, ch, cv, ct)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if unit_encoder is not None:
+        unit_encoder.close()
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
