@@ -48,7 +48,7 @@ bool force_serial_stage(int bit) { return (serial_mask() & bit) != 0; }
 // Device workspaces are recycled across contexts (one context per archive handle): hipMalloc / hipFree of
 // multi-GB buffers cost hundreds of milliseconds and an implicit device sync each.
 struct PoolEntry { uint8_t* p; size_t cap; };
-static PoolEntry g_pool[24];
+static PoolEntry g_pool[160];   // eight archives read at once park ~8 x 2 streams x 5 buffers
 static int g_pool_n = 0;
 static std::mutex g_pool_mutex;
 
