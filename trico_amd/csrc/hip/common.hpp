@@ -137,6 +137,12 @@ int launch_lz4_encode_wave(const uint8_t* d_planes, size_t plane_stride, uint32_
 int launch_lz4_decode_lds(const uint8_t* const d_payloads[8], const uint32_t sizes[8], int nplanes,
                           uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, uint32_t* d_status);
 
+// data-parallel LZ4 decompressor (k_lz4_pdecode.hip): planes of at least lz4_pdecode_threshold() bytes
+uint32_t lz4_pdecode_threshold();
+size_t lz4_pdecode_workspace(uint32_t plane_bytes, const uint32_t* sizes, int nplanes);
+int launch_lz4_decode_parallel(const uint8_t* const d_payloads[8], const uint32_t sizes[8], int nplanes, uint8_t* d_planes, size_t plane_stride,
+                               uint32_t plane_bytes, uint32_t* d_status, uint8_t* d_ws, size_t ws_bytes);
+
 // chunk-speculative exact LZ4 compressor for large planes (k_lz4_chunked.hip)
 uint32_t lz4_chunked_threshold();
 size_t lz4_chunked_workspace(uint32_t n, int nplanes, size_t plane_stride);

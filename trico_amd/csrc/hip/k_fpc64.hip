@@ -296,8 +296,17 @@ __global__ void __launch_bounds__(64) k_fpc64_decode(DecodeArgs args, int arity,
     if (lane == 0) atomicOr(status, 2u);
     return;
     }
-  const u64* T1 = tables + (size_t)comp * 2 * TSIZE;      // zeroed by the launcher (fpsc.c:822-833)
+  const u64* T1 = tables + (size_t)comp * 2 * TSIZE;
   const u64* T2 = T1 + TSIZE;
+  // The tables start at zero (fpsc.c:822-833).  They are zeroed HERE, through the scalar cache this wave will read them
+  // through, so that no stale line of an earlier kernel that used the same buffer can be hit (2 x 8 MiB = 1 M stores of 16
+  // bytes, ~3 ms; the launcher's memset only covers what the vector side might read).
+  for (uint32_t off = 0; off < 2u * TSIZE * 8u; off += 64u)
+    asm volatile("s_mov_b64 s[40:41], 0\n s_mov_b64 s[42:43], 0\n"
+                 "s_store_dwordx4 s[40:43], %0, %1\n s_store_dwordx4 s[40:43], %0, %2\n"
+                 "s_store_dwordx4 s[40:43], %0, %3\n s_store_dwordx4 s[40:43], %0, %4"
+                 :: "s"(T1), "s"(off), "s"(off + 16u), "s"(off + 32u), "s"(off + 48u) : "s40", "s41", "s42", "s43", "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const u64 m1 = (1ull << e1) - 1ull, m2 = (1ull << e2) - 1ull;
   const uint32_t sh1 = 64u - e1, sh2 = 64u - e2, e2h = e2 >> 1;
   const uint32_t al = (uint32_t)((uintptr_t)in & 3u);

@@ -1,0 +1,547 @@
+// k_lz4_pdecode.hip — data-parallel LZ4 block decompressor.
+//
+// Replaces LZ4_decompress_safe (lz4.c:2078-2083 -> LZ4_decompress_generic lz4.c:1657-2072) as called per byte plane by the
+// readers (trico.c:1100-1129), with the acceptance rules of k_lz4_decode.hip (in-bounds input, literal and match runs inside
+// the output, offsets that are neither zero nor reach before the start, exact output size) and a status word for anything else.
+//
+// A block is one chain of sequences (token, literal run, offset, match), every match possibly reading what an earlier
+// sequence wrote: decoded in order, a plane of short sequences (43 M sequences of 7 bytes in a scanned-mesh-like index plane)
+// is one dependent chain of seconds.  Both dependences are broken here:
+//   * WHERE the sequences are.  The compressed bytes are cut into tiles.  One wave per tile starts parsing a little
+//     before its tile at an arbitrary byte; a wrong start falls into step with the real chain after a few sequences
+//     (every hop lands on a real token with probability ~1 / sequence length).  The tile records the first token it sees
+//     inside the tile, where its walk leaves the tile, and the sequences / output bytes in between (k_pd_tiles).  A
+//     single wave then follows the chain from position 0 through those records: a tile whose first token is exactly
+//     where its predecessor's walk arrived was walked from a true token, so its record is exact; the (rare) others are
+//     re-walked on the spot (k_pd_chain).  That also yields every tile's first output position.
+//   * WHAT the bytes are.  Every output byte gets a 32-bit source: a position in the compressed input (literal) or an
+//     earlier output position (match), written by one wave per tile (k_pd_fill; runs of 1 KiB and more go to a job
+//     list worked off by whole workgroups, k_pd_jobs).  Pointer jumping (src[i] = src[src[i]]) resolves chains of matches in
+//     log2(longest chain) rounds without any ordering between threads (k_pd_jump), and a gather produces the plane
+//     (k_pd_gather).
+// Nothing waits on the host: the jump rounds are launched up front and return at once when the previous round changed
+// nothing.  Traffic: ~4 B written + 12 B per round and output byte; planes are decoded one after the other in one workspace.
+#include "common.hpp"
+#include <stdlib.h>
+
+namespace trico {
+
+namespace {
+
+constexpr uint32_t PD_TILE = 8192;            // compressed bytes per tile
+constexpr uint32_t PD_LEAD = 1024;            // a tile's walk starts this many bytes before the tile
+constexpr uint32_t PD_STAGE = PD_LEAD + PD_TILE + 512;   // bytes of a tile staged in LDS (dword aligned base)
+constexpr uint32_t PD_LONG = 1024;            // runs from this length go to the job list ...
+constexpr uint32_t PD_PIECE = 65536;          // ... in pieces of at most this many bytes
+constexpr uint32_t PD_END = 0xffffffffu;      // "walk ended with the last sequence of the block"
+constexpr uint32_t PD_NONE = 0xfffffffeu;     // "no token seen / walk failed"
+constexpr uint32_t PD_FINAL = 0x80000000u;    // src word: low 31 bits index the compressed input (else: an output index)
+constexpr int PD_ROUNDS = 31;                 // chains are shorter than 2^31
+
+struct Tile { uint32_t first, exit, nseq, pad; unsigned long long obytes; };
+struct Job { uint32_t op, len, kind, a; };    // kind 0: literals from input position a; 1: match at offset a
+struct Ctl { uint32_t error, njobs, changed, done, total_seq, pad[3]; };
+
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+
+// bytes of the compressed block: from the tile's LDS image when they are there
+struct Bytes
+  {
+  const uint8_t* in;
+  const uint8_t* lds;          // lds - al is dword aligned (al = base's misalignment inside the global buffer)
+  uint32_t base, staged, clen, al;
+  __device__ __forceinline__ uint32_t at(uint32_t pos) const
+    {
+    const uint32_t r = pos - base;
+    return r < staged ? lds[r] : (pos < clen ? in[pos] : 0u);
+    }
+  // bytes pos .. pos + 7, little endian (zeros beyond the block): one LDS round trip when the image holds them
+  __device__ __forceinline__ uint64_t at8(uint32_t pos) const
+    {
+    const uint32_t r = pos - base;
+    if (r + 12u <= staged && r < staged)
+      {
+      const uint32_t o = r + al;                                  // offset from the aligned LDS base
+      const uint32_t* w = (const uint32_t*)(lds - al) + (o >> 2);
+      const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+      const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, o & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, o & 3u);
+      return ((uint64_t)hi << 32) | lo;
+      }
+    uint64_t v = 0;
+    for (uint32_t k = 0; k < 8u; ++k)
+      v |= (uint64_t)at(pos + k) << (8u * k);
+    return v;
+    }
+  };
+
+struct Seq { uint32_t lit_pos, lit_len, off, mlen, next; int kind; };   // kind 0: literals + match, 1: last (literals only), 2: malformed
+
+// length extension bytes starting at q (lz4.c:1702-1710): adds them to `len`, advances q past them.  All 64 lanes of the wave
+// call this together with the same arguments: 64 bytes per round (a 30 KiB match has 118 extension bytes).  false: malformed.
+__device__ __forceinline__ bool ext_length(const Bytes& b, uint32_t& q, uint32_t& len, int lane)
+  {
+  for (;;)
+    {
+    const uint32_t pos = q + (uint32_t)lane;
+    const uint32_t x = pos < b.clen ? b.at(pos) : 0x100u;          // beyond the block: stops the run, flagged below
+    const uint64_t stop = __ballot(x != 255u);
+    if (stop)
+      {
+      const int k = __builtin_ctzll(stop);
+      const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)x, k);
+      if (last > 255u)
+        return false;                                              // the run reaches the end of the block
+      const uint64_t add = 255ull * (uint32_t)k + last;
+      if (add + len > 0x7fffffffull)
+        return false;
+      len += (uint32_t)add;
+      q += (uint32_t)k + 1u;
+      return true;
+      }
+    if (len > 0x7fffffffu - 255u * 64u)
+      return false;
+    len += 255u * 64u;
+    q += 64u;
+    }
+  }
+
+// one sequence starting at p.  Wave-uniform: every lane calls it with the same p.
+__device__ __forceinline__ void parse_seq(const Bytes& b, uint32_t p, Seq& s, int lane)
+  {
+  s.kind = 2;
+  s.off = 0; s.mlen = 0; s.lit_len = 0; s.lit_pos = p; s.next = p;
+  if (p >= b.clen)
+    return;
+  uint64_t w = b.at8(p);
+  const uint32_t tok = (uint32_t)w & 255u;
+  uint32_t q = p + 1u;
+  uint32_t ll = tok >> 4;
+  if (ll == 15u && !ext_length(b, q, ll, lane))
+    return;
+  s.lit_pos = q;
+  s.lit_len = ll;
+  if (ll > b.clen - q)
+    return;
+  q += ll;
+  if (q == b.clen)
+    {
+    s.kind = 1;                                  // last sequence: literals only (lz4.c:1757-1790)
+    s.next = q;
+    return;
+    }
+  if (b.clen - q < 2u)
+    return;
+  // offset (+ the first extension byte of the match length) usually sit in the 8 bytes already fetched
+  uint32_t o2;
+  if (q + 2u <= p + 8u)
+    o2 = (uint32_t)(w >> (8u * (q - p))) & 0xffffu;
+  else
+    o2 = (uint32_t)b.at8(q) & 0xffffu;
+  s.off = o2;
+  q += 2u;
+  uint32_t ml = tok & 15u;
+  if (ml == 15u && !ext_length(b, q, ml, lane))
+    return;
+  s.mlen = ml + 4u;
+  s.next = q;
+  s.kind = 0;
+  }
+
+__device__ __forceinline__ void stage_tile(uint32_t* lds, const uint8_t* __restrict__ in, uint32_t clen, uint32_t from, int lane, Bytes& b)
+  {
+  // dword-aligned image of in[from .. from + PD_STAGE)
+  const uint32_t al = (uint32_t)((uintptr_t)(in + from) & 3u);
+  const uint8_t* a = in + from - al;
+  const uint32_t avail = clen - from + al;                    // bytes from a to the end of the block
+  const uint32_t want = PD_STAGE < avail ? PD_STAGE : avail;
+  for (uint32_t i = (uint32_t)lane; 4u * i < want; i += 64u)
+    {
+    uint32_t w = 0;
+    if (4u * i + 4u <= avail)
+      w = ((const uint32_t*)a)[i];
+    else
+      for (uint32_t k = 0; 4u * i + k < avail; ++k)
+        w |= (uint32_t)a[4u * i + k] << (8u * k);
+    lds[i] = w;
+    }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  b.in = in;
+  b.lds = (const uint8_t*)lds + al;
+  b.base = from;
+  b.staged = want - al;
+  b.clen = clen;
+  b.al = al;
+  }
+
+// walk from `start`: first token at or after lo, position where the walk reaches hi (or PD_END), sequences and output bytes from
+// that first token on.  A malformed sequence ends the walk with exit = PD_NONE.
+__device__ __forceinline__ void walk_tile(const Bytes& b, uint32_t start, uint32_t lo, uint32_t hi, Tile& t, int lane)
+  {
+  t.first = PD_NONE; t.exit = PD_NONE; t.nseq = 0; t.pad = 0; t.obytes = 0;
+  uint32_t p = start;
+  for (;;)
+    {
+    if (p >= hi)
+      {
+      t.exit = p;
+      if (t.first == PD_NONE) t.first = p;       // nothing starts inside the tile: the chain passes through
+      return;
+      }
+    Seq s;
+    parse_seq(b, p, s, lane);
+    if (s.kind == 2)
+      return;
+    if (p >= lo && t.first == PD_NONE)
+      t.first = p;
+    if (t.first != PD_NONE)
+      {
+      ++t.nseq;
+      t.obytes += (unsigned long long)s.lit_len + s.mlen;
+      }
+    if (s.kind == 1)
+      {
+      t.exit = PD_END;
+      return;
+      }
+    p = s.next;
+    }
+  }
+
+__global__ void __launch_bounds__(64) k_pd_tiles(const uint8_t* __restrict__ in, uint32_t clen, uint32_t ntiles, Tile* __restrict__ tiles,
+                                                 uint32_t* __restrict__ onpath, const Tile* __restrict__ prev)
+  {
+  __shared__ uint32_t lds[PD_STAGE / 4 + 2];
+  const int lane = threadIdx.x;
+  const uint32_t t = blockIdx.x;
+  const uint32_t lo = t * PD_TILE, hi = lo + PD_TILE;
+  uint32_t start = lo > PD_LEAD ? lo - PD_LEAD : 0u;
+  if (prev)
+    {
+    // second round: where the predecessor's walk of the first round left its tile.  Even if that walk started at a wrong
+    // byte, it has normally fallen into step with the real chain within its 8 KiB, so this is a real token.
+    if (t == 0)
+      return;
+    const uint32_t e = prev[t - 1].exit;
+    if (e < lo || e >= hi)
+      return;                                       // nothing (known) starts here: keep the record of the first round
+    start = e;
+    }
+  Bytes b;
+  stage_tile(lds, in, clen, start, lane, b);
+  Tile r;
+  walk_tile(b, start, lo, hi, r, lane);           // every lane walks the same chain (uniform control flow, LDS broadcast reads)
+  if (lane == 0)
+    {
+    tiles[t] = r;
+    onpath[t] = 0u;
+    }
+  (void)ntiles;
+  }
+
+// One wave follows the chain of tiles from position 0.  seq_base / out_base: sequences and output bytes before the tile.
+__global__ void __launch_bounds__(64) k_pd_chain(const uint8_t* __restrict__ in, uint32_t clen, uint32_t n, uint32_t ntiles, Tile* __restrict__ tiles,
+                                                 uint32_t* __restrict__ onpath, uint32_t* __restrict__ out_base, Ctl* __restrict__ ctl,
+                                                 uint32_t* __restrict__ status)
+  {
+  constexpr uint32_t WIN = 512;                   // tiles whose records are staged in LDS at a time
+  __shared__ Tile win[WIN];
+  __shared__ uint32_t lds[PD_STAGE / 4 + 2];
+  const int lane = threadIdx.x;
+  uint32_t w0 = 0xffffffffu;
+  uint32_t entry = 0;
+  unsigned long long outp = 0;
+  uint32_t seqs = 0;
+  bool bad = clen == 0u;
+  for (uint32_t guard = 0; !bad && guard <= ntiles; ++guard)
+    {
+    const uint32_t t = entry / PD_TILE;
+    if (t >= ntiles) { bad = true; break; }
+    if (t < w0 || t >= w0 + WIN)
+      {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      w0 = t;
+      for (uint32_t i = (uint32_t)lane; i < WIN && w0 + i < ntiles; i += 64u)
+        win[i] = tiles[w0 + i];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+    Tile r = win[t - w0];
+    if (uni(r.first) != entry)
+      {
+      // the tile's own walk had not fallen into step when it entered the tile (or the chain enters it from far away): walk it
+      // from the true token
+      Bytes b;
+      stage_tile(lds, in, clen, entry, lane, b);
+      walk_tile(b, entry, entry, (t + 1u) * PD_TILE, r, lane);
+      if (lane == 0)
+        tiles[t] = r;
+      }
+    if (uni(r.exit) == PD_NONE) { bad = true; break; }
+    if (lane == 0)
+      {
+      onpath[t] = 1u;
+      out_base[t] = (uint32_t)outp;
+      }
+    outp += r.obytes;
+    seqs += r.nseq;
+    if (outp > n) { bad = true; break; }
+    if (uni(r.exit) == PD_END)
+      break;
+    if (uni(r.exit) <= entry) { bad = true; break; }
+    entry = uni(r.exit);
+    }
+  if (bad || outp != n)
+    {
+    if (lane == 0)
+      {
+      atomicOr(status, 8u);
+      ctl->error = 1u;
+      }
+    }
+  if (lane == 0)
+    ctl->total_seq = seqs;
+  }
+
+// one wave per tile on the chain: source words of its output bytes
+__global__ void __launch_bounds__(64) k_pd_fill(const uint8_t* __restrict__ in, uint32_t clen, uint32_t n, const Tile* __restrict__ tiles,
+                                                const uint32_t* __restrict__ onpath, const uint32_t* __restrict__ out_base,
+                                                uint32_t* __restrict__ src, Job* __restrict__ jobs, uint32_t job_cap, Ctl* __restrict__ ctl,
+                                                uint32_t* __restrict__ status)
+  {
+  __shared__ uint32_t lds[PD_STAGE / 4 + 2];
+  const int lane = threadIdx.x;
+  const uint32_t t = blockIdx.x;
+  if (ctl->error || !onpath[t])
+    return;
+  const Tile r = tiles[t];
+  const uint32_t hi = (t + 1u) * PD_TILE;
+  Bytes b;
+  stage_tile(lds, in, clen, r.first, lane, b);
+  uint32_t p = r.first;
+  uint32_t op = out_base[t];
+  bool bad = false;
+  while (p < hi)
+    {
+    Seq s;
+    parse_seq(b, p, s, lane);
+    if (s.kind == 2) { bad = true; break; }
+    // literals
+    if (s.lit_len > n - op) { bad = true; break; }
+    if (s.lit_len >= PD_LONG)
+      {
+      // pieces of at most PD_PIECE bytes, one workgroup each
+      const uint32_t np = (s.lit_len + PD_PIECE - 1u) / PD_PIECE;
+      uint32_t j0 = 0;
+      if (lane == 0)
+        j0 = atomicAdd(&ctl->njobs, np);
+      j0 = uni(j0);
+      for (uint32_t k = (uint32_t)lane; k < np; k += 64u)
+        if (j0 + k < job_cap)
+          jobs[j0 + k] = Job{ op + k * PD_PIECE, (k + 1u == np) ? s.lit_len - k * PD_PIECE : PD_PIECE, 0u, s.lit_pos + k * PD_PIECE };
+      }
+    else
+      for (uint32_t k = (uint32_t)lane; k < s.lit_len; k += 64u)
+        src[op + k] = PD_FINAL | (s.lit_pos + k);
+    op += s.lit_len;
+    if (s.kind == 1)
+      break;
+    // match (lz4.c:1800-1830: the offset must stay inside what has been written)
+    if (s.off == 0u || s.off > op || s.mlen > n - op) { bad = true; break; }
+    if (s.mlen >= PD_LONG)
+      {
+      const uint32_t np = (s.mlen + PD_PIECE - 1u) / PD_PIECE;
+      uint32_t j0 = 0;
+      if (lane == 0)
+        j0 = atomicAdd(&ctl->njobs, np);
+      j0 = uni(j0);
+      for (uint32_t k = (uint32_t)lane; k < np; k += 64u)
+        if (j0 + k < job_cap)
+          jobs[j0 + k] = Job{ op + k * PD_PIECE, (k + 1u == np) ? s.mlen - k * PD_PIECE : PD_PIECE, 1u, s.off };
+      }
+    else
+      for (uint32_t k = (uint32_t)lane; k < s.mlen; k += 64u)
+        src[op + k] = op + k - s.off;
+    op += s.mlen;
+    p = s.next;
+    }
+  if (bad && lane == 0)
+    {
+    atomicOr(status, 8u);
+    ctl->error = 1u;
+    }
+  }
+
+// long runs: whole workgroups, grid-stride over the job list
+__global__ void __launch_bounds__(256) k_pd_jobs(const Job* __restrict__ jobs, uint32_t job_cap, uint32_t* __restrict__ src, Ctl* __restrict__ ctl,
+                                                 uint32_t* __restrict__ status)
+  {
+  if (ctl->error)
+    return;
+  const uint32_t nj = ctl->njobs;
+  if (nj > job_cap)
+    {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { atomicOr(status, 8u); ctl->error = 1u; }   // cannot happen: the list holds n / PD_LONG + tiles entries
+    return;
+    }
+  for (uint32_t j = blockIdx.x; j < nj; j += gridDim.x)
+    {
+    const Job q = jobs[j];
+    if (q.kind == 0u)
+      for (uint32_t k = threadIdx.x; k < q.len; k += 256u)
+        src[q.op + k] = PD_FINAL | (q.a + k);
+    else
+      for (uint32_t k = threadIdx.x; k < q.len; k += 256u)
+        src[q.op + k] = q.op + k - q.a;
+    }
+  }
+
+// one round of pointer jumping; returns at once when the previous round changed nothing
+__global__ void __launch_bounds__(256) k_pd_jump(uint32_t* __restrict__ src, uint32_t n, Ctl* __restrict__ ctl)
+  {
+  if (ctl->done || ctl->error)
+    return;
+  bool changed = false;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
+    {
+    const uint32_t s = src[i];
+    if (!(s & PD_FINAL))
+      {
+      // s < i: an earlier output byte; whatever it holds right now is final or a still earlier byte
+      const uint32_t t = __hip_atomic_load(&src[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&src[i], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      changed = true;
+      }
+    }
+  if (__ballot(changed) && (threadIdx.x & 63) == 0)
+    ctl->changed = 1u;
+  }
+
+__global__ void k_pd_round_end(Ctl* __restrict__ ctl)
+  {
+  ctl->done = ctl->changed ? 0u : 1u;
+  ctl->changed = 0u;
+  }
+
+__global__ void __launch_bounds__(256) k_pd_gather(const uint8_t* __restrict__ in, uint32_t clen, const uint32_t* __restrict__ src, uint32_t n,
+                                                   uint8_t* __restrict__ out, Ctl* __restrict__ ctl, uint32_t* __restrict__ status)
+  {
+  if (ctl->error)
+    return;
+  bool bad = false;
+  for (uint32_t i0 = 4u * (blockIdx.x * 256u + threadIdx.x); i0 < n; i0 += 4u * gridDim.x * 256u)
+    {
+    uint32_t w = 0;
+    const uint32_t m = n - i0 < 4u ? n - i0 : 4u;
+    for (uint32_t k = 0; k < m; ++k)
+      {
+      const uint32_t s = src[i0 + k];
+      const uint32_t q = s & ~PD_FINAL;
+      if (!(s & PD_FINAL) || q >= clen)
+        bad = true;
+      else
+        w |= (uint32_t)in[q] << (8u * k);
+      }
+    if (m == 4u && (((uintptr_t)(out + i0)) & 3u) == 0u)
+      *(uint32_t*)(out + i0) = w;
+    else
+      for (uint32_t k = 0; k < m; ++k)
+        out[i0 + k] = (uint8_t)(w >> (8u * k));
+    }
+  if (__ballot(bad) && (threadIdx.x & 63) == 0)
+    atomicOr(status, 8u);                           // a chain that never reached a literal: cannot happen after PD_ROUNDS rounds
+  }
+
+struct PdPlan { size_t tiles, tiles0, onpath, out_base, ctl, jobs, src, total; uint32_t job_cap, max_tiles; };
+
+PdPlan pd_plan(uint32_t plane_bytes, uint32_t max_clen)
+  {
+  PdPlan p;
+  p.max_tiles = (max_clen + PD_TILE - 1) / PD_TILE + 1;
+  p.job_cap = plane_bytes / PD_LONG + 2 * p.max_tiles + 16;    // every job covers >= PD_LONG output bytes or ends a run
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes + 16, 256); return at; };
+  p.tiles = take(sizeof(Tile) * (size_t)p.max_tiles);
+  p.tiles0 = take(sizeof(Tile) * (size_t)p.max_tiles);
+  p.onpath = take(4 * (size_t)p.max_tiles);
+  p.out_base = take(4 * (size_t)p.max_tiles);
+  p.ctl = take(sizeof(Ctl));
+  p.jobs = take(sizeof(Job) * (size_t)p.job_cap);
+  p.src = take(4 * (size_t)plane_bytes);
+  p.total = o;
+  return p;
+  }
+
+} // namespace
+
+uint32_t lz4_pdecode_threshold()
+  {
+  static uint32_t t = 0;
+  if (!t)
+    {
+    const char* e = getenv("TRICO_LZ4_PDECODE_MIN");             // planes of at least this many bytes take the data-parallel decoder
+    t = e ? (uint32_t)strtoul(e, nullptr, 10) : (1u << 20);
+    if (t < 1) t = 1;
+    }
+  return t;
+  }
+
+size_t lz4_pdecode_workspace(uint32_t plane_bytes, const uint32_t* sizes, int nplanes)
+  {
+  uint32_t mx = 0;
+  for (int c = 0; c < nplanes; ++c)
+    mx = sizes[c] > mx ? sizes[c] : mx;
+  return pd_plan(plane_bytes, mx).total;
+  }
+
+int launch_lz4_decode_parallel(const uint8_t* const d_payloads[8], const uint32_t sizes[8], int nplanes, uint8_t* d_planes, size_t plane_stride,
+                               uint32_t plane_bytes, uint32_t* d_status, uint8_t* d_ws, size_t ws_bytes)
+  {
+  uint32_t mx = 0;
+  for (int c = 0; c < nplanes; ++c)
+    mx = sizes[c] > mx ? sizes[c] : mx;
+  const PdPlan p = pd_plan(plane_bytes, mx);
+  if (p.total > ws_bytes)
+    {
+    set_error("lz4 parallel decode: workspace too small");
+    return 0;
+    }
+  hipStream_t st = current_stream();
+  Tile* tiles = (Tile*)(d_ws + p.tiles);
+  Tile* tiles0 = (Tile*)(d_ws + p.tiles0);
+  uint32_t* onpath = (uint32_t*)(d_ws + p.onpath);
+  uint32_t* out_base = (uint32_t*)(d_ws + p.out_base);
+  Ctl* ctl = (Ctl*)(d_ws + p.ctl);
+  Job* jobs = (Job*)(d_ws + p.jobs);
+  uint32_t* src = (uint32_t*)(d_ws + p.src);
+  const unsigned sweep = 2048;                                     // blocks of the element-wise sweeps (grid-stride)
+  for (int c = 0; c < nplanes; ++c)
+    {
+    const uint8_t* in = d_payloads[c];
+    const uint32_t clen = sizes[c];
+    uint8_t* out = d_planes + (size_t)c * plane_stride;
+    const uint32_t nt = (clen + PD_TILE - 1) / PD_TILE;
+    if (!hip_ok(hipMemsetAsync(ctl, 0, sizeof(Ctl), st), "memset(lz4 decode control)"))
+      return 0;
+    if (clen == 0)
+      {
+      // no block at all (an empty plane is the one-byte block 0x00, lz4.c:1146-1172 with n = 0): the chain kernel reports it
+      hipLaunchKernelGGL(k_pd_chain, dim3(1), dim3(64), 0, st, in, clen, plane_bytes, 0u, tiles, onpath, out_base, ctl, d_status);
+      continue;
+      }
+    hipLaunchKernelGGL(k_pd_tiles, dim3(nt), dim3(64), 0, st, in, clen, nt, tiles0, onpath, (const Tile*)nullptr);
+    if (!hip_ok(hipMemcpyAsync(tiles, tiles0, sizeof(Tile) * (size_t)nt, hipMemcpyDeviceToDevice, st), "copy(tile records)"))
+      return 0;
+    hipLaunchKernelGGL(k_pd_tiles, dim3(nt), dim3(64), 0, st, in, clen, nt, tiles, onpath, (const Tile*)tiles0);
+    hipLaunchKernelGGL(k_pd_chain, dim3(1), dim3(64), 0, st, in, clen, plane_bytes, nt, tiles, onpath, out_base, ctl, d_status);
+    hipLaunchKernelGGL(k_pd_fill, dim3(nt), dim3(64), 0, st, in, clen, plane_bytes, tiles, onpath, out_base, src, jobs, p.job_cap, ctl, d_status);
+    hipLaunchKernelGGL(k_pd_jobs, dim3(1024), dim3(256), 0, st, jobs, p.job_cap, src, ctl, d_status);
+    for (int r = 0; r < PD_ROUNDS; ++r)
+      {
+      hipLaunchKernelGGL(k_pd_jump, dim3(sweep), dim3(256), 0, st, src, plane_bytes, ctl);
+      hipLaunchKernelGGL(k_pd_round_end, dim3(1), dim3(1), 0, st, ctl);
+      }
+    hipLaunchKernelGGL(k_pd_gather, dim3(sweep), dim3(256), 0, st, in, clen, src, plane_bytes, out, ctl, d_status);
+    }
+  return hip_ok(hipGetLastError(), "lz4 parallel decode kernels") ? 1 : 0;
+  }
+
+} // namespace trico

@@ -642,8 +642,20 @@ static int int_decode_launch(trico_hip_ctx* ctx, const uint8_t* const payloads[8
   TRICO_HIP_TRY(hipMemsetAsync(d_status, 0, 64, current_stream()));
   {
   ProfSpan span(TRICO_HIP_K_LZ4_DECODE);
-  if (!(force_serial_stage(8) ? launch_lz4_decode_serial(d_pay, sizes, width, d_planes, plane_stride, count, d_status)
-                       : launch_lz4_decode_lds(d_pay, sizes, width, d_planes, plane_stride, count, d_status)))
+  if (force_serial_stage(8))
+    {
+    if (!launch_lz4_decode_serial(d_pay, sizes, width, d_planes, plane_stride, count, d_status))
+      return 0;
+    }
+  else if (count >= lz4_pdecode_threshold() && !getenv("TRICO_LZ4_DECODE_LDS"))
+    {
+    const size_t ws = lz4_pdecode_workspace(count, sizes, width);
+    if (!ctx->ws.reserve(ws))
+      return 0;
+    if (!launch_lz4_decode_parallel(d_pay, sizes, width, d_planes, plane_stride, count, d_status, ctx->ws.p, ctx->ws.cap))
+      return 0;
+    }
+  else if (!launch_lz4_decode_lds(d_pay, sizes, width, d_planes, plane_stride, count, d_status))
     return 0;
   }
   if (width > 1)
