@@ -7,9 +7,10 @@
  * (caller frees), as in the reference.
  *
  * Differences, forced by the missing error channel (the functions return void):
- *   - on failure (no device, unsupported exponents, malformed stream) *out is NULL and the count 0;
- *   - table size exponents are supported up to what the archive API uses: even values 2..4 / 2..10 for floats
- *     (the reference's call passes 4, 10) and 2..20 / 2..20 for doubles (20, 20);
+ *   - on failure (no device, malformed stream, tables that do not fit the device) *out is NULL and the count 0;
+ *   - table size exponents: any value, normalised like the reference does (odd values rounded down, at most 30;
+ *     fpsc.c:88-93, 578-583).  The archive API's (4,10) / (20,20) take the throughput kernels, every other shape the
+ *     reference-order kernel with tables of 2^e1 + 2^e2 entries in device memory;
  *   - the decoders take a HOST pointer: the format does not carry its own length, so the group headers are
  *     walked on the host to find the end of the stream before it is handed to the device (the reference simply
  *     trusts its input, fpsc.c:212-417).

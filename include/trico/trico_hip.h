@@ -48,8 +48,8 @@ TRICO_API int   trico_hip_copy(void* dst, const void* src, size_t bytes);   /* a
  * the next encode and are copied out with trico_hip_fetch_payload. */
 TRICO_API int trico_hip_fpc_encode(trico_hip_ctx* ctx, const void* src, uint32_t n, int arity, int width, uint32_t sizes[3]);
 
-/* Same with explicit table size exponents (the arguments of trico_compress, fpsc.c:86): even values, 2..4 / 2..10
- * for width 4 and 2..20 / 2..20 for width 8 (larger tables than the archive API ever writes are not supported). */
+/* Same with explicit table size exponents (the arguments of trico_compress, fpsc.c:86), normalised like the reference
+ * does (odd values rounded down, at most 30).  Shapes other than the archive API's run in reference order on the device. */
 TRICO_API int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int arity, int width,
                                       uint32_t e1, uint32_t e2, uint32_t sizes[3]);
 

@@ -80,12 +80,24 @@ def test_double_other_exponents(L, e):
     assert _decompress(L, got, np.float64).tobytes() == vals.tobytes()
 
 
-def test_unsupported_exponents_fail_cleanly(L):
-    vals = np.arange(100, dtype=np.float32)
-    assert _compress(L, vals, 6, 10) is None        # FCM table larger than the 16 entries the device path keeps
-    assert _compress(L, vals, 4, 12) is None
-    assert _compress(L, vals, 3, 10) is None        # odd exponents cannot be stored in the header nibble
-    assert _compress(L, np.arange(10, dtype=np.float64), 22, 20) is None
+@pytest.mark.parametrize("e", [(6, 10), (4, 12), (10, 12), (3, 11), (5, 10), (16, 22), (26, 24), (31, 40), (0, 10), (4, 0)])
+def test_float_any_exponents_like_the_reference(L, e):
+    """fpsc.c:88-93: any exponent is legal; odd ones are rounded down, everything above 30 becomes 30.  Tables beyond
+    (4,10) live in global memory.  (31, 40) normalises to (30, 30): two 4 GiB tables."""
+    vals = _data("noisy", 3001, np.float32, np.random.default_rng(sum(e)))
+    got = _compress(L, vals, *e)
+    assert got is not None
+    assert got == O.fpc_encode(vals, *e)
+    assert _decompress(L, got, np.float32).tobytes() == vals.tobytes()
+
+
+@pytest.mark.parametrize("e", [(22, 20), (20, 24), (7, 9), (26, 26), (0, 20)])
+def test_double_any_exponents_like_the_reference(L, e):
+    vals = _data("steps", 2005, np.float64, np.random.default_rng(sum(e)))
+    got = _compress(L, vals, *e)
+    assert got is not None
+    assert got == O.fpc_encode(vals, *e)
+    assert _decompress(L, got, np.float64).tobytes() == vals.tobytes()
 
 
 def _ptrs(arrs):

@@ -84,8 +84,10 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // serial reference-order kernels (k_serial.hip): one workgroup per component stream / plane.
 int launch_fpc_encode_serial(const void* d_src, uint32_t n, int arity, int width, uint8_t* d_out, size_t out_stride,
                              uint32_t* d_sizes, uint64_t* d_tables, unsigned e1, unsigned e2);
+// d_tables: zeroed scratch, component c at c * table_stride entries of `width` bytes (tables of 2^e1 + 2^e2 entries each); encode
+// side: c * (2^e1 + 2^e2).  Float streams with exponents up to (4,10) keep their tables in LDS and need none.
 int launch_fpc_decode_serial(const uint8_t* const d_payloads[3], const uint32_t sizes[3], int arity, int width,
-                             uint32_t n, void* d_dst, uint64_t* d_tables, uint32_t* d_status);
+                             uint32_t n, void* d_dst, uint64_t* d_tables, size_t table_stride, uint32_t* d_status);
 int launch_lz4_encode_serial(const uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, int nplanes, uint8_t* d_out,
                              size_t out_stride, uint32_t* d_sizes);
 int launch_lz4_decode_serial(const uint8_t* const d_payloads[8], const uint32_t sizes[8], int nplanes,

@@ -39,14 +39,15 @@ __global__ void __launch_bounds__(64) k_fpc_encode_serial(const typename word<W>
                                                           uint8_t* out_base, size_t out_stride, uint32_t* sizes,
                                                           uint64_t* gtables, unsigned E1, unsigned E2)
   {
-  // E1 / E2: table size exponents (even; at most 4 / 10 for W = 32 where the tables live in LDS, 20 / 20 for W = 64)
+  // E1 / E2: table size exponents as the reference normalises them (even, 0..30: fpsc.c:88-93, 578-583).  W = 32 with at most
+  // (4, 10): tables in LDS; otherwise in the zeroed global scratch, component c at c * (2^E1 + 2^E2) entries.
   typedef typename word<W>::type T;
   constexpr unsigned G = (W == 32) ? 8 : 2, WB = W / 8;
   __shared__ T lds_tab[(W == 32) ? (16 + 1024) : 1];
   const int c = blockIdx.x;
   T* T1;
   T* T2;
-  if (W == 32)
+  if (W == 32 && E1 <= 4 && E2 <= 10)
     {
     for (unsigned i = threadIdx.x; i < 16 + 1024; i += blockDim.x)
       lds_tab[i] = 0;
@@ -55,8 +56,8 @@ __global__ void __launch_bounds__(64) k_fpc_encode_serial(const typename word<W>
     }
   else
     {
-    T1 = (T*)(gtables + (size_t)c * 2 * ((size_t)1 << 20));
-    T2 = T1 + ((size_t)1 << 20);
+    T1 = (T*)gtables + (size_t)c * (((size_t)1 << E1) + ((size_t)1 << E2));
+    T2 = T1 + ((size_t)1 << E1);
     }
   __syncthreads();
   if (threadIdx.x != 0)
@@ -75,13 +76,13 @@ __global__ void __launch_bounds__(64) k_fpc_encode_serial(const typename word<W>
     const T v = src[(size_t)i * arity + c];
     const T x1 = v ^ p1;
     T1[h1] = v;
-    h1 = (T)(v >> (W - E1));                       // the shifted-in old hash is masked away entirely
+    h1 = E1 ? (T)(v >> (W - E1)) : (T)0;           // the shifted-in old hash is masked away entirely; exponent 0: one entry
     p1 = T1[h1];
     const T s = v - last;
     const T x2 = v ^ (T)(last + p2);
     last = v;
     T2[h2] = s;
-    h2 = (T)(((h2 << (E2 / 2)) ^ (s >> (W - E2))) & (((T)1 << E2) - 1));
+    h2 = E2 ? (T)(((h2 << (E2 / 2)) ^ (s >> (W - E2))) & (((T)1 << E2) - 1)) : (T)0;
     p2 = T2[h2];
     const unsigned n1 = byte_len(x1);
     unsigned n2 = byte_len(x2);
@@ -122,7 +123,7 @@ struct DecodeArgs
 
 template <int W>
 __global__ void __launch_bounds__(64) k_fpc_decode_serial(DecodeArgs a, int arity, uint32_t n, typename word<W>::type* dst,
-                                                          uint64_t* gtables, uint32_t* status)
+                                                          uint64_t* gtables, size_t gstride, uint32_t* status)
   {
   typedef typename word<W>::type T;
   constexpr unsigned G = (W == 32) ? 8 : 2, WB = W / 8;
@@ -138,11 +139,13 @@ __global__ void __launch_bounds__(64) k_fpc_decode_serial(DecodeArgs a, int arit
     }
   const unsigned e1 = (unsigned)(in[0] >> 4) << 1, e2 = (unsigned)(in[0] & 15) << 1;
   const uint32_t cnt = ((uint32_t)in[1] << 24) | ((uint32_t)in[2] << 16) | ((uint32_t)in[3] << 8) | in[4];
-  // supported table shapes: the ones the archive API writes (trico.c:231,396): (4,10) for
-  // floats in LDS, up to (20,20) for doubles in the zeroed global scratch.
-  bool ok = cnt == n && e1 != 0 && e2 != 0;
-  if (W == 32) ok = ok && e1 <= LDS_E1 && e2 <= LDS_E2;
-  else ok = ok && e1 <= 20 && e2 <= 20;
+  // any table shape the reference can write (fpsc.c:214-217, 580-583: even exponents up to 30): floats up to (4,10) in LDS,
+  // everything else in the zeroed global scratch, component c at c * gstride entries (the launcher sized it from the
+  // header bytes; a payload whose header asks for more than that is refused)
+  bool ok = cnt == n && e1 <= 30 && e2 <= 30;
+  const bool in_lds = W == 32 && e1 <= LDS_E1 && e2 <= LDS_E2;
+  if (!in_lds)
+    ok = ok && gtables != nullptr && (((size_t)1 << e1) + ((size_t)1 << e2)) <= gstride;
   if (!ok)
     {
     if (threadIdx.x == 0) atomicOr(status, 2u);
@@ -150,7 +153,7 @@ __global__ void __launch_bounds__(64) k_fpc_decode_serial(DecodeArgs a, int arit
     }
   T* T1;
   T* T2;
-  if (W == 32)
+  if (in_lds)
     {
     for (unsigned i = threadIdx.x; i < 16 + 1024; i += blockDim.x)
       lds_tab[i] = 0;
@@ -159,8 +162,8 @@ __global__ void __launch_bounds__(64) k_fpc_decode_serial(DecodeArgs a, int arit
     }
   else
     {
-    T1 = (T*)(gtables + (size_t)c * 2 * ((size_t)1 << 20));
-    T2 = T1 + ((size_t)1 << 20);
+    T1 = (T*)gtables + (size_t)c * gstride;
+    T2 = T1 + ((size_t)1 << e1);
     }
   __syncthreads();
   if (threadIdx.x != 0)
@@ -195,11 +198,11 @@ __global__ void __launch_bounds__(64) k_fpc_decode_serial(DecodeArgs a, int arit
       if (code[k] > WB) p1 = p2;
       const T v = xr ^ p1;
       T1[h1] = v;
-      h1 = (T)(((h1 << e1) ^ (v >> (W - e1))) & m1);
+      h1 = e1 ? (T)(((h1 << e1) ^ (v >> (W - e1))) & m1) : (T)0;      // exponent 0: a one-entry table (the reference masks with 0)
       p1 = T1[h1];
       const T s = v - last;
       T2[h2] = s;
-      h2 = (T)(((h2 << (e2 / 2)) ^ (s >> (W - e2))) & m2);
+      h2 = e2 ? (T)(((h2 << (e2 / 2)) ^ (s >> (W - e2))) & m2) : (T)0;
       p2 = (T)(v + T2[h2]);
       last = v;
       dst[(size_t)(i + k) * arity + c] = v;
@@ -376,7 +379,7 @@ int launch_fpc_encode_serial(const void* d_src, uint32_t n, int arity, int width
   }
 
 int launch_fpc_decode_serial(const uint8_t* const d_payloads[3], const uint32_t sizes[3], int arity, int width,
-                             uint32_t n, void* d_dst, uint64_t* d_tables, uint32_t* d_status)
+                             uint32_t n, void* d_dst, uint64_t* d_tables, size_t table_stride, uint32_t* d_status)
   {
   DecodeArgs a;
   for (int c = 0; c < 3; ++c)
@@ -386,10 +389,10 @@ int launch_fpc_decode_serial(const uint8_t* const d_payloads[3], const uint32_t 
     }
   if (width == 4)
     hipLaunchKernelGGL(k_fpc_decode_serial<32>, dim3(arity), dim3(64), 0, current_stream(),
-                       a, arity, n, (uint32_t*)d_dst, d_tables, d_status);
+                       a, arity, n, (uint32_t*)d_dst, d_tables, table_stride, d_status);
   else
     hipLaunchKernelGGL(k_fpc_decode_serial<64>, dim3(arity), dim3(64), 0, current_stream(),
-                       a, arity, n, (uint64_t*)d_dst, d_tables, d_status);
+                       a, arity, n, (uint64_t*)d_dst, d_tables, table_stride, d_status);
   return hip_ok(hipGetLastError(), "k_fpc_decode_serial") ? 1 : 0;
   }
 

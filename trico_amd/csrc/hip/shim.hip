@@ -354,11 +354,10 @@ int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int
     return 0;
     }
   const uint32_t emax1 = width == 4 ? 4u : 20u, emax2 = width == 4 ? 10u : 20u;
-  if (e1 == 0 || e2 == 0 || (e1 & 1u) || (e2 & 1u) || e1 > emax1 || e2 > emax2)
-    {
-    set_error("trico_hip_fpc_encode: table exponents must be even, 2..4 / 2..10 (float) or 2..20 (double)");
-    return 0;
-    }
+  // the reference's normalisation (fpsc.c:88-93, 578-583): odd exponents are rounded down, everything above 30 is 30
+  e1 &= ~1u; e2 &= ~1u;
+  if (e1 > 30u) e1 = 30u;
+  if (e2 > 30u) e2 = 30u;
   const bool defaults = e1 == emax1 && e2 == emax2;
   const size_t in_bytes = (size_t)n * arity * width;
   const size_t stride = align_up(fpc_bound(n, width), 256);
@@ -375,10 +374,12 @@ int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int
   ProfSpan span(width == 4 ? TRICO_HIP_K_FPC32_ENCODE : TRICO_HIP_K_FPC64_ENCODE);
   uint64_t* d_tables = nullptr;
   const bool sorted64 = width == 8 && defaults && !force_serial_stage(1) && n >= fpc64_sorted_threshold() && n <= 0x7fffffffu;
-  if (width == 8 && !sorted64)
+  const bool lds_tables = width == 4 && e1 <= 4u && e2 <= 10u;        // the reference-order kernel keeps such float tables in LDS
+  if (!(width == 4 && defaults && !force_serial_stage(1)) && !sorted64 && !lds_tables)
     {
-    // two 2^20-entry u64 tables per component (fpsc.c:592-593), zeroed per call
-    const size_t tb = (size_t)arity * 2 * ((size_t)1 << 20) * 8;
+    // tables of 2^e1 + 2^e2 entries per component (fpsc.c:96-97, 592-593), zeroed per call.  The API's own (20,20) doubles
+    // need 16 MiB per component; exponent 30 means 8 / 16 GiB per component, which the device has.
+    const size_t tb = (size_t)arity * (((size_t)1 << e1) + ((size_t)1 << e2)) * (size_t)width;
     if (!ctx->tmp.reserve(tb))
       return 0;
     TRICO_HIP_TRY(hipMemsetAsync(ctx->tmp.p, 0, tb, current_stream()));
@@ -463,29 +464,57 @@ static int fpc_decode_launch(trico_hip_ctx* ctx, const uint8_t* const payloads[3
   TRICO_HIP_TRY(hipMemsetAsync(d_status, 0, 64, current_stream()));
   {
   ProfSpan span(width == 4 ? TRICO_HIP_K_FPC32_DECODE : TRICO_HIP_K_FPC64_DECODE);
-  uint64_t* d_tables = nullptr;
-  if (width == 8)
+  // The table sizes come from the payload's hash_info byte (fpsc.c:214-217, 806-809).  The archive API always writes (4,10)
+  // for floats and (20,20) for doubles, which the throughput kernels are built for; any other shape the reference can
+  // write (even exponents up to 30) goes through the reference-order kernel with tables sized from the header.
+  uint32_t e1max = 0, e2max = 0;
+  bool standard = true;
+  for (int c = 0; c < arity; ++c)
     {
-    // table sizes come from the payload's hash_info byte; the archive API always writes (20,20).
-    const size_t tb = (size_t)arity * 2 * ((size_t)1 << 20) * 8;
+    uint8_t hi = 0;
+    if (trico_hip_pointer_is_device(payloads[c]))
+      {
+      TRICO_HIP_TRY(hipMemcpyAsync(ctx->h_pinned, d_pay[c], 1, hipMemcpyDeviceToHost, current_stream()));
+      TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
+      hi = *(const uint8_t*)ctx->h_pinned;
+      }
+    else
+      hi = payloads[c][0];
+    const uint32_t e1 = (uint32_t)(hi >> 4) << 1, e2 = (uint32_t)(hi & 15u) << 1;
+    standard = standard && (width == 4 ? (e1 == 4u && e2 == 10u) : (e1 == 20u && e2 == 20u));
+    e1max = e1 > e1max ? e1 : e1max;
+    e2max = e2 > e2max ? e2 : e2max;
+    }
+  if (e1max > 30u || e2max > 30u)
+    {
+    set_error("trico_hip_fpc_decode: table exponents above 30");
+    return 0;
+    }
+  const size_t table_stride = ((size_t)1 << e1max) + ((size_t)1 << e2max);     // entries per component
+  const bool lds_tables = width == 4 && e1max <= 4u && e2max <= 10u;
+  uint64_t* d_tables = nullptr;
+  if (width == 8 || !lds_tables)
+    {
+    const size_t tb = (size_t)arity * table_stride * (size_t)width;
     if (!ctx->tmp.reserve(tb))
       return 0;
-    TRICO_HIP_TRY(hipMemsetAsync(ctx->tmp.p, 0, tb, current_stream()));
+    if (!standard || force_serial_stage(2))          // the throughput double decoder zeroes its tables itself, through the scalar cache
+      TRICO_HIP_TRY(hipMemsetAsync(ctx->tmp.p, 0, tb, current_stream()));
     d_tables = (uint64_t*)ctx->tmp.p;
     }
-  if (width == 4 && !force_serial_stage(2))
+  if (width == 4 && standard && !force_serial_stage(2))
     {
     if (!ctx->tmp.reserve(3 * FPC32_DECODE_TABLE_BYTES))
       return 0;
     if (!launch_fpc32_decode(d_pay, sizes, arity, n, d_dst, d_status, (uint32_t*)ctx->tmp.p))
       return 0;
     }
-  else if (width == 8 && !force_serial_stage(2))
+  else if (width == 8 && standard && !force_serial_stage(2))
     {
     if (!launch_fpc64_decode(d_pay, sizes, arity, n, d_dst, d_tables, d_status))
       return 0;
     }
-  else if (!launch_fpc_decode_serial(d_pay, sizes, arity, width, n, d_dst, d_tables, d_status))
+  else if (!launch_fpc_decode_serial(d_pay, sizes, arity, width, n, d_dst, d_tables, table_stride, d_status))
     return 0;
   }
   TRICO_HIP_TRY(hipMemcpyAsync(ctx->h_pinned, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, current_stream()));

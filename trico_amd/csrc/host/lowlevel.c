@@ -15,8 +15,9 @@ static void compress_any(uint32_t* payload_bytes, uint8_t** payload, const void*
   {
   *payload = NULL;
   *payload_bytes = 0;
-  if (e1 > 30 || e2 > 30)
-    return;
+  /* any exponent is legal: the reference rounds odd ones down and caps at 30 (fpsc.c:88-93, 578-583); the shim does the same */
+  if (e1 > 30) e1 = 30;
+  if (e2 > 30) e2 = 30;
   trico_hip_ctx* ctx = trico_hip_ctx_create();
   if (!ctx)
     return;
