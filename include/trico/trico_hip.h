@@ -38,6 +38,7 @@ TRICO_API int   trico_hip_pointer_is_device(const void* p);
 TRICO_API void* trico_hip_device_alloc(size_t bytes);
 TRICO_API void  trico_hip_device_free(void* p);
 TRICO_API int   trico_hip_copy(void* dst, const void* src, size_t bytes);   /* any direction, complete on return */
+TRICO_API uint64_t trico_hip_device_free_bytes(void);     /* free device memory right now (0 without a device) */
 
 /* ---- floating-point streams ---------------------------------------------------------------
  * Replaces trico_transpose_*_aos_to_soa (transpose_aos_to_soa.c:8-82) fused with

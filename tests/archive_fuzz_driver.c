@@ -15,6 +15,7 @@ int trico_hip_pointer_is_device(const void* p) { (void)p; return 0; }
 void* trico_hip_device_alloc(size_t n) { (void)n; return NULL; }
 void trico_hip_device_free(void* p) { (void)p; }
 int trico_hip_copy(void* d, const void* s, size_t n) { memcpy(d, s, n); return 1; }
+uint64_t trico_hip_device_free_bytes(void) { return 0; }
 int trico_hip_fpc_encode(trico_hip_ctx* c, const void* s, uint32_t n, int a, int w, uint32_t z[3]) { (void)c; (void)s; (void)n; (void)a; (void)w; (void)z; return 0; }
 int trico_hip_fpc_decode(trico_hip_ctx* c, const uint8_t* const p[3], const uint32_t z[3], int a, int w, uint32_t n, void* d) { (void)c; (void)p; (void)z; (void)a; (void)w; (void)n; (void)d; return 0; }
 int trico_hip_int_encode(trico_hip_ctx* c, const void* s, uint32_t n, int w, uint32_t z[8]) { (void)c; (void)s; (void)n; (void)w; (void)z; return 0; }

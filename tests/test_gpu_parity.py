@@ -138,8 +138,10 @@ def test_double_uv_writer_quirk(api):
     assert got[8] == 5
     r = api.Archive.open_for_reading(got)
     out = np.empty(40, np.float32)
-    assert r.read("uv_per_vertex", out) == 0      # a double payload cannot be read by the float reader
     assert r.read("uv_per_vertex_double", np.empty(40, np.float64)) == 0   # tag is 5, not 6
+    # The float reader accepts the tag.  The payload announces (20,20) tables, which are legal for a float stream too
+    # (fpsc.c:214-217), so it is decoded as one - garbage or a clean failure, like the reference, but never a fault.
+    assert r.read("uv_per_vertex", out) in (0, 1)
     r.close()
 
 

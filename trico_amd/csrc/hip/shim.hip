@@ -281,6 +281,19 @@ int trico_hip_pointer_is_device(const void* p)
   return attr.type == hipMemoryTypeDevice ? 1 : 0;
   }
 
+uint64_t trico_hip_device_free_bytes(void)
+  {
+  if (!device_ready())
+    return 0;
+  size_t fr = 0, total = 0;
+  if (hipMemGetInfo(&fr, &total) != hipSuccess)
+    {
+    (void)hipGetLastError();
+    return 0;
+    }
+  return (uint64_t)fr;
+  }
+
 // device allocations handed to the host code (archive buffers) come from the same pool as the workspaces
 struct LiveAlloc { void* p; size_t cap; };
 static LiveAlloc g_live[64];

@@ -523,11 +523,51 @@ static struct stream_layout layout_of(uint8_t type)
 static int parse_frames(struct trico_archive* a, int ncomp, uint32_t* count, const uint8_t** payloads,
                         uint32_t* sizes, uint64_t* end_pos);
 
+/* device bytes the streams decoded ahead may occupy: TRICO_HIP_READAHEAD_MB (default 64 GiB), but never more than half
+ * of what the device has free right now.  A stream is charged its decoded size plus its working set (staged payload,
+ * byte planes, the 4 bytes per plane byte of the LZ4 decoder, the double tables): three times the output + 64 MiB. */
 static uint64_t readahead_budget(void)
   {
   const char* e = getenv("TRICO_HIP_READAHEAD_MB");
   const uint64_t mb = e ? strtoull(e, NULL, 10) : 65536ull;
-  return mb << 20;
+  uint64_t budget = mb << 20;
+  const uint64_t half_free = trico_hip_device_free_bytes() / 2;
+  if (budget > half_free)
+    budget = half_free;
+  return budget;
+  }
+
+static uint64_t readahead_cost(uint64_t decoded_bytes)
+  {
+  return 3 * decoded_bytes + (64ull << 20);
+  }
+
+/* drops the decode that was started ahead for the stream at the cursor (the caller skips it) */
+static void drop_readahead(struct trico_archive* a)
+  {
+  for (int i = 0; i < a->ra_n; ++i)
+    if (a->ra[i].ctx && a->ra[i].pos == a->pos)
+      {
+      (void)trico_hip_decode_finish(a->ra[i].ctx, NULL);
+      trico_hip_ctx_destroy(a->ra[i].ctx);
+      a->ra[i].ctx = NULL;
+      }
+  }
+
+/* the one-by-one decode of a stream failed while other streams are still parked on the device: give their memory back
+ * (their reads will decode them again, one by one) so that the caller can retry */
+static int drop_all_readahead(struct trico_archive* a)
+  {
+  int dropped = 0;
+  for (int i = 0; i < a->ra_n; ++i)
+    if (a->ra[i].ctx)
+      {
+      (void)trico_hip_decode_finish(a->ra[i].ctx, NULL);
+      trico_hip_ctx_destroy(a->ra[i].ctx);
+      a->ra[i].ctx = NULL;
+      ++dropped;
+      }
+  return dropped;
   }
 
 static void start_readahead(struct trico_archive* a)
@@ -569,7 +609,7 @@ static void start_readahead(struct trico_archive* a)
       break;
     const uint64_t n = (uint64_t)count * L.per_count;
     const uint64_t bytes = n * (uint64_t)L.width * (uint64_t)(L.is_int ? 1 : L.arity);
-    if (n != 0 && n <= 0xffffffffull && held + bytes <= budget)
+    if (n != 0 && n <= 0xffffffffull && held + readahead_cost(bytes) <= budget)
       {
       if (a->ra_n == cap)
         {
@@ -586,7 +626,7 @@ static void start_readahead(struct trico_archive* a)
         a->ra[a->ra_n].pos = a->pos;
         a->ra[a->ra_n].ctx = ctx;
         ++a->ra_n;
-        held += bytes;
+        held += readahead_cost(bytes);
         }
       else if (ctx)
         trico_hip_ctx_destroy(ctx);       /* the one-by-one path will report what is wrong with it */
@@ -637,7 +677,14 @@ static int read_fp_stream(void* archive, enum trico_stream_type st, void** dst, 
         return 0;
       }
     const int ahead = collect_readahead(a, out);
-    if (ahead == 0 || (ahead < 0 && !trico_hip_fpc_decode(a->ctx, payloads, sizes, arity, width, count, out)))
+    int ok = ahead > 0;
+    if (ahead < 0)
+      {
+      ok = trico_hip_fpc_decode(a->ctx, payloads, sizes, arity, width, count, out);
+      if (!ok && drop_all_readahead(a))
+        ok = trico_hip_fpc_decode(a->ctx, payloads, sizes, arity, width, count, out);
+      }
+    if (!ok)
       {
       if (lib_alloc)
         free(out);
@@ -646,6 +693,8 @@ static int read_fp_stream(void* archive, enum trico_stream_type st, void** dst, 
     if (lib_alloc)
       *dst = out;
     }
+  else if (a->ra_started)
+    drop_readahead(a);
   a->pos = end_pos;
   read_next_stream_type(a);
   return 1;
@@ -668,9 +717,18 @@ static int read_int_stream(void* archive, enum trico_stream_type st, void** dst,
     if (!arch_ctx(a))
       return 0;
     const int ahead = collect_readahead(a, *dst);
-    if (ahead == 0 || (ahead < 0 && !trico_hip_int_decode(a->ctx, payloads, sizes, width, count * per_count, *dst)))
+    int ok = ahead > 0;
+    if (ahead < 0)
+      {
+      ok = trico_hip_int_decode(a->ctx, payloads, sizes, width, count * per_count, *dst);
+      if (!ok && drop_all_readahead(a))
+        ok = trico_hip_int_decode(a->ctx, payloads, sizes, width, count * per_count, *dst);
+      }
+    if (!ok)
       return 0;
     }
+  else if (a->ra_started)
+    drop_readahead(a);
   a->pos = end_pos;
   read_next_stream_type(a);
   return 1;

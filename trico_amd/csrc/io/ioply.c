@@ -159,6 +159,10 @@ static long bind(elem_t* e, const char* name, int role, int slot)
   prop_t* p = find_prop(e, name);
   if (!p)
     return 0;
+  /* a scalar role (position, normal, colour) bound to a list property would never be stored: treat it as absent; the
+   * face / texcoord roles are the list-typed ones */
+  if (p->is_list != (role == ROLE_FACE || role == ROLE_UV))
+    return 0;
   p->role = role;
   p->slot = slot;
   return e->count;
@@ -225,7 +229,7 @@ int trico_read_ply(uint32_t* nr_of_vertices, float** vertices, float** vertex_no
       char cnt[64], *endp;
       if (!next_word(&c, e->name, sizeof(e->name)) || !next_word(&c, cnt, sizeof(cnt))) { ok = 0; break; }
       e->count = strtol(cnt, &endp, 10);
-      if (*endp || e->count < 0) { ok = 0; break; }
+      if (*endp || e->count < 0 || (unsigned long)e->count > 0xffffffffUL) { ok = 0; break; }   /* the API reports counts as uint32_t */
       ++nelems;
       continue;
       }

@@ -201,6 +201,21 @@ int main(int argc, const char** argv)
   if (!have_output)
     with_extension(output, sizeof(output), input, as_ply ? "ply" : "stl");
 
+  /* the archive is untrusted input: triangle indices must address the vertex stream that came with them, and the per-vertex
+   * streams must have the vertex count (the writers below index with both) */
+  {
+  int sane = 1;
+  if (nt && (!vertices || !triangles || nv == 0))
+    sane = 0;
+  for (size_t k = 0; sane && triangles && k < (size_t)nt * 3; ++k)
+    if (triangles[k] >= nv)
+      sane = 0;
+  if (!sane)
+    {
+    printf("Inconsistent archive: triangle indices without matching vertices\n");
+    return -1;
+    }
+  }
   int ok;
   if (as_stl)
     {
