@@ -17,8 +17,8 @@
 //            with, as value indices (0 = never written = the reference's zeroed table).
 //   sweep C  (k_fpc32_code):   loads the incoming table (payloads gathered from the input by index),
 //            then per step: the latest earlier value of my class is the previous lane inside a run
-//            of equal classes (runs span steps through the carry); run starts are resolved with a
-//            per-class lane-mask table + the wave-private payload table, only in steps that have
+//            of equal classes (runs span steps through the carry); run starts are resolved with ballots
+//            (the lanes of my class) + the wave-private payload table, only in steps that have
 //            any (see the comment block above code_step).  Codes, residual lengths, wave prefix sums
 //            (mbcnt), 3-byte group headers (DPP or-reduce), bytes staged in a linear LDS buffer and
 //            flushed as aligned dwords into the segment's slot.
@@ -28,7 +28,8 @@
 //
 // HBM traffic: 2 x raw input + 2 x payload bytes + table traffic (measured 3.3 x algorithmic, DESIGN.md
 // 4.1).  No MFMA: integer bit-twiddling; algorithmic bytes per value = 4 + its payload share.  The bound
-// today is VALU issue (97 instructions per 64-value step), not HBM.
+// today is the vector ALU (121 instructions per 64-value step at 4 cycles each; SQ counters: 78 % VALU busy at 30 waves per
+// CU), not HBM.
 #include "common.hpp"
 #include <stdlib.h>
 
@@ -39,7 +40,6 @@ namespace {
 constexpr int TAB = 1040;      // 16 FCM entries followed by 1024 DFCM entries
 constexpr int ROW = 1040;      // words per (segment, component) row in the global index tables
 constexpr int CH = 32;         // segments per chunk in the cross-segment scan
-constexpr int MASKW = 2 * TAB;  // words of the per-class lane-mask table (u64 per class)
 constexpr int LDSW_A = TAB;                        // per-wave LDS words, sweep A
 constexpr int PF = 8;          // steps (of 64 values) whose loads are kept in flight per wave
 
@@ -295,14 +295,16 @@ __global__ void __launch_bounds__(256) k_fpc32_scan_b(const uint32_t* __restrict
 //   * full steps (64 values, the normal case) are a separate instantiation without activity masks.
 //
 // Run starts: lanes form runs of equal class.  A run START needs the nearest lower lane of its class, which
-// is the END lane of an earlier run: run ends OR their lane bit into M[class] (u64 per class, zero between
-// steps), every lane reads its class's mask back, ends clear it.  The nearest lower set bit is the source
-// lane (ds_bpermute); no bit below means the table T holds the latest earlier value (from an earlier step
-// or the segment's incoming table).  The run end whose mask has no higher bit owns the table write.
+// is the END lane of an earlier run.  Every lane gets the set of lanes of its class from one ballot per class
+// bit (match_any: 4 ballots for the FCM class, 10 for the DFCM class; round 1 kept a u64 lane mask per class in
+// LDS, 8.3 KB per wave, which held the sweep at 12 waves per CU and three dependent LDS round trips per step).
+// The nearest lower set bit is the source lane (ds_bpermute); no bit below means the table T holds the latest
+// earlier value (from an earlier step or the segment's incoming table).  The highest lane of a class owns the
+// table write.
 
 constexpr int STAGE_LIVE = 544;                   // < 256 unflushed + <= 280 of the step, rounded
 constexpr int STAGE = STAGE_LIVE + 256;           // + 4 dump bytes per lane
-constexpr int LDSW_C = TAB + STAGE / 4 + MASKW;   // per-wave LDS words, sweep C (13,280 B: 4 x 3 waves per CU)
+constexpr int LDSW_C = TAB + STAGE / 4;           // per-wave LDS words, sweep C (4,960 B: 10 x 3 waves per CU)
 
 struct LaneK                                      // per-lane constants
   {
@@ -320,37 +322,42 @@ struct Sweep                                      // wave-uniform running state
   uint32_t posl, flushed;                         // bytes staged in LDS / bytes already in the slot
   };
 
+// lanes whose class equals mine, for B-bit classes: B ballots.  `same` starts as the set of active lanes; per bit,
+// same &= ~(ballot(bit) ^ mybit) — one v_bitop3 per half.
+template <int B>
+__device__ __forceinline__ void match_any(uint32_t k, uint32_t& same_lo, uint32_t& same_hi)
+  {
+#pragma unroll
+  for (int b = 0; b < B; ++b)
+    {
+    const uint32_t pb = (uint32_t)((int32_t)(k << (31 - b)) >> 31);          // all ones if bit b of k is set
+    const uint64_t m = __ballot(pb != 0u);
+    same_lo &= ~((uint32_t)m ^ pb);
+    same_hi &= ~((uint32_t)(m >> 32) ^ pb);
+    }
+  }
+
 template <bool FULL, bool D1, bool D2>
 __device__ __forceinline__ void resolve(uint32_t k1, uint32_t k2, bool st1, bool st2, bool act, uint32_t v, uint32_t s,
-                                        uint32_t& p1, uint32_t& p2, uint32_t* __restrict__ T, uint64_t* __restrict__ M,
-                                        Sweep& sw, const LaneK& lk)
+                                        uint32_t& p1, uint32_t& p2, uint32_t* __restrict__ T, Sweep& sw, const LaneK& lk)
   {
   // pending writes of the previous step's last value (lane 0 writes, the others hit their dump word)
   if (D1 && sw.pend1) T[lk.lane == 0 ? sw.kc1 : lk.dumpw] = sw.cy.m1;
   if (D2 && sw.pend2) T[lk.lane == 0 ? sw.kc2 : lk.dumpw] = sw.cy.m1 - sw.cy.m2;
-  bool en1 = false, en2 = false;
-  if (D1)
-    {
-    en1 = k1 != dpp_shl1(0xfffffffeu, k1);
-    if (!FULL) en1 = en1 && act;
-    if (en1) atomicOr((unsigned long long*)&M[k1], (unsigned long long)lk.bit);
-    }
-  if (D2)
-    {
-    en2 = k2 != dpp_shl1(0xfffffffeu, k2);
-    if (!FULL) en2 = en2 && act;
-    if (en2) atomicOr((unsigned long long*)&M[k2], (unsigned long long)lk.bit);
-    }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // table entries of the run starts that have no earlier value of their class in this step
   const uint32_t r1 = FULL ? k1 : (act ? k1 : 0u), r2 = FULL ? k2 : (act ? k2 : 16u);
-  uint64_t m1 = 0, m2 = 0;
   uint32_t tv1 = 0, tv2 = 0;
-  if (D1) { m1 = M[r1]; tv1 = T[r1]; }
-  if (D2) { m2 = M[r2]; tv2 = T[r2]; }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  if (D1 && en1) M[k1] = 0ull;
-  if (D2 && en2) M[k2] = 0ull;
-  const uint64_t lo1 = m1 & lk.lt, lo2 = m2 & lk.lt;
+  if (D1) tv1 = T[r1];
+  if (D2) tv2 = T[r2];
+  // the lanes of my class (no LDS: ballots), while those reads are in flight
+  const uint64_t live = FULL ? ~0ull : __ballot(act);
+  uint32_t s1lo = (uint32_t)live, s1hi = (uint32_t)(live >> 32), s2lo = s1lo, s2hi = s1hi;
+  if (D1) match_any<4>(k1, s1lo, s1hi);
+  if (D2) match_any<10>(k2 - 16u, s2lo, s2hi);
+  const uint64_t same1 = ((uint64_t)s1hi << 32) | s1lo, same2 = ((uint64_t)s2hi << 32) | s2lo;
+  // a run START takes the payload of the nearest lower lane of its class (the END of an earlier run), else the table's
+  const uint64_t lo1 = same1 & lk.lt, lo2 = same2 & lk.lt;
   const bool hit1 = D1 && st1 && lo1 != 0ull, hit2 = D2 && st2 && lo2 != 0ull;
   if (D1) p1 = st1 ? tv1 : p1;
   if (D2) p2 = st2 ? tv2 : p2;
@@ -367,9 +374,10 @@ __device__ __forceinline__ void resolve(uint32_t k1, uint32_t k2, bool st1, bool
       p2 = hit2 ? q : p2;
       }
     }
-  // table writes by the last value of every class (after the reads: LDS operations of a wave stay in order)
-  if (D1) T[(en1 && (m1 >> lk.lane) == 1ull) ? k1 : lk.dumpw] = v;
-  if (D2) T[(en2 && (m2 >> lk.lane) == 1ull) ? k2 : lk.dumpw] = s;
+  // table writes by the highest lane of every class (after the reads: LDS operations of a wave stay in order)
+  const bool own1 = (FULL || act) && (same1 >> lk.lane) == 1ull, own2 = (FULL || act) && (same2 >> lk.lane) == 1ull;
+  if (D1) T[own1 ? k1 : lk.dumpw] = v;
+  if (D2) T[own2 ? k2 : lk.dumpw] = s;
   if (D1) { sw.kc1 = (uint32_t)__builtin_amdgcn_readlane((int)k1, 63); sw.pend1 = false; }
   if (D2) { sw.kc2 = (uint32_t)__builtin_amdgcn_readlane((int)k2, 63); sw.pend2 = false; }
   }
@@ -388,7 +396,7 @@ __device__ __forceinline__ void store_span(uint8_t* __restrict__ gbase, uint32_t
 // one step: 64 values starting at index i0 (FULL: all of them inside the segment)
 template <bool FULL>
 __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_end, uint32_t n, uint32_t* __restrict__ T,
-                                          uint64_t* __restrict__ M, uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase,
+                                          uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase,
                                           Sweep& sw, const LaneK& lk)
   {
   const uint32_t i = i0 + (uint32_t)lk.lane;
@@ -408,15 +416,15 @@ __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_en
   const uint32_t s = v - a;
   uint32_t p1 = a, p2 = s1;                                 // inside a run: previous value / previous stride
   if (any1 && any2)
-    resolve<FULL, true, true>(k1, k2, st1, st2, act, v, s, p1, p2, T, M, sw, lk);
+    resolve<FULL, true, true>(k1, k2, st1, st2, act, v, s, p1, p2, T, sw, lk);
   else if (any1)
     {
-    resolve<FULL, true, false>(k1, k2, st1, st2, act, v, s, p1, p2, T, M, sw, lk);
+    resolve<FULL, true, false>(k1, k2, st1, st2, act, v, s, p1, p2, T, sw, lk);
     sw.pend2 = true;
     }
   else if (any2)
     {
-    resolve<FULL, false, true>(k1, k2, st1, st2, act, v, s, p1, p2, T, M, sw, lk);
+    resolve<FULL, false, true>(k1, k2, st1, st2, act, v, s, p1, p2, T, sw, lk);
     sw.pend1 = true;
     }
   else
@@ -496,9 +504,6 @@ __global__ void __launch_bounds__(192) k_fpc32_code(const uint32_t* __restrict__
   const uint32_t g = blockIdx.x;
   uint32_t* T = lds + c * LDSW_C;                      // [TAB] payload table
   uint8_t* stage = (uint8_t*)(T + TAB);                // [STAGE] packed bytes of the steps not yet flushed + dump
-  uint64_t* M = (uint64_t*)(T + TAB + STAGE / 4);      // [TAB] lane masks
-  for (int k = lane; k < TAB; k += 64)
-    M[k] = 0ull;
   // incoming table: payload of the last writer of every class before this segment (0 if none)
   const uint32_t* row = inc + ((size_t)g * arity + c) * ROW;
   for (int k = lane; k < TAB; k += 64)
@@ -551,9 +556,9 @@ __global__ void __launch_bounds__(192) k_fpc32_code(const uint32_t* __restrict__
       {
       const uint32_t i0 = ib + 64u * pu;
       if (i0 + 64u <= i_end)
-        code_step<true>(cur[pu], i0, i_end, n, T, M, stage, gbase, sw, lk);
+        code_step<true>(cur[pu], i0, i_end, n, T, stage, gbase, sw, lk);
       else if (i0 < i_end)
-        code_step<false>(cur[pu], i0, i_end, n, T, M, stage, gbase, sw, lk);
+        code_step<false>(cur[pu], i0, i_end, n, T, stage, gbase, sw, lk);
       }
 #pragma unroll
     for (int pu = 0; pu < PF; ++pu)
@@ -654,7 +659,7 @@ Plan make_plan(uint32_t n, int arity)
   if (!waves)
     {
     const char* e = getenv("TRICO_FPC32_WAVES");      // tuning knob: waves per sweep
-    waves = e ? atoi(e) : 3072;
+    waves = e ? atoi(e) : 7680;                       // 30 waves per CU: the code sweep needs 4,960 B of LDS per wave
     if (waves < 3) waves = 3;
     }
   Plan p;
