@@ -322,19 +322,42 @@ struct Sweep                                      // wave-uniform running state
   uint32_t posl, flushed;                         // bytes staged in LDS / bytes already in the slot
   };
 
-// lanes whose class equals mine, for B-bit classes: B ballots.  `same` starts as the set of active lanes; per bit,
-// same &= ~(ballot(bit) ^ mybit) — one v_bitop3 per half.
+// lanes whose class equals mine, for B-bit classes (B even): one ballot per class bit.  `diff` collects the lanes that differ
+// from me in some bit: diff |= ballot(bit) ^ mybit, one v_bitop3 per half; the caller takes live & ~diff.  Four vector
+// instructions per bit, written out because the kernel is bound by the vector ALU (hipcc spent six); two bits per
+// statement so that the wait states between a v_cmp writing an SGPR pair and the v_bitop3 reading it are filled.
+template <int B0>
+__device__ __forceinline__ void match_bits2(uint32_t k, uint32_t& dlo, uint32_t& dhi)
+  {
+  uint32_t p0, p1;
+  asm volatile("v_bfe_i32 %[p0], %[k], %[b0], 1\n"
+               "v_bfe_i32 %[p1], %[k], %[b1], 1\n"
+               "v_cmp_ne_u32_e64 s[40:41], 0, %[p0]\n"
+               "v_cmp_ne_u32_e64 s[42:43], 0, %[p1]\n"
+               "s_nop 0\n"
+               "v_bitop3_b32 %[dlo], %[dlo], s40, %[p0] bitop3:0xf6\n"       // dlo | (ballot ^ p0)
+               "v_bitop3_b32 %[dhi], %[dhi], s41, %[p0] bitop3:0xf6\n"
+               "v_bitop3_b32 %[dlo], %[dlo], s42, %[p1] bitop3:0xf6\n"
+               "v_bitop3_b32 %[dhi], %[dhi], s43, %[p1] bitop3:0xf6\n"
+               : [dlo] "+v"(dlo), [dhi] "+v"(dhi), [p0] "=&v"(p0), [p1] "=&v"(p1)
+               : [k] "v"(k), [b0] "n"(B0), [b1] "n"(B0 + 1)
+               : "s40", "s41", "s42", "s43");
+  }
+
 template <int B>
 __device__ __forceinline__ void match_any(uint32_t k, uint32_t& same_lo, uint32_t& same_hi)
   {
-#pragma unroll
-  for (int b = 0; b < B; ++b)
+  uint32_t dlo = 0, dhi = 0;
+  match_bits2<0>(k, dlo, dhi);
+  match_bits2<2>(k, dlo, dhi);
+  if (B > 4)
     {
-    const uint32_t pb = (uint32_t)((int32_t)(k << (31 - b)) >> 31);          // all ones if bit b of k is set
-    const uint64_t m = __ballot(pb != 0u);
-    same_lo &= ~((uint32_t)m ^ pb);
-    same_hi &= ~((uint32_t)(m >> 32) ^ pb);
+    match_bits2<4>(k, dlo, dhi);
+    match_bits2<6>(k, dlo, dhi);
+    match_bits2<8>(k, dlo, dhi);
     }
+  same_lo &= ~dlo;
+  same_hi &= ~dhi;
   }
 
 template <bool FULL, bool D1, bool D2>
