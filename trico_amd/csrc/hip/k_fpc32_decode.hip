@@ -16,7 +16,7 @@
 //   * wave 1 (parser) stages the payload through LDS, finds the 8 groups of the next 64 values with a short scalar walk
 //     over the 3-byte headers, lets all 64 lanes locate, align and byte-swap their residual at once, and hands the
 //     residuals (scalar stores) and the mask of DFCM-coded values (LDS) to wave 0; it also stores the previous batch's
-//     values.  One barrier per batch, double-buffered.
+//     values.  The two waves are coupled only through two counters in LDS (a ring of four batches).
 //   * wave 0 (chain) runs the recurrence, fully unrolled and branch-free, on the SCALAR unit, with the DFCM table (1024
 //     entries) in global memory behind the scalar data cache and the FCM table (16 entries) in SGPRs: see below.
 // History: one wave, scalar chain with branches and both tables in registers: 165-225 cycles per value (69-93 ns); vector
@@ -205,17 +205,18 @@ __device__ void serial_values(const uint8_t* __restrict__ in, uint32_t len, uint
   }
 
 // Scratch of one stream in global memory (FPC32_DECODE_TABLE_BYTES): DFCM table (4 KiB), FCM table between batches (64 B),
-// at 4352 two slots of 64 residuals.  Only this workgroup touches it, and only through the scalar cache.
+// at 4352 RING slots of 64 residuals.  Only this workgroup touches it, and only through the scalar cache.
 constexpr uint32_t SCRATCH_DWORDS = 2048, SCRATCH_T1 = 1024, SCRATCH_X = 1088;
+constexpr uint32_t RING = 4;                  // batches the parser may run ahead of the chain (4 x 256 B of residuals at SCRATCH_X)
 
 __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity, uint32_t n, uint32_t* __restrict__ dst,
                                                       uint32_t* __restrict__ status, uint32_t* __restrict__ scratch)
   {
   __shared__ uint32_t win[WINW + 4];
   __shared__ uint32_t T2[1024], T1[16];          // tail loop only
-  __shared__ uint32_t dmask[2][2];               // DFCM-coded values of a parsed batch
-  __shared__ uint32_t outb[2][64];
-  __shared__ uint32_t sh_bad, sh_q;
+  __shared__ uint32_t dmask[RING][2];            // DFCM-coded values of a parsed batch
+  __shared__ uint32_t outb[RING][64];
+  __shared__ uint32_t sh_bad, sh_q, produced, consumed;
   const int lane = threadIdx.x & 63;
   const int wave = (int)rfl(threadIdx.x >> 6);
   const int comp = blockIdx.x;
@@ -227,6 +228,8 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
     {
     sh_bad = 0u;
     sh_q = 5u;
+    produced = 0u;
+    consumed = 0u;
     }
   const uint8_t* in = args.pay[comp];
   const uint32_t len = args.size[comp];
@@ -272,13 +275,25 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
     };
   if (wave == 1 && nb)
     refill(q);
-  // iteration t: the parser parses batch t and stores the values of batch t - 2; the chain decodes batch t - 1
-  for (uint32_t t = 0; t < nb + 2u; ++t)
+  // The two waves run decoupled through a ring of RING batches: `produced` = batches parsed (slot t % RING holds batch t's
+  // residuals in the scratch and its DFCM mask in LDS), `consumed` = batches decoded (outb[t % RING] holds batch t's values).
+  // The parser parses batch t only after it has stored batch t - RING, so the chain never overwrites values that are not
+  // in memory yet.  (Round-2 first version: one barrier per batch; the chain lost 2-10 % waiting at it.)
+  if (wave == 1)
     {
-    if (wave == 1)
+    uint32_t t = 0, st = 0;                              // next batch to parse / next batch to store
+    while (st < nb)
       {
-      if (t < nb)
+      const uint32_t cdone = rfl(__hip_atomic_load(&consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+      bool progress = false;
+      for (; st < cdone; ++st)
         {
+        dst[(size_t)(64u * st + (uint32_t)lane) * arity + comp] = outb[st % RING][lane];
+        progress = true;
+        }
+      if (t < nb && t < st + RING)
+        {
+        progress = true;
         if (q + BATCH_BYTES + 8u > 4u * (wd + (uint32_t)WINW))
           refill(q);
         // ---- positions of the 8 groups: scalar walk over the headers -----------------------------------
@@ -299,41 +314,58 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
         const uint32_t qend = 4u * wd + lq;
         if (qend > total_q)
           {
-          if (lane == 0) sh_bad = 1u;
-          }
-        else
-          {
-          q = qend;
-          // ---- all 64 lanes fetch their residual ------------------------------------------------------------
-          const uint32_t j3 = 3u * ((uint32_t)lane & 7u);
-          const uint32_t code = (bcv >> j3) & 7u;
-          const uint32_t nbytes = code <= 4u ? code : code - 4u;
-          const uint32_t rp = myq + 3u + lens_sum(bcv & ((1u << j3) - 1u));
-          const uint32_t raw = __builtin_amdgcn_alignbyte(win[(rp >> 2) + 1u], win[rp >> 2], rp & 3u);
-          const uint32_t xr = nbytes ? __builtin_bswap32(raw) >> (8u * (4u - nbytes)) : 0u;
-          const uint64_t dfcm = __ballot(code > 4u);
-          chain4_put_residuals(xr, Xg + 64u * (t & 1u));
           if (lane == 0)
-            {
-            dmask[t & 1u][0] = (uint32_t)dfcm;
-            dmask[t & 1u][1] = (uint32_t)(dfcm >> 32);
-            sh_q = q - al;
-            }
+            __hip_atomic_store(&sh_bad, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          break;
           }
+        q = qend;
+        // ---- all 64 lanes fetch their residual ------------------------------------------------------------
+        const uint32_t j3 = 3u * ((uint32_t)lane & 7u);
+        const uint32_t code = (bcv >> j3) & 7u;
+        const uint32_t nbytes = code <= 4u ? code : code - 4u;
+        const uint32_t rp = myq + 3u + lens_sum(bcv & ((1u << j3) - 1u));
+        const uint32_t raw = __builtin_amdgcn_alignbyte(win[(rp >> 2) + 1u], win[rp >> 2], rp & 3u);
+        const uint32_t xr = nbytes ? __builtin_bswap32(raw) >> (8u * (4u - nbytes)) : 0u;
+        const uint64_t dfcm = __ballot(code > 4u);
+        chain4_put_residuals(xr, Xg + 64u * (t % RING));          // scalar stores, complete on return
+        if (lane == 0)
+          {
+          dmask[t % RING][0] = (uint32_t)dfcm;
+          dmask[t % RING][1] = (uint32_t)(dfcm >> 32);
+          sh_q = q - al;
+          __hip_atomic_store(&produced, t + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        ++t;
         }
-      if (t >= 2u)
-        dst[(size_t)(64u * (t - 2u) + (uint32_t)lane) * arity + comp] = outb[t & 1u][lane];
+      if (!progress)
+        __builtin_amdgcn_s_sleep(2);
       }
-    else if (t >= 1u && t <= nb)
+    }
+  else
+    {
+    for (uint32_t t = 0; t < nb; ++t)
       {
-      const uint32_t b = (t - 1u) & 1u;
+      bool stop = false;
+      while (rfl(__hip_atomic_load(&produced, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) <= t)
+        {
+        if (rfl(__hip_atomic_load(&sh_bad, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)))
+          {
+          stop = true;
+          break;
+          }
+        __builtin_amdgcn_s_sleep(1);
+        }
+      if (stop)
+        break;
+      const uint32_t b = t % RING;
       const uint32_t dlo = rfl(dmask[b][0]), dhi = rfl(dmask[b][1]);
       outb[b][lane] = chain4_batch(c, dlo, dhi, T2g, Xg + 64u * b);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0)
+        __hip_atomic_store(&consumed, t + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-    __syncthreads();
-    if (sh_bad)
-      break;
     }
+  __syncthreads();
   bool bad = sh_bad != 0u;
   const uint32_t i0 = 64u * nb;
   if (nb)
