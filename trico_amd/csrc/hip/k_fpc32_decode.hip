@@ -343,6 +343,9 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
     }
   else
     {
+    // the chain owns its SIMD's issue slots whenever it can issue: other kernels' waves (the sweeps of the LZ4 decoder, other
+    // archives) may share the CU
+    __builtin_amdgcn_s_setprio(3);
     for (uint32_t t = 0; t < nb; ++t)
       {
       bool stop = false;
@@ -404,7 +407,12 @@ int launch_fpc32_decode(const uint8_t* const d_payloads[3], const uint32_t sizes
     a.pay[c] = c < arity ? d_payloads[c] : nullptr;
     a.size[c] = c < arity ? sizes[c] : 0;
     }
-  hipLaunchKernelGGL(k_fpc32_decode, dim3(arity), dim3(128), 0, current_stream(), a, arity, n, (uint32_t*)d_dst, d_status, d_scratch);
+  // One chain per CU: the chain wave needs its SIMD's issue slots and its CU's scalar cache; the workgroup asks for more than
+  // half of the CU's LDS (it uses 14 KB of it) so that no second workgroup of this kernel can be placed beside it.
+  constexpr size_t CLAIM = 88u << 10;
+  static const bool claimed = hipFuncSetAttribute((const void*)k_fpc32_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLAIM) == hipSuccess;
+  hipLaunchKernelGGL(k_fpc32_decode, dim3(arity), dim3(128), claimed ? CLAIM : 0, current_stream(), a, arity, n, (uint32_t*)d_dst, d_status,
+                     d_scratch);
   return hip_ok(hipGetLastError(), "k_fpc32_decode") ? 1 : 0;
   }
 

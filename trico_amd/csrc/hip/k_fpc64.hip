@@ -323,6 +323,7 @@ __global__ void __launch_bounds__(64) k_fpc64_decode(DecodeArgs args, int arity,
     __syncthreads();
     };
   refill(q);
+  __builtin_amdgcn_s_setprio(3);                        // the chain owns its SIMD's issue slots whenever it can issue
   const uint8_t* wb = (const uint8_t*)win;
   // wave-uniform chain state.  fwd1 / fwd2: the hash did not change with the last value, so the entry of the current hash
   // is the value / stride just stored and is taken from the register (p1 / t2v) instead of being loaded
@@ -430,7 +431,11 @@ int launch_fpc64_decode(const uint8_t* const d_payloads[3], const uint32_t sizes
     a.pay[c] = c < arity ? d_payloads[c] : nullptr;
     a.size[c] = c < arity ? sizes[c] : 0;
     }
-  hipLaunchKernelGGL(k_fpc64_decode, dim3(arity), dim3(64), 0, current_stream(), a, arity, n, (u64*)d_dst, (u64*)d_tables, d_status);
+  // one chain per CU (see launch_fpc32_decode): the workgroup claims more than half of the CU's LDS
+  constexpr size_t CLAIM = 72u << 10;
+  static const bool claimed = hipFuncSetAttribute((const void*)k_fpc64_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLAIM) == hipSuccess;
+  hipLaunchKernelGGL(k_fpc64_decode, dim3(arity), dim3(64), claimed ? CLAIM : 0, current_stream(), a, arity, n, (u64*)d_dst, (u64*)d_tables,
+                     d_status);
   return hip_ok(hipGetLastError(), "k_fpc64_decode") ? 1 : 0;
   }
 
