@@ -110,6 +110,8 @@ int launch_fpc32_decode(const uint8_t* const d_payloads[3], const uint32_t sizes
 
 // double-precision coder (k_fpc64.hip): one wave per component stream, 2 x 2^20-entry tables per stream in d_tables (zeroed)
 int launch_fpc64_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes, uint64_t* d_tables);
+// d_tables: 2 x 2^20 entries per component, followed by FPC64_DECODE_SCRATCH_BYTES per component (rings of the kernel's two waves)
+constexpr size_t FPC64_DECODE_SCRATCH_BYTES = 8192;
 int launch_fpc64_decode(const uint8_t* const d_payloads[3], const uint32_t sizes[3], int arity, uint32_t n, void* d_dst,
                         uint64_t* d_tables, uint32_t* d_status);
 

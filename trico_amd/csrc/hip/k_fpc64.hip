@@ -276,140 +276,274 @@ __device__ __forceinline__ void table_store(const u64* base, uint32_t byte_offse
   asm volatile("s_store_dwordx2 %0, %1, %2" :: "s"(v), "s"(base), "s"(byte_offset) : "memory");
   }
 
-__global__ void __launch_bounds__(64) k_fpc64_decode(DecodeArgs args, int arity, uint32_t n, u64* __restrict__ dst, u64* __restrict__ tables,
-                                                     uint32_t* __restrict__ status)
+// Two waves: wave 1 parses the group headers and the residuals of the next batches and stores the values of the finished ones;
+// wave 0 runs the chain.  They are coupled through two LDS counters and two rings in the stream's scratch (residuals in,
+// values out) that both waves access through the scalar cache (k_fpc32_decode.hip has the float version of the same design).
+constexpr uint32_t RING64 = 4;                                   // batches the parser may run ahead
+constexpr uint32_t SCR64_DWORDS = 2048;                          // scratch per component: RING64 x 512 B of residuals, then of values
+
+// lane l's 64-bit word -> dwords 2l, 2l + 1 of `slot` (512 bytes), with scalar stores
+__device__ __forceinline__ void put_words64(u64 w, const uint32_t* slot)
+  {
+  const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+#define P64_PUT2(J, R0, R1, R2, R3) \
+  "v_readlane_b32 s" #R0 ", %[lo], 2 * (" #J ")\n v_readlane_b32 s" #R1 ", %[hi], 2 * (" #J ")\n" \
+  "v_readlane_b32 s" #R2 ", %[lo], 2 * (" #J ") + 1\n v_readlane_b32 s" #R3 ", %[hi], 2 * (" #J ") + 1\n" \
+  "s_nop 0\n s_store_dwordx4 s[" #R0 ":" #R3 "], %[slot], 16 * (" #J ")\n"
+#define P64_4(J) P64_PUT2(J, 52, 53, 54, 55) P64_PUT2(J + 1, 56, 57, 58, 59) P64_PUT2(J + 2, 60, 61, 62, 63) P64_PUT2(J + 3, 64, 65, 66, 67)
+  asm volatile(P64_4(0) P64_4(4) P64_4(8) P64_4(12) P64_4(16) P64_4(20) P64_4(24) P64_4(28)
+               "s_waitcnt lgkmcnt(0)\n"
+               :: [lo] "v"(lo), [hi] "v"(hi), [slot] "s"(slot)
+               : "memory", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67");
+  }
+
+// dwords 2l, 2l + 1 of `slot` -> lane l, with scalar loads (the values were stored through the scalar cache)
+__device__ __forceinline__ u64 get_words64(const uint32_t* slot)
+  {
+  uint32_t lo = 0, hi = 0;
+#define G64_8(Q) \
+  "s_load_dwordx16 s[52:67], %[slot], 64 * (" #Q ")\n s_waitcnt lgkmcnt(0)\n" \
+  "v_writelane_b32 %[lo], s52, 8 * (" #Q ") + 0\n v_writelane_b32 %[hi], s53, 8 * (" #Q ") + 0\n" \
+  "v_writelane_b32 %[lo], s54, 8 * (" #Q ") + 1\n v_writelane_b32 %[hi], s55, 8 * (" #Q ") + 1\n" \
+  "v_writelane_b32 %[lo], s56, 8 * (" #Q ") + 2\n v_writelane_b32 %[hi], s57, 8 * (" #Q ") + 2\n" \
+  "v_writelane_b32 %[lo], s58, 8 * (" #Q ") + 3\n v_writelane_b32 %[hi], s59, 8 * (" #Q ") + 3\n" \
+  "v_writelane_b32 %[lo], s60, 8 * (" #Q ") + 4\n v_writelane_b32 %[hi], s61, 8 * (" #Q ") + 4\n" \
+  "v_writelane_b32 %[lo], s62, 8 * (" #Q ") + 5\n v_writelane_b32 %[hi], s63, 8 * (" #Q ") + 5\n" \
+  "v_writelane_b32 %[lo], s64, 8 * (" #Q ") + 6\n v_writelane_b32 %[hi], s65, 8 * (" #Q ") + 6\n" \
+  "v_writelane_b32 %[lo], s66, 8 * (" #Q ") + 7\n v_writelane_b32 %[hi], s67, 8 * (" #Q ") + 7\n"
+  asm volatile(G64_8(0) G64_8(1) G64_8(2) G64_8(3) G64_8(4) G64_8(5) G64_8(6) G64_8(7)
+               : [lo] "+v"(lo), [hi] "+v"(hi) : [slot] "s"(slot)
+               : "memory", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67");
+  return ((u64)hi << 32) | lo;
+  }
+
+struct Oct64 { u64 v[8]; };
+#define OCT_REGS "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83"
+// eight 64-bit words at byte offset `off` of `slot`, through the scalar cache
+__device__ __forceinline__ void load_oct(const uint32_t* slot, uint32_t off, Oct64& o)
+  {
+  asm volatile("s_load_dwordx16 s[68:83], %8, %9\n s_waitcnt lgkmcnt(0)\n"
+               "s_mov_b64 %0, s[68:69]\n s_mov_b64 %1, s[70:71]\n s_mov_b64 %2, s[72:73]\n s_mov_b64 %3, s[74:75]\n"
+               "s_mov_b64 %4, s[76:77]\n s_mov_b64 %5, s[78:79]\n s_mov_b64 %6, s[80:81]\n s_mov_b64 %7, s[82:83]"
+               : "=&s"(o.v[0]), "=&s"(o.v[1]), "=&s"(o.v[2]), "=&s"(o.v[3]), "=&s"(o.v[4]), "=&s"(o.v[5]), "=&s"(o.v[6]), "=&s"(o.v[7])
+               : "s"(slot), "s"(off) : "memory", OCT_REGS);
+  }
+__device__ __forceinline__ void store_oct(const uint32_t* slot, uint32_t off, const Oct64& o)
+  {
+  asm volatile("s_mov_b64 s[68:69], %0\n s_mov_b64 s[70:71], %1\n s_mov_b64 s[72:73], %2\n s_mov_b64 s[74:75], %3\n"
+               "s_mov_b64 s[76:77], %4\n s_mov_b64 s[78:79], %5\n s_mov_b64 s[80:81], %6\n s_mov_b64 s[82:83], %7\n"
+               "s_store_dwordx4 s[68:71], %8, %9\n s_store_dwordx4 s[72:75], %8, %10\n"
+               "s_store_dwordx4 s[76:79], %8, %11\n s_store_dwordx4 s[80:83], %8, %12\n"
+               "s_waitcnt lgkmcnt(0)"
+               :: "s"(o.v[0]), "s"(o.v[1]), "s"(o.v[2]), "s"(o.v[3]), "s"(o.v[4]), "s"(o.v[5]), "s"(o.v[6]), "s"(o.v[7]),
+                  "s"(slot), "s"(off), "s"(off + 16u), "s"(off + 32u), "s"(off + 48u) : "memory", OCT_REGS);
+  }
+
+__global__ void __launch_bounds__(128) k_fpc64_decode(DecodeArgs args, int arity, uint32_t n, u64* __restrict__ dst, u64* __restrict__ tables,
+                                                      uint32_t* __restrict__ scratch, uint32_t* __restrict__ status)
   {
   __shared__ uint32_t win[WINW + 8];
-  const int lane = threadIdx.x;
+  __shared__ uint32_t dmask[RING64][2];
+  __shared__ uint32_t sh_bad, produced, consumed;
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)rfl(threadIdx.x >> 6);
   const int comp = blockIdx.x;
   const uint8_t* in = args.pay[comp];
+  if (threadIdx.x == 0)
+    {
+    sh_bad = 0u;
+    produced = 0u;
+    consumed = 0u;
+    }
   const uint32_t len = args.size[comp];
   if (len < 5u)
     {
-    if (lane == 0) atomicOr(status, 1u);
+    if (threadIdx.x == 0) atomicOr(status, 1u);
     return;
     }
   const uint32_t e1 = (uint32_t)(in[0] >> 4) << 1, e2 = (uint32_t)(in[0] & 15) << 1;
   const uint32_t cnt = ((uint32_t)in[1] << 24) | ((uint32_t)in[2] << 16) | ((uint32_t)in[3] << 8) | in[4];
   if (cnt != n || e1 == 0u || e2 == 0u || e1 > E || e2 > E)
     {
-    if (lane == 0) atomicOr(status, 2u);
+    if (threadIdx.x == 0) atomicOr(status, 2u);
     return;
     }
+  __syncthreads();
   const u64* T1 = tables + (size_t)comp * 2 * TSIZE;
   const u64* T2 = T1 + TSIZE;
-  // The tables start at zero (fpsc.c:822-833).  They are zeroed HERE, through the scalar cache this wave will read them
-  // through, so that no stale line of an earlier kernel that used the same buffer can be hit (2 x 8 MiB = 1 M stores of 16
-  // bytes, ~3 ms; the launcher's memset only covers what the vector side might read).
-  for (uint32_t off = 0; off < 2u * TSIZE * 8u; off += 64u)
-    asm volatile("s_mov_b64 s[40:41], 0\n s_mov_b64 s[42:43], 0\n"
-                 "s_store_dwordx4 s[40:43], %0, %1\n s_store_dwordx4 s[40:43], %0, %2\n"
-                 "s_store_dwordx4 s[40:43], %0, %3\n s_store_dwordx4 s[40:43], %0, %4"
-                 :: "s"(T1), "s"(off), "s"(off + 16u), "s"(off + 32u), "s"(off + 48u) : "s40", "s41", "s42", "s43", "memory");
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const u64 m1 = (1ull << e1) - 1ull, m2 = (1ull << e2) - 1ull;
-  const uint32_t sh1 = 64u - e1, sh2 = 64u - e2, e2h = e2 >> 1;
-  const uint32_t al = (uint32_t)((uintptr_t)in & 3u);
-  const uint32_t* abase = (const uint32_t*)(in - al);
-  const uint32_t total_q = len + al;
-  const uint32_t ndw = (total_q + 3u) >> 2;
-  uint32_t wd = 0, q = 5u + al;
-  auto refill = [&](uint32_t from_q)
+  const uint32_t* xring = scratch + SCR64_DWORDS * (uint32_t)comp;        // RING64 slots of 64 residuals
+  const uint32_t* oring = xring + 128u * RING64;                           // RING64 slots of 64 values
+  const uint32_t nb = (n + 63u) / 64u;                                     // the last batch may be partial
+  if (wave == 1)
     {
-    __syncthreads();
-    wd = from_q >> 2;
-    for (uint32_t i = (uint32_t)lane; i < (uint32_t)WINW + 8u; i += 64u)
-      win[i] = (wd + i < ndw) ? abase[wd + i] : 0u;
-    __syncthreads();
-    };
-  refill(q);
-  __builtin_amdgcn_s_setprio(3);                        // the chain owns its SIMD's issue slots whenever it can issue
-  const uint8_t* wb = (const uint8_t*)win;
-  // wave-uniform chain state.  fwd1 / fwd2: the hash did not change with the last value, so the entry of the current hash
-  // is the value / stride just stored and is taken from the register (p1 / t2v) instead of being loaded
-  uint32_t h1 = 0, h2 = 0;
-  u64 p1 = 0, last = 0, t2v = 0;
-  bool fwd1 = true, fwd2 = true;                      // zeroed tables: the entries of hash 0 are 0
-  bool bad = false;
-  for (uint32_t i0 = 0; i0 < n; i0 += 64u)
-    {
-    if (q + BATCH_BYTES + 16u > 4u * (wd + (uint32_t)WINW))
-      refill(q);
-    const uint32_t nvals = n - i0 < 64u ? n - i0 : 64u;
-    const uint32_t ngroups = (nvals + 1u) >> 1;
-    // ---- positions of the groups: scalar walk over the header bytes ---------------------------------
-    uint32_t lq = q - 4u * wd;
-    uint32_t myhdr = 0, myq = 0;
-    for (uint32_t g = 0; g < ngroups; ++g)
+    // ---- parser: group headers and residuals of batch t, values of the finished batches to memory ----------------
+    const uint32_t al = (uint32_t)((uintptr_t)in & 3u);
+    const uint32_t* abase = (const uint32_t*)(in - al);
+    const uint32_t total_q = len + al;
+    const uint32_t ndw = (total_q + 3u) >> 2;
+    uint32_t wd = 0, q = 5u + al;
+    auto refill = [&](uint32_t from_q)
       {
-      const uint32_t hdr = rfl((uint32_t)wb[lq]);
-      if (((uint32_t)lane >> 1) == g)
-        {
-        myhdr = hdr;
-        myq = lq;
-        }
-      lq += 1u + nib_len(hdr & 15u) + nib_len(hdr >> 4);
-      }
-    const uint32_t qend = 4u * wd + lq;
-    if (qend > total_q)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      wd = from_q >> 2;
+      for (uint32_t i = (uint32_t)lane; i < (uint32_t)WINW + 8u; i += 64u)
+        win[i] = (wd + i < ndw) ? abase[wd + i] : 0u;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      };
+    refill(q);
+    const uint8_t* wb = (const uint8_t*)win;
+    uint32_t t = 0, st = 0;
+    while (st < nb)
       {
-      bad = true;
-      break;
-      }
-    q = qend;
-    // ---- all lanes fetch their residual -----------------------------------------------------------------
-    const uint32_t code = (lane & 1) ? (myhdr >> 4) : (myhdr & 15u);
-    const uint32_t nb = nib_len(code);
-    const uint32_t rp = myq + 1u + ((lane & 1) ? nib_len(myhdr & 15u) : 0u);
-    const uint32_t w0 = win[rp >> 2], w1 = win[(rp >> 2) + 1u], w2 = win[(rp >> 2) + 2u];
-    const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, rp & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, rp & 3u);
-    const u64 be = ((u64)__builtin_bswap32(lo) << 32) | __builtin_bswap32(hi);      // first stream byte on top
-    const u64 xr = nb ? be >> (8u * (8u - nb)) : 0ull;
-    const uint64_t dfcm = __ballot(code > 8u);
-    // ---- the dependent chain (wave-uniform, scalar unit) ---------------------------------------------------
-    // Per value ONE table entry is needed: the DFCM entry if the value is DFCM-coded, else the FCM entry
-    // (fpsc.c:977-978), and only if the hash changed with the previous value; both tables are written for every value
-    // (fpsc.c:980-995), fire and forget.  On noisy doubles that is one dependent miss into an 8 MiB table (Infinity
-    // Cache, ~230 ns) for the DFCM-coded values and a scalar-cache / L2 hit for the others.
-    u64 outv = 0;
-    for (uint32_t k = 0; k < nvals; ++k)
-      {
-      const u64 x = readlane64(xr, (int)k);
-      u64 p;
-      if ((dfcm >> k) & 1ull)
+      const uint32_t cdone = rfl(__hip_atomic_load(&consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+      bool progress = false;
+      for (; st < cdone; ++st)
         {
-        if (!fwd2)
-          t2v = table_load(T2, h2 << 3);
-        p = last + t2v;                                           // prediction2 = value + table entry
+        const u64 v = get_words64(oring + 128u * (st % RING64));
+        const uint32_t idx = 64u * st + (uint32_t)lane;
+        if (idx < n)
+          dst[(size_t)idx * arity + comp] = v;
+        progress = true;
         }
-      else
+      if (t < nb && t < st + RING64)
         {
-        if (!fwd1)
-          p1 = table_load(T1, h1 << 3);
-        p = p1;
+        progress = true;
+        if (q + BATCH_BYTES + 16u > 4u * (wd + (uint32_t)WINW))
+          refill(q);
+        const uint32_t i0 = 64u * t;
+        const uint32_t nvals = n - i0 < 64u ? n - i0 : 64u;
+        const uint32_t ngroups = (nvals + 1u) >> 1;
+        // positions of the groups: scalar walk over the header bytes
+        uint32_t lq = q - 4u * wd;
+        uint32_t myhdr = 0, myq = 0;
+        for (uint32_t g = 0; g < ngroups; ++g)
+          {
+          const uint32_t hdr = rfl((uint32_t)wb[lq]);
+          if (((uint32_t)lane >> 1) == g)
+            {
+            myhdr = hdr;
+            myq = lq;
+            }
+          lq += 1u + nib_len(hdr & 15u) + nib_len(hdr >> 4);
+          }
+        const uint32_t qend = 4u * wd + lq;
+        if (qend > total_q)
+          {
+          if (lane == 0)
+            __hip_atomic_store(&sh_bad, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          break;
+          }
+        q = qend;
+        // all lanes fetch their residual
+        const uint32_t code = (lane & 1) ? (myhdr >> 4) : (myhdr & 15u);
+        const uint32_t nbytes = nib_len(code);
+        const uint32_t rp = myq + 1u + ((lane & 1) ? nib_len(myhdr & 15u) : 0u);
+        const uint32_t w0 = win[rp >> 2], w1 = win[(rp >> 2) + 1u], w2 = win[(rp >> 2) + 2u];
+        const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, rp & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, rp & 3u);
+        const u64 be = ((u64)__builtin_bswap32(lo) << 32) | __builtin_bswap32(hi);      // first stream byte on top
+        const u64 xr = nbytes ? be >> (8u * (8u - nbytes)) : 0ull;
+        const uint64_t dfcm = __ballot(code > 8u);
+        put_words64(xr, xring + 128u * (t % RING64));
+        if (lane == 0)
+          {
+          dmask[t % RING64][0] = (uint32_t)dfcm;
+          dmask[t % RING64][1] = (uint32_t)(dfcm >> 32);
+          __hip_atomic_store(&produced, t + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        ++t;
         }
-      const u64 v = x ^ p;
-      const u64 s = v - last;
-      table_store(T1, h1 << 3, v);                                // hash_table_1[hash1] = value
-      table_store(T2, h2 << 3, s);                                // hash_table_2[hash2] = stride
-      const uint32_t nh1 = (uint32_t)((((u64)h1 << e1) ^ (v >> sh1)) & m1);
-      const uint32_t nh2 = (uint32_t)((((u64)h2 << e2h) ^ (s >> sh2)) & m2);
-      fwd1 = nh1 == h1;
-      fwd2 = nh2 == h2;
-      h1 = nh1;
-      h2 = nh2;
-      p1 = v;
-      t2v = s;
-      last = v;
-      outv = ((uint32_t)lane == k) ? v : outv;
+      if (!progress)
+        __builtin_amdgcn_s_sleep(4);
       }
-    const uint32_t idx = i0 + (uint32_t)lane;
-    if (idx < n)
-      dst[(size_t)idx * arity + comp] = outv;
     }
-  // no dirty line of the scalar cache may outlive the table buffer
-  asm volatile("s_dcache_wb\n s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (bad && lane == 0)
+  else
+    {
+    // ---- chain (wave-uniform, scalar unit) -------------------------------------------------------------------------
+    // The tables start at zero (fpsc.c:822-833).  They are zeroed HERE, through the scalar cache this wave will read them
+    // through, so that no stale line of an earlier kernel that used the same buffer can be hit (2 x 8 MiB = 1 M stores of 16
+    // bytes, ~3 ms).
+    for (uint32_t off = 0; off < 2u * TSIZE * 8u; off += 64u)
+      asm volatile("s_mov_b64 s[40:41], 0\n s_mov_b64 s[42:43], 0\n"
+                   "s_store_dwordx4 s[40:43], %0, %1\n s_store_dwordx4 s[40:43], %0, %2\n"
+                   "s_store_dwordx4 s[40:43], %0, %3\n s_store_dwordx4 s[40:43], %0, %4"
+                   :: "s"(T1), "s"(off), "s"(off + 16u), "s"(off + 32u), "s"(off + 48u) : "s40", "s41", "s42", "s43", "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(3);                        // the chain owns its SIMD's issue slots whenever it can issue
+    const u64 m1 = (1ull << e1) - 1ull, m2 = (1ull << e2) - 1ull;
+    const uint32_t sh1 = 64u - e1, sh2 = 64u - e2, e2h = e2 >> 1;
+    // fwd1 / fwd2: the hash did not change with the last value, so the entry of the current hash is the value / stride just
+    // stored and is taken from the register (p1 / t2v) instead of being loaded
+    uint32_t h1 = 0, h2 = 0;
+    u64 p1 = 0, last = 0, t2v = 0;
+    bool fwd1 = true, fwd2 = true;                        // zeroed tables: the entries of hash 0 are 0
+    for (uint32_t t = 0; t < nb; ++t)
+      {
+      bool stop = false;
+      while (rfl(__hip_atomic_load(&produced, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) <= t)
+        {
+        if (rfl(__hip_atomic_load(&sh_bad, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)))
+          {
+          stop = true;
+          break;
+          }
+        __builtin_amdgcn_s_sleep(1);
+        }
+      if (stop)
+        break;
+      const uint32_t b = t % RING64;
+      const uint64_t dfcm = ((uint64_t)rfl(dmask[b][1]) << 32) | rfl(dmask[b][0]);
+      const uint32_t nvals = n - 64u * t < 64u ? n - 64u * t : 64u;
+      // Per value ONE table entry is needed: the DFCM entry if the value is DFCM-coded, else the FCM entry
+      // (fpsc.c:977-978), and only if the hash changed with the previous value; both tables are written for every value
+      // (fpsc.c:980-995), fire and forget.  On noisy doubles that is one dependent miss into an 8 MiB table (Infinity
+      // Cache, ~230 ns) for the DFCM-coded values and a scalar-cache / L2 hit for the others.
+      for (uint32_t j = 0; 8u * j < nvals; ++j)
+        {
+        Oct64 xs, vs;
+        load_oct(xring + 128u * b, 64u * j, xs);
+#pragma unroll
+        for (uint32_t k8 = 0; k8 < 8u; ++k8)
+          {
+          const uint32_t k = 8u * j + k8;
+          u64 p;
+          if ((dfcm >> k) & 1ull)
+            {
+            if (!fwd2)
+              t2v = table_load(T2, h2 << 3);
+            p = last + t2v;                                         // prediction2 = value + table entry
+            }
+          else
+            {
+            if (!fwd1)
+              p1 = table_load(T1, h1 << 3);
+            p = p1;
+            }
+          const u64 v = xs.v[k8] ^ p;
+          const u64 s = v - last;
+          // (the padding slots of a partial last batch run too: nothing reads the tables or the state after them)
+          table_store(T1, h1 << 3, v);                              // hash_table_1[hash1] = value
+          table_store(T2, h2 << 3, s);                              // hash_table_2[hash2] = stride
+          const uint32_t nh1 = (uint32_t)((((u64)h1 << e1) ^ (v >> sh1)) & m1);
+          const uint32_t nh2 = (uint32_t)((((u64)h2 << e2h) ^ (s >> sh2)) & m2);
+          fwd1 = nh1 == h1;
+          fwd2 = nh2 == h2;
+          h1 = nh1;
+          h2 = nh2;
+          p1 = v;
+          t2v = s;
+          last = v;
+          vs.v[k8] = v;
+          }
+        store_oct(oring + 128u * b, 64u * j, vs);
+        }
+      if (lane == 0)
+        __hip_atomic_store(&consumed, t + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    // no dirty line of the scalar cache may outlive the table buffer
+    asm volatile("s_dcache_wb\n s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  __syncthreads();
+  if (sh_bad && threadIdx.x == 0)
     atomicOr(status, 4u);
   }
 
@@ -434,8 +568,10 @@ int launch_fpc64_decode(const uint8_t* const d_payloads[3], const uint32_t sizes
   // one chain per CU (see launch_fpc32_decode): the workgroup claims more than half of the CU's LDS
   constexpr size_t CLAIM = 72u << 10;
   static const bool claimed = hipFuncSetAttribute((const void*)k_fpc64_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLAIM) == hipSuccess;
-  hipLaunchKernelGGL(k_fpc64_decode, dim3(arity), dim3(64), claimed ? CLAIM : 0, current_stream(), a, arity, n, (u64*)d_dst, (u64*)d_tables,
-                     d_status);
+  // the rings of the two waves live behind the tables: FPC64_DECODE_SCRATCH_BYTES per component
+  uint32_t* scratch = (uint32_t*)(d_tables + (size_t)arity * 2 * TSIZE);
+  hipLaunchKernelGGL(k_fpc64_decode, dim3(arity), dim3(128), claimed ? CLAIM : 0, current_stream(), a, arity, n, (u64*)d_dst, (u64*)d_tables,
+                     scratch, d_status);
   return hip_ok(hipGetLastError(), "k_fpc64_decode") ? 1 : 0;
   }
 

@@ -509,7 +509,7 @@ static int fpc_decode_launch(trico_hip_ctx* ctx, const uint8_t* const payloads[3
   if (width == 8 || !lds_tables)
     {
     const size_t tb = (size_t)arity * table_stride * (size_t)width;
-    if (!ctx->tmp.reserve(tb))
+    if (!ctx->tmp.reserve(tb + 3 * FPC64_DECODE_SCRATCH_BYTES))
       return 0;
     if (!standard || force_serial_stage(2))          // the throughput double decoder zeroes its tables itself, through the scalar cache
       TRICO_HIP_TRY(hipMemsetAsync(ctx->tmp.p, 0, tb, current_stream()));
