@@ -15,12 +15,16 @@
 //     v_readlane inside a scalar instruction stream                  ~21 cycles
 //   * wave 1 (parser) stages the payload through LDS, finds the 8 groups of the next 64 values with a short scalar walk
 //     over the 3-byte headers, lets all 64 lanes locate, align and byte-swap their residual at once, and hands the
-//     residuals (scalar stores) and the mask of DFCM-coded values (LDS) to wave 0; it also stores the previous batch's
-//     values.  The two waves are coupled only through two counters in LDS (a ring of four batches).
+//     residuals and the mask of DFCM-coded values to wave 0 through a ring of four batches in scalar memory.
 //   * wave 0 (chain) runs the recurrence, fully unrolled and branch-free, on the SCALAR unit, with the DFCM table (1024
-//     entries) in global memory behind the scalar data cache and the FCM table (16 entries) in SGPRs: see below.
+//     entries) in global memory behind the scalar data cache and the FCM table (16 entries) in SGPRs: see below.  It is one
+//     asm statement from the first value to the last: it polls the parser's counter with a scalar load, stores the 64 values
+//     of a batch with one vector store straight into the interleaved output, and publishes its own counter with a scalar
+//     store — no LDS instruction, no barrier and no v_readlane on its path.
 // History: one wave, scalar chain with branches and both tables in registers: 165-225 cycles per value (69-93 ns); vector
-// chain with the tables in LDS: 146; this design: 87 cycles = 38-43 ns per value whatever the stream.
+// chain with the tables in LDS: 146; scalar chain, one barrier per batch: 38-43 ns; LDS counters instead of the barrier and
+// the parser storing the values: 37-41 ns (~400 cycles of handshake, table save / restore and LDS traffic per batch); this
+// design: 35-37 ns per value whatever the stream.
 // Streams with table exponents below the (4,10) the archive API writes, and stream tails (< 64 values), take the
 // reference-order loop of one lane at the end of the file.
 //
@@ -65,30 +69,31 @@ __device__ __forceinline__ uint32_t lens_sum(uint32_t x)
 //     {cand, lm} = dfcm ? {previous stride, last} : {T1 entry, 0}      s_bitcmp1, s_cselect_b64   (while the load is in flight)
 //     q = (dfcm and not forwarded) ? loaded T2 entry : cand            s_bitcmp1, s_waitcnt, s_cselect
 //     v = x ^ (q + lm); s = v - last                                   s_add, s_xor, s_sub        (fpsc.c:308-311, 323)
-//     a2' = ((s & 0xffc00000) ^ P) >> 20; load T2[a2']; T2[a2] = s     s_and, s_xor, s_lshr, s_load, s_store   (fpsc.c:81-84, 324-326)
+//     T2[a2] = s; a2' = ((s & 0xffc00000) ^ P) >> 20; load T2[a2']     s_store, s_and, s_xor, s_lshr, s_load   (fpsc.c:81-84, 324-326)
 //     T1[M0] = v; M0 = v >> 28; T1 entry = T1[M0]                      s_movreld, s_lshr, s_movrels   (fpsc.c:76-79, 312-314)
 //     P = (s & 0xffc00000) << 5; forwarded = (a2' == a2)               s_lshl, s_cmp_lg, s_cselect
 //     out lane K = v                                                   v_writelane
 // 20 instructions; the critical path (wait ... load) is 8 ALU instructions + the load = ~73 cycles, the rest issues under
 // the load.
 // One value.  Registers alternate between consecutive values (value / last, stride / previous stride, hash address /
-// previous hash address) so that nothing is copied.  The T2 load of the new hash is issued BEFORE the store of this
-// value's stride under the old hash; when both addresses are equal the load has read the entry too early and the next
-// value takes the stride from the register instead (`g` = the DFCM mask of the coming value, or 0 if forwarding).  A
-// scalar load issued right after a scalar store to the same address is NOT reliably ordered behind it when the line
-// misses (smem2.hip under cache pressure; a parity test caught it too); every other store is complete before the
-// next value starts, because each value begins with s_waitcnt lgkmcnt(0).
+// previous hash address) so that nothing is copied.  The store of this value's stride under the old hash is issued as soon
+// as the stride exists, the T2 load of the new hash four instructions later; a scalar load issued after a scalar store to
+// the same address is NOT reliably ordered behind it when the line misses (smem2.hip under cache pressure; a parity test
+// caught it too), so when both addresses are equal the loaded word is ignored and the next value takes the stride from the
+// register instead (`g` = the DFCM mask of the coming value, or 0 if forwarding).  Every other store is complete before the
+// next value starts, because each value begins with s_waitcnt lgkmcnt(0) — which waits for the store as well as for the
+// load, so the store goes first (issued behind the load it cost the noisy stream 1 ns per value).
 // v_readlane costs ~21 cycles in a scalar instruction stream (tools/ubench/chain4.hip), so the residuals do not come from
 // a VGPR: the parser wave puts them into global memory with scalar stores (same scalar cache, same CU) and the chain
 // loads eight at a time with s_load_dwordx8.  Fixed registers (clobbered by the statement):
 //   s[52:53] = {stride, value} of the previous value on even steps, s[54:55] on odd steps
 //   s[56:57] = {T1 entry of the current hash, 0}    s[58:59] = {cand, lm}: one s_cselect_b64 picks {stride, value} or {T1 entry, 0}
 //   s[60:67], s[68:75] residuals of the current / next eight values      s[84:99] the FCM table (s_movrels / s_movreld, M0 = hash)
-//   D: mask word of value K, DN: mask word of value K + 1
-#define CH4_XLOAD(K) "s_load_dwordx8 s[60 + (((" #K ") + 8) & 15) : 67 + (((" #K ") + 8) & 15)], %[Xb], 4 * ((" #K ") + 8)\n"
+//   D: register with the mask word of value K, DN: of value K + 1
+#define CH4_XLOAD(K) "s_load_dwordx8 s[60 + (((" #K ") + 8) & 15) : 67 + (((" #K ") + 8) & 15)], s[78:79], 4 * ((" #K ") + 8)\n"
 #define CH4_NOX(K) ""
 #define CH4_STEP(K, D, DN, PIN, PINV, POUTS, POUTV, AO, AN, XL)       \
-  "s_bitcmp1_b32 %[" D "], (" #K ") & 31\n"                          \
+  "s_bitcmp1_b32 " D ", (" #K ") & 31\n"                             \
   "s_cselect_b64 s[58:59], " PIN ", s[56:57]\n"                      \
   "s_bitcmp1_b32 %[g], (" #K ") & 31\n"                              \
   "s_waitcnt lgkmcnt(0)\n"                                           \
@@ -96,49 +101,86 @@ __device__ __forceinline__ uint32_t lens_sum(uint32_t x)
   "s_add_u32 %[q], %[q], s59\n"                                      \
   "s_xor_b32 " POUTV ", s[60 + ((" #K ") & 15)], %[q]\n"             \
   "s_sub_u32 " POUTS ", " POUTV ", " PINV "\n"                       \
+  "s_store_dword " POUTS ", %[T2b], %[" AO "]\n"                     \
   "s_and_b32 %[h], " POUTS ", 0xffc00000\n"                          \
   "s_xor_b32 %[q], %[h], %[P]\n"                                     \
   "s_lshr_b32 %[" AN "], %[q], 20\n"                                 \
   "s_load_dword %[t2], %[T2b], %[" AN "]\n"                          \
-  "s_store_dword " POUTS ", %[T2b], %[" AO "]\n"                     \
   XL(K)                                                               \
   "s_movreld_b32 s84, " POUTV "\n"                                   \
   "s_lshr_b32 m0, " POUTV ", 28\n"                                   \
   "s_lshl_b32 %[P], %[h], 5\n"                                       \
   "s_movrels_b32 s56, s84\n"                                         \
   "s_cmp_lg_u32 %[" AN "], %[" AO "]\n"                              \
-  "s_cselect_b32 %[g], %[" DN "], 0\n"                               \
+  "s_cselect_b32 %[g], " DN ", 0\n"                                  \
   "v_writelane_b32 %[outv], " POUTV ", " #K "\n"
 #define CH4_EVEN(K, D, DN, XL) CH4_STEP(K, D, DN, "s[52:53]", "s53", "s54", "s55", "a2a", "a2b", XL)
 #define CH4_ODD(K, D, DN, XL) CH4_STEP(K, D, DN, "s[54:55]", "s55", "s52", "s53", "a2b", "a2a", XL)
 #define CH4_OCT(B, D, DN, XL) CH4_EVEN(B + 0, D, D, XL) CH4_ODD(B + 1, D, D, CH4_NOX) CH4_EVEN(B + 2, D, D, CH4_NOX) CH4_ODD(B + 3, D, D, CH4_NOX) \
                               CH4_EVEN(B + 4, D, D, CH4_NOX) CH4_ODD(B + 5, D, D, CH4_NOX) CH4_EVEN(B + 6, D, D, CH4_NOX) CH4_ODD(B + 7, D, DN, CH4_NOX)
 
-// wave-uniform chain state (SGPRs); the FCM table is parked in the stream's scratch between batches
-struct Chain4 { uint32_t last, sprev, a2, P, t2, fwd; };
+// Scratch of one stream in global memory (FPC32_DECODE_TABLE_BYTES), touched by this workgroup only and only through the
+// scalar cache: DFCM table (4 KiB), FCM table for the tail (64 B), at SCRATCH_X RING slots of 512 B (64 residuals, then the
+// mask of DFCM-coded values), then the two counters that couple the waves, each in a cache line of its own.
+constexpr uint32_t SCRATCH_DWORDS = 2048, SCRATCH_T1 = 1024, SCRATCH_X = 1088;
+constexpr uint32_t RING = 4;                  // batches the parser may run ahead of the chain
+constexpr uint32_t SLOT_DWORDS = 128;
+constexpr uint32_t SCRATCH_PRODUCED = SCRATCH_X + RING * SLOT_DWORDS, SCRATCH_CONSUMED = SCRATCH_PRODUCED + 16;
+constexpr uint32_t SCRATCH_USED = SCRATCH_CONSUMED + 16;          // dwords zeroed at the start (a multiple of 16)
+static_assert(SCRATCH_PRODUCED * 4 == 0x1900 && SCRATCH_CONSUMED * 4 == 0x1940 && SCRATCH_USED <= SCRATCH_DWORDS, "offsets are spelled out in the chain");
+constexpr uint32_t ABORT = 0xffffffffu;       // `produced` when the parser gives up: the chain stops
 
-// one batch of 64 values; T2b: the stream's scratch in global memory (DFCM table, then 64 B for the FCM table); Xb: the 64
-// residuals of the batch (written by the parser wave with scalar stores).  Returns the 64 values (lane K = value K).
-__device__ __forceinline__ uint32_t chain4_batch(Chain4& c, uint32_t dlo, uint32_t dhi, const uint32_t* T2b, const uint32_t* Xb)
+struct ChainEnd { uint32_t last, a2; };       // what the tail loop needs: last value, byte address of the current DFCM entry
+
+// The whole chain of a stream: batches 0 .. nb-1 of 64 values.  Per batch: wait until the parser has published it (scalar load
+// of `produced`), load its mask and first eight residuals, 64 values, one vector store of the 64 values straight to their
+// place in the interleaved output (lane K holds value K), publish `consumed`.  One asm statement, so that the FCM table and the
+// rest of the state stay in their registers from the first value to the last.
+//   s[76:77] scratch / batch counter    s[78:79] ring slot of the batch    s[80:81] output address of the batch's value 0
+//   s82, s83 mask of DFCM-coded values
+__device__ __forceinline__ ChainEnd chain4_run(const uint32_t* T2b, uint32_t nb, uint32_t* out0, uint32_t voff, uint32_t out_step)
   {
-  uint32_t outv = 0, a2b, q, h, g;
+  const uint64_t xb = (uint64_t)(uintptr_t)(T2b + SCRATCH_X), ob = (uint64_t)(uintptr_t)out0;
+  const uint32_t xlo = (uint32_t)xb, xhi = (uint32_t)(xb >> 32), olo = (uint32_t)ob, ohi = (uint32_t)(ob >> 32);
+  uint32_t last, sprev, a2a, a2b, P, t2, fwd, outv, q, h, g;
   asm volatile(
-    "s_load_dwordx8 s[60:67], %[Xb], 0x0\n"
-    "s_load_dwordx4 s[84:87], %[T2b], 0x1000\n"
-    "s_load_dwordx4 s[88:91], %[T2b], 0x1010\n"
-    "s_load_dwordx4 s[92:95], %[T2b], 0x1020\n"
-    "s_load_dwordx4 s[96:99], %[T2b], 0x1030\n"
-    "s_mov_b32 s52, %[sprev]\n"
-    "s_mov_b32 s53, %[last]\n"
-    "s_mov_b32 s57, 0\n"
-    "s_lshr_b32 m0, %[last], 28\n"
-    "s_cmp_eq_u32 %[fwd], 0\n"
-    "s_cselect_b32 %[g], %[dlo], 0\n"
+    "s_mov_b64 s[84:85], 0\n s_mov_b64 s[86:87], 0\n s_mov_b64 s[88:89], 0\n s_mov_b64 s[90:91], 0\n"
+    "s_mov_b64 s[92:93], 0\n s_mov_b64 s[94:95], 0\n s_mov_b64 s[96:97], 0\n s_mov_b64 s[98:99], 0\n"
+    "s_mov_b64 s[52:53], 0\n s_mov_b64 s[56:57], 0\n s_mov_b32 m0, 0\n"
+    "s_mov_b32 %[a2a], 0\n s_mov_b32 %[P], 0\n s_mov_b32 %[t2], 0\n s_mov_b32 %[fwd], 1\n"
+    "s_mov_b32 s77, 0\n s_mov_b32 s80, %[olo]\n s_mov_b32 s81, %[ohi]\n"
+    "s_cmp_lt_u32 s77, %[nb]\n"
+    "s_cbranch_scc0 3f\n"
+    "0:\n"
+    "s_load_dword s76, %[T2b], 0x1900\n"
     "s_waitcnt lgkmcnt(0)\n"
-    "s_movrels_b32 s56, s84\n"
-    CH4_OCT(0, "dlo", "dlo", CH4_XLOAD) CH4_OCT(8, "dlo", "dlo", CH4_XLOAD) CH4_OCT(16, "dlo", "dlo", CH4_XLOAD) CH4_OCT(24, "dlo", "dhi", CH4_XLOAD)
-    CH4_OCT(32, "dhi", "dhi", CH4_XLOAD) CH4_OCT(40, "dhi", "dhi", CH4_XLOAD) CH4_OCT(48, "dhi", "dhi", CH4_XLOAD) CH4_OCT(56, "dhi", "dhi", CH4_NOX)
+    "s_cmp_gt_u32 s76, s77\n"
+    "s_cbranch_scc1 1f\n"
+    "s_sleep 1\n"
+    "s_branch 0b\n"
+    "1:\n"
+    "s_cmp_eq_u32 s76, -1\n"
+    "s_cbranch_scc1 3f\n"
+    "s_and_b32 s76, s77, 3\n"
+    "s_lshl_b32 s76, s76, 9\n"
+    "s_add_u32 s78, %[xlo], s76\n"
+    "s_addc_u32 s79, %[xhi], 0\n"
+    "s_load_dwordx2 s[82:83], s[78:79], 0x100\n"
+    "s_load_dwordx8 s[60:67], s[78:79], 0x0\n"
+    "s_cmp_eq_u32 %[fwd], 0\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    "s_cselect_b32 %[g], s82, 0\n"
+    CH4_OCT(0, "s82", "s82", CH4_XLOAD) CH4_OCT(8, "s82", "s82", CH4_XLOAD) CH4_OCT(16, "s82", "s82", CH4_XLOAD) CH4_OCT(24, "s82", "s83", CH4_XLOAD)
+    CH4_OCT(32, "s83", "s83", CH4_XLOAD) CH4_OCT(40, "s83", "s83", CH4_XLOAD) CH4_OCT(48, "s83", "s83", CH4_XLOAD) CH4_OCT(56, "s83", "s83", CH4_NOX)
     "s_cselect_b32 %[fwd], 0, 1\n"                     /* SCC still says whether the last load address differed from the last store address */
+    "global_store_dword %[voff], %[outv], s[80:81]\n"
+    "s_add_u32 s80, s80, %[ostep]\n"
+    "s_addc_u32 s81, s81, 0\n"
+    "s_add_u32 s77, s77, 1\n"
+    "s_store_dword s77, %[T2b], 0x1940\n"
+    "s_cmp_lt_u32 s77, %[nb]\n"
+    "s_cbranch_scc1 0b\n"
+    "3:\n"
     "s_mov_b32 %[sprev], s52\n"
     "s_mov_b32 %[last], s53\n"
     "s_store_dwordx4 s[84:87], %[T2b], 0x1000\n"
@@ -146,30 +188,45 @@ __device__ __forceinline__ uint32_t chain4_batch(Chain4& c, uint32_t dlo, uint32
     "s_store_dwordx4 s[92:95], %[T2b], 0x1020\n"
     "s_store_dwordx4 s[96:99], %[T2b], 0x1030\n"
     "s_waitcnt lgkmcnt(0)\n"
-    : [last] "+s"(c.last), [sprev] "+s"(c.sprev), [a2a] "+s"(c.a2), [a2b] "=&s"(a2b), [P] "+s"(c.P), [t2] "+s"(c.t2), [fwd] "+s"(c.fwd),
-      [outv] "+v"(outv), [q] "=&s"(q), [h] "=&s"(h), [g] "=&s"(g)
-    : [T2b] "s"(T2b), [Xb] "s"(Xb), [dlo] "s"(dlo), [dhi] "s"(dhi)
+    : [last] "=&s"(last), [sprev] "=&s"(sprev), [a2a] "=&s"(a2a), [a2b] "=&s"(a2b), [P] "=&s"(P), [t2] "=&s"(t2), [fwd] "=&s"(fwd),
+      [outv] "=&v"(outv), [q] "=&s"(q), [h] "=&s"(h), [g] "=&s"(g)
+    : [T2b] "s"(T2b), [xlo] "s"(xlo), [xhi] "s"(xhi), [olo] "s"(olo), [ohi] "s"(ohi), [voff] "v"(voff), [ostep] "s"(out_step), [nb] "s"(nb)
     : "scc", "memory", "m0", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
-      "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94",
-      "s95", "s96", "s97", "s98", "s99");
-  return outv;
+      "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87",
+      "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+  (void)sprev;
+  return ChainEnd{ last, a2a };
   }
 
-// parser wave: the 64 residuals of a batch (lane K = residual K) go to `Xb` with scalar stores, through the scalar cache the chain reads
-__device__ __forceinline__ void chain4_put_residuals(uint32_t xr, const uint32_t* Xb)
+// parser wave: the 64 residuals of a batch (lane K = residual K) and the mask of its DFCM-coded values go to the ring slot with
+// scalar stores, through the scalar cache the chain reads; complete on return
+__device__ __forceinline__ void chain4_put_batch(uint32_t xr, uint64_t dfcm, const uint32_t* slot)
   {
 #define CH4_PUT4(J, R0, R1, R2, R3) \
-  "v_readlane_b32 s" #R0 ", %[xr], 4 * " #J "\n v_readlane_b32 s" #R1 ", %[xr], 4 * " #J " + 1\n" \
-  "v_readlane_b32 s" #R2 ", %[xr], 4 * " #J " + 2\n v_readlane_b32 s" #R3 ", %[xr], 4 * " #J " + 3\n" \
-  "s_nop 0\n s_store_dwordx4 s[" #R0 ":" #R3 "], %[Xb], 16 * " #J "\n"
+  "v_readlane_b32 s" #R0 ", %[xr], 4 * (" #J ")\n v_readlane_b32 s" #R1 ", %[xr], 4 * (" #J ") + 1\n" \
+  "v_readlane_b32 s" #R2 ", %[xr], 4 * (" #J ") + 2\n v_readlane_b32 s" #R3 ", %[xr], 4 * (" #J ") + 3\n" \
+  "s_nop 0\n s_store_dwordx4 s[" #R0 ":" #R3 "], %[slot], 16 * (" #J ")\n"
   asm volatile(
     CH4_PUT4(0, 52, 53, 54, 55) CH4_PUT4(1, 56, 57, 58, 59) CH4_PUT4(2, 60, 61, 62, 63) CH4_PUT4(3, 64, 65, 66, 67)
     CH4_PUT4(4, 52, 53, 54, 55) CH4_PUT4(5, 56, 57, 58, 59) CH4_PUT4(6, 60, 61, 62, 63) CH4_PUT4(7, 64, 65, 66, 67)
     CH4_PUT4(8, 52, 53, 54, 55) CH4_PUT4(9, 56, 57, 58, 59) CH4_PUT4(10, 60, 61, 62, 63) CH4_PUT4(11, 64, 65, 66, 67)
     CH4_PUT4(12, 52, 53, 54, 55) CH4_PUT4(13, 56, 57, 58, 59) CH4_PUT4(14, 60, 61, 62, 63) CH4_PUT4(15, 64, 65, 66, 67)
+    "s_store_dwordx2 %[dfcm], %[slot], 0x100\n"
     "s_waitcnt lgkmcnt(0)\n"
-    :: [xr] "v"(xr), [Xb] "s"(Xb)
+    :: [xr] "v"(xr), [dfcm] "s"(dfcm), [slot] "s"(slot)
     : "memory", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67");
+  }
+
+// the counters that couple the two waves live in the scalar cache both of them go through
+__device__ __forceinline__ uint32_t counter_load(const uint32_t* base, uint32_t dword)
+  {
+  uint32_t r;
+  asm volatile("s_load_dword %0, %1, %2\n s_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(base), "s"(4u * dword) : "memory");
+  return r;
+  }
+__device__ __forceinline__ void counter_store(const uint32_t* base, uint32_t dword, uint32_t v)
+  {
+  asm volatile("s_store_dword %0, %1, %2\n s_waitcnt lgkmcnt(0)" :: "s"(v), "s"(base), "s"(4u * dword) : "memory");
   }
 
 // reference-order loop of one lane over LDS tables: stream tails (< 64 values) and table exponents below the API's (4,10)
@@ -204,19 +261,12 @@ __device__ void serial_values(const uint8_t* __restrict__ in, uint32_t len, uint
     }
   }
 
-// Scratch of one stream in global memory (FPC32_DECODE_TABLE_BYTES): DFCM table (4 KiB), FCM table between batches (64 B),
-// at 4352 RING slots of 64 residuals.  Only this workgroup touches it, and only through the scalar cache.
-constexpr uint32_t SCRATCH_DWORDS = 2048, SCRATCH_T1 = 1024, SCRATCH_X = 1088;
-constexpr uint32_t RING = 4;                  // batches the parser may run ahead of the chain (4 x 256 B of residuals at SCRATCH_X)
-
 __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity, uint32_t n, uint32_t* __restrict__ dst,
                                                       uint32_t* __restrict__ status, uint32_t* __restrict__ scratch)
   {
   __shared__ uint32_t win[WINW + 4];
   __shared__ uint32_t T2[1024], T1[16];          // tail loop only
-  __shared__ uint32_t dmask[RING][2];            // DFCM-coded values of a parsed batch
-  __shared__ uint32_t outb[RING][64];
-  __shared__ uint32_t sh_bad, sh_q, produced, consumed;
+  __shared__ uint32_t sh_bad, sh_q;
   const int lane = threadIdx.x & 63;
   const int wave = (int)rfl(threadIdx.x >> 6);
   const int comp = blockIdx.x;
@@ -228,8 +278,6 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
     {
     sh_bad = 0u;
     sh_q = 5u;
-    produced = 0u;
-    consumed = 0u;
     }
   const uint8_t* in = args.pay[comp];
   const uint32_t len = args.size[comp];
@@ -245,128 +293,101 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
     if (threadIdx.x == 0) atomicOr(status, 2u);
     return;
     }
-  __syncthreads();
   const bool standard = (e1 == 4u && e2 == 10u);
   const uint32_t nb = standard ? n / 64u : 0u;
-  Chain4 c = { 0u, 0u, 0u, 0u, 0u, 1u };
   const uint32_t* T2g = scratch + SCRATCH_DWORDS * (uint32_t)comp;
-  const uint32_t* Xg = T2g + SCRATCH_X;
   if (wave == 0 && nb)
     {
-    // the tables start at zero (fpsc.c:219-228); scalar stores, so that every line is in the scalar cache whatever it held
-    for (uint32_t off = 0; off < 4096u + 64u; off += 16u)
+    // the tables start at zero (fpsc.c:219-228) and so do the counters; scalar stores of whole lines, so that every line is in
+    // the scalar cache whatever it held
+    for (uint32_t off = 0; off < 4u * SCRATCH_USED; off += 16u)
       asm volatile("s_mov_b64 s[40:41], 0\n s_mov_b64 s[42:43], 0\n s_store_dwordx4 s[40:43], %0, %1" :: "s"(T2g), "s"(off) : "s40", "s41", "s42", "s43", "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-  // ---- parser state (wave 1): window over the payload, in units of aligned dwords of the underlying buffer ----------
-  const uint32_t al = (uint32_t)((uintptr_t)in & 3u);
-  const uint32_t* abase = (const uint32_t*)(in - al);
-  const uint32_t total_q = len + al;                     // payload end in aligned-byte coordinates
-  const uint32_t ndw = (total_q + 3u) >> 2;
-  uint32_t wd = 0;                                       // first dword of the window
-  uint32_t q = 5u + al;                                  // read cursor, aligned-byte coordinates
-  auto refill = [&](uint32_t from_q)
-    {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    wd = from_q >> 2;
-    for (uint32_t i = (uint32_t)lane; i < (uint32_t)WINW + 4u; i += 64u)
-      win[i] = (wd + i < ndw) ? abase[wd + i] : 0u;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    };
+  __syncthreads();
+  ChainEnd ce = { 0u, 0u };
+  // The two waves run decoupled through a ring of RING batches in the scratch: `produced` = batches parsed (slot t % RING holds
+  // batch t's residuals and mask), `consumed` = batches decoded; both counters are scalar-memory words, so the chain wave
+  // never touches LDS or a VGPR-to-SGPR path.  (First version of round 2: one barrier per batch, the chain lost 2-10 % waiting
+  // at it; second: LDS counters and the parser storing the values, ~400 cycles of chain time per batch.)
   if (wave == 1 && nb)
-    refill(q);
-  // The two waves run decoupled through a ring of RING batches: `produced` = batches parsed (slot t % RING holds batch t's
-  // residuals in the scratch and its DFCM mask in LDS), `consumed` = batches decoded (outb[t % RING] holds batch t's values).
-  // The parser parses batch t only after it has stored batch t - RING, so the chain never overwrites values that are not
-  // in memory yet.  (Round-2 first version: one barrier per batch; the chain lost 2-10 % waiting at it.)
-  if (wave == 1)
     {
-    uint32_t t = 0, st = 0;                              // next batch to parse / next batch to store
-    while (st < nb)
+    // ---- parser: window over the payload, in units of aligned dwords of the underlying buffer --------------------------
+    const uint32_t al = (uint32_t)((uintptr_t)in & 3u);
+    const uint32_t* abase = (const uint32_t*)(in - al);
+    const uint32_t total_q = len + al;                   // payload end in aligned-byte coordinates
+    const uint32_t ndw = (total_q + 3u) >> 2;
+    uint32_t wd = 0;                                     // first dword of the window
+    uint32_t q = 5u + al;                                // read cursor, aligned-byte coordinates
+    auto refill = [&](uint32_t from_q)
       {
-      const uint32_t cdone = rfl(__hip_atomic_load(&consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-      bool progress = false;
-      for (; st < cdone; ++st)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      wd = from_q >> 2;
+      for (uint32_t i = (uint32_t)lane; i < (uint32_t)WINW + 4u; i += 64u)
+        win[i] = (wd + i < ndw) ? abase[wd + i] : 0u;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      };
+    refill(q);
+    uint32_t t = 0;
+    bool failed = false;
+    while (t < nb)
+      {
+      if (t >= counter_load(T2g, SCRATCH_CONSUMED) + RING)
         {
-        dst[(size_t)(64u * st + (uint32_t)lane) * arity + comp] = outb[st % RING][lane];
-        progress = true;
+        __builtin_amdgcn_s_sleep(4);
+        continue;
         }
-      if (t < nb && t < st + RING)
-        {
-        progress = true;
-        if (q + BATCH_BYTES + 8u > 4u * (wd + (uint32_t)WINW))
-          refill(q);
-        // ---- positions of the 8 groups: scalar walk over the headers -----------------------------------
-        uint32_t lq = q - 4u * wd;
-        uint32_t bcv = 0, myq = 0;
+      if (q + BATCH_BYTES + 8u > 4u * (wd + (uint32_t)WINW))
+        refill(q);
+      // ---- positions of the 8 groups: scalar walk over the headers -----------------------------------
+      uint32_t lq = q - 4u * wd;
+      uint32_t bcv = 0, myq = 0;
 #pragma unroll
-        for (uint32_t g = 0; g < 8u; ++g)
+      for (uint32_t g = 0; g < 8u; ++g)
+        {
+        const uint32_t w = rfl(__builtin_amdgcn_alignbyte(win[(lq >> 2) + 1u], win[lq >> 2], lq & 3u));
+        const uint32_t bc = __builtin_bswap32(w) >> 8;              // 3 header bytes, big-endian (fpsc.c:245-247)
+        if (((uint32_t)lane >> 3) == g)
           {
-          const uint32_t w = rfl(__builtin_amdgcn_alignbyte(win[(lq >> 2) + 1u], win[lq >> 2], lq & 3u));
-          const uint32_t bc = __builtin_bswap32(w) >> 8;              // 3 header bytes, big-endian (fpsc.c:245-247)
-          if (((uint32_t)lane >> 3) == g)
-            {
-            bcv = bc;
-            myq = lq;
-            }
-          lq += 3u + lens_sum(bc);
+          bcv = bc;
+          myq = lq;
           }
-        const uint32_t qend = 4u * wd + lq;
-        if (qend > total_q)
-          {
-          if (lane == 0)
-            __hip_atomic_store(&sh_bad, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-          break;
-          }
-        q = qend;
-        // ---- all 64 lanes fetch their residual ------------------------------------------------------------
-        const uint32_t j3 = 3u * ((uint32_t)lane & 7u);
-        const uint32_t code = (bcv >> j3) & 7u;
-        const uint32_t nbytes = code <= 4u ? code : code - 4u;
-        const uint32_t rp = myq + 3u + lens_sum(bcv & ((1u << j3) - 1u));
-        const uint32_t raw = __builtin_amdgcn_alignbyte(win[(rp >> 2) + 1u], win[rp >> 2], rp & 3u);
-        const uint32_t xr = nbytes ? __builtin_bswap32(raw) >> (8u * (4u - nbytes)) : 0u;
-        const uint64_t dfcm = __ballot(code > 4u);
-        chain4_put_residuals(xr, Xg + 64u * (t % RING));          // scalar stores, complete on return
-        if (lane == 0)
-          {
-          dmask[t % RING][0] = (uint32_t)dfcm;
-          dmask[t % RING][1] = (uint32_t)(dfcm >> 32);
-          sh_q = q - al;
-          __hip_atomic_store(&produced, t + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-        ++t;
+        lq += 3u + lens_sum(bc);
         }
-      if (!progress)
-        __builtin_amdgcn_s_sleep(2);
+      const uint32_t qend = 4u * wd + lq;
+      if (qend > total_q)
+        {
+        failed = true;
+        break;
+        }
+      q = qend;
+      // ---- all 64 lanes fetch their residual ------------------------------------------------------------
+      const uint32_t j3 = 3u * ((uint32_t)lane & 7u);
+      const uint32_t code = (bcv >> j3) & 7u;
+      const uint32_t nbytes = code <= 4u ? code : code - 4u;
+      const uint32_t rp = myq + 3u + lens_sum(bcv & ((1u << j3) - 1u));
+      const uint32_t raw = __builtin_amdgcn_alignbyte(win[(rp >> 2) + 1u], win[rp >> 2], rp & 3u);
+      const uint32_t xr = nbytes ? __builtin_bswap32(raw) >> (8u * (4u - nbytes)) : 0u;
+      const uint64_t dfcm = __ballot(code > 4u);
+      chain4_put_batch(xr, dfcm, T2g + SCRATCH_X + SLOT_DWORDS * (t % RING));
+      ++t;
+      counter_store(T2g, SCRATCH_PRODUCED, t);
+      }
+    if (failed)
+      counter_store(T2g, SCRATCH_PRODUCED, ABORT);
+    if (lane == 0)
+      {
+      sh_q = q - al;
+      if (failed)
+        sh_bad = 1u;
       }
     }
-  else
+  else if (wave == 0 && nb)
     {
     // the chain owns its SIMD's issue slots whenever it can issue: other kernels' waves (the sweeps of the LZ4 decoder, other
     // archives) may share the CU
     __builtin_amdgcn_s_setprio(3);
-    for (uint32_t t = 0; t < nb; ++t)
-      {
-      bool stop = false;
-      while (rfl(__hip_atomic_load(&produced, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) <= t)
-        {
-        if (rfl(__hip_atomic_load(&sh_bad, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)))
-          {
-          stop = true;
-          break;
-          }
-        __builtin_amdgcn_s_sleep(1);
-        }
-      if (stop)
-        break;
-      const uint32_t b = t % RING;
-      const uint32_t dlo = rfl(dmask[b][0]), dhi = rfl(dmask[b][1]);
-      outb[b][lane] = chain4_batch(c, dlo, dhi, T2g, Xg + 64u * b);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0)
-        __hip_atomic_store(&consumed, t + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
+    ce = chain4_run(T2g, nb, dst + comp, 4u * (uint32_t)lane * (uint32_t)arity, 256u * (uint32_t)arity);
     }
   __syncthreads();
   bool bad = sh_bad != 0u;
@@ -389,7 +410,7 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
   if (!bad && i0 < n && threadIdx.x == 0)
     {
     // tail of the stream (fewer than 64 values, fpsc.c:329-414), or a stream with smaller tables than the API's
-    uint32_t pos = sh_q, h1 = c.last >> 28, h2 = c.a2 >> 2, last = c.last;
+    uint32_t pos = sh_q, h1 = ce.last >> 28, h2 = ce.a2 >> 2, last = ce.last;
     serial_values(in, len, pos, i0, n, e1, e2, h1, h2, last, T1, T2, dst, arity, comp, bad);
     }
   if (bad && lane == 0)
