@@ -403,6 +403,41 @@ __global__ void __launch_bounds__(64) k_lz4_parse(const uint8_t* __restrict__ pl
             snapTs + ck * 4096, endTs + ck * 4096, lane);
   }
 
+// ---- which geometry?  -----------------------------------------------------------------------------------------------------
+// A plane of long matches (the grid's index planes: a few dozen sequences per chunk) is bound by the serial stitch pass, whose
+// re-parses grow with the number of chunks and shrink with the warm-up; a plane of short sequences (a real mesh's second
+// index plane: one sequence per 7 bytes) is bound by the ~1.5 us a wave needs per sequence, i.e. by how many chunk waves the
+// GPU holds at once, and its table state converges within a few KiB.  Measured on the MI355X (4 x 300 MB planes):
+//     chunk / warm-up        grid      walk
+//     1 MiB / 384 KiB        70 ms    294 ms
+//     384 KiB / 96 KiB      136 ms    164 ms
+// So the launcher looks first: PROBE_S windows of PROBE_W bytes per plane are parsed as stand-alone blocks, and the densest
+// plane's bytes per sequence decide.  The choice never changes the output, only the time.
+constexpr uint32_t PROBE_S = 8, PROBE_W = 4096, PROBE_DCAP = PROBE_W / 4 + 16;
+
+__global__ void __launch_bounds__(64) k_lz4_probe(const uint8_t* __restrict__ planes, uint32_t n, size_t plane_stride, Desc* __restrict__ descs,
+                                                  Meta* __restrict__ metas)
+  {
+  __shared__ uint32_t tab[4096];
+  __shared__ uint8_t dup[4096];
+  const int lane = threadIdx.x;
+  const uint32_t s = blockIdx.x, p = blockIdx.y;
+  for (int i = lane; i < 4096; i += 64)
+    tab[i] = 0u;
+  __syncthreads();
+  const size_t pw = (size_t)p * PROBE_S + s;
+  Meta* meta = metas + pw;
+  if (lane == 0)
+    {
+    meta->snap_valid = 0; meta->snap_ip = 0; meta->end_kind = END_NONE; meta->end_ip = 0; meta->ndesc = 0; meta->accepted = 0;
+    meta->first_in = 0; meta->reparsed = 0;
+    }
+  const uint32_t section = n / PROBE_S;                                     // n >= the chunked threshold (MiB)
+  const uint32_t w0 = s * section + (section - PROBE_W) / 2u;
+  lz4_parse<1>(planes + (size_t)p * plane_stride + w0, PROBE_W, tab, dup, 0u, false, true, true, 0u, 0xffffffffu, descs + pw * PROBE_DCAP,
+            PROBE_DCAP, meta, nullptr, nullptr, lane);
+  }
+
 // One workgroup per plane walks the chain: accept speculative chunks whose snapshot is equivalent to the true state, re-parse the
 // others.  Re-parsing is serial by nature (the next chunk needs this one's end state) and on periodic planes it consists of a
 // few dozen matches of tens of KiB per chunk, i.e. of counting equal bytes: STITCH_W waves run the same walk and the same
@@ -676,19 +711,27 @@ __global__ void __launch_bounds__(EMIT_T) k_lz4_emit(const uint8_t* __restrict__
 
 struct Plan { Geom g; size_t off_desc, off_meta, off_snap, off_end, off_cbytes, off_coff, total; };
 
-Plan make_plan(uint32_t n, int nplanes, size_t plane_stride)
+// mode 0: long matches (1 MiB chunks, 384 KiB warm-up), mode 1: short sequences (384 KiB / 96 KiB); TRICO_LZ4_CHUNK / TRICO_LZ4_WARM
+// fix one geometry for both (tuning knobs)
+static bool geometry_forced() { return getenv("TRICO_LZ4_CHUNK") || getenv("TRICO_LZ4_WARM"); }
+
+Plan make_plan(uint32_t n, int nplanes, size_t plane_stride, int mode)
   {
-  static uint32_t chunk = 0, warm = 0;
-  if (!chunk)
+  static uint32_t env_chunk = 0, env_warm = 0;
+  static bool forced = false;
+  if (!env_chunk)
     {
+    forced = geometry_forced();
     const char* e = getenv("TRICO_LZ4_CHUNK");
-    chunk = e ? (uint32_t)atoi(e) : (1u << 20);
-    if (chunk < (1u << 17)) chunk = 1u << 17;
+    env_chunk = e ? (uint32_t)atoi(e) : (1u << 20);
+    if (env_chunk < (1u << 17)) env_chunk = 1u << 17;
     const char* w = getenv("TRICO_LZ4_WARM");
-    warm = w ? (uint32_t)atoi(w) : (384u << 10);
-    if (warm < 70000u) warm = 70000u;
-    if (warm > chunk) warm = chunk;
+    env_warm = w ? (uint32_t)atoi(w) : (384u << 10);
+    if (env_warm < 70000u) env_warm = 70000u;
+    if (env_warm > env_chunk) env_warm = env_chunk;
     }
+  const uint32_t chunk = forced || mode == 0 ? env_chunk : (384u << 10);
+  const uint32_t warm = forced || mode == 0 ? env_warm : (96u << 10);
   Plan p;
   p.g.n = n;
   p.g.chunk = chunk;
@@ -708,6 +751,17 @@ Plan make_plan(uint32_t n, int nplanes, size_t plane_stride)
   return p;
   }
 
+// the probe's descriptors and chunk records live behind the larger of the two plans
+size_t probe_bytes(int nplanes)
+  {
+  return align_up((size_t)nplanes * PROBE_S * (PROBE_DCAP * sizeof(Desc) + sizeof(Meta)), 256) + 256;
+  }
+size_t plans_bytes(uint32_t n, int nplanes, size_t plane_stride)
+  {
+  const size_t a = make_plan(n, nplanes, plane_stride, 0).total, b = make_plan(n, nplanes, plane_stride, 1).total;
+  return align_up(a > b ? a : b, 256);
+  }
+
 } // namespace
 
 // planes at or above this size take the chunked path (below, one workgroup per plane is faster)
@@ -725,19 +779,40 @@ uint32_t lz4_chunked_threshold()
 
 size_t lz4_chunked_workspace(uint32_t n, int nplanes, size_t plane_stride)
   {
-  return make_plan(n, nplanes, plane_stride).total;
+  return plans_bytes(n, nplanes, plane_stride) + probe_bytes(nplanes);
   }
 
 int launch_lz4_encode_chunked(const uint8_t* d_planes, size_t plane_stride, uint32_t n, int nplanes, uint8_t* d_out, size_t out_stride,
                               uint32_t* d_sizes, uint8_t* d_ws, size_t ws_bytes, uint32_t* d_status)
   {
-  const Plan p = make_plan(n, nplanes, plane_stride);
-  if (p.total > ws_bytes)
+  if (lz4_chunked_workspace(n, nplanes, plane_stride) > ws_bytes || nplanes > 8)
     {
     set_error("lz4 chunked encode: workspace too small");
     return 0;
     }
   hipStream_t st = current_stream();
+  int mode = 0;
+  if (!geometry_forced())
+    {
+    // look before parsing: bytes per sequence of the densest plane (see k_lz4_probe)
+    uint8_t* pa = d_ws + plans_bytes(n, nplanes, plane_stride);
+    Meta* pm = (Meta*)pa;
+    Desc* pd = (Desc*)(pa + align_up((size_t)nplanes * PROBE_S * sizeof(Meta), 256));
+    hipLaunchKernelGGL(k_lz4_probe, dim3(PROBE_S, nplanes), dim3(64), 0, st, d_planes, n, plane_stride, pd, pm);
+    Meta h[8 * PROBE_S];
+    if (!hip_ok(hipMemcpyAsync(h, pm, (size_t)nplanes * PROBE_S * sizeof(Meta), hipMemcpyDeviceToHost, st), "lz4 probe readback") ||
+        !hip_ok(hipStreamSynchronize(st), "lz4 probe"))
+      return 0;
+    for (int pl = 0; pl < nplanes; ++pl)
+      {
+      uint32_t nd = 0;
+      for (uint32_t k = 0; k < PROBE_S; ++k)
+        nd += h[pl * PROBE_S + k].ndesc;
+      if ((uint64_t)nd * 48u > (uint64_t)PROBE_S * PROBE_W)                 // fewer than 48 bytes per sequence
+        mode = 1;
+      }
+    }
+  const Plan p = make_plan(n, nplanes, plane_stride, mode);
   Desc* descs = (Desc*)(d_ws + p.off_desc);
   Meta* metas = (Meta*)(d_ws + p.off_meta);
   uint32_t* snapTs = (uint32_t*)(d_ws + p.off_snap);
