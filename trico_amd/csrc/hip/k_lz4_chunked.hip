@@ -31,6 +31,7 @@ namespace {
 
 constexpr uint32_t MAXD = 65535u;          // LZ4_DISTANCE_MAX (lz4.h:535)
 constexpr int EMIT_T = 256;
+constexpr uint32_t EMIT_STAGE = 8192;        // bytes of one emit round that are assembled in LDS
 
 struct __attribute__((packed, aligned(1))) u32u { uint32_t v; };
 struct __attribute__((packed, aligned(1))) u64u { uint64_t v; };
@@ -598,13 +599,21 @@ __device__ __forceinline__ void block_copy(uint8_t* __restrict__ dst, const uint
   }
 
 // writes the block bytes of every accepted chunk
+// A literal run of BIG_RUN bytes or more (an incompressible plane is ONE run of 300 MB) is not copied by the workgroup that
+// meets it: it goes to a list, and k_lz4_bigcopy moves all listed runs in 256 KiB pieces with the whole GPU.
+constexpr uint32_t BIG_RUN = 1u << 20, BIG_PIECE = 256u << 10, BIG_CAP = 4096;
+struct BigJob { uint32_t plane, src, dst, len; };
+struct BigList { uint32_t count, pad[3]; BigJob job[BIG_CAP]; };
+
 __global__ void __launch_bounds__(EMIT_T) k_lz4_emit(const uint8_t* __restrict__ planes, Geom g, const Desc* __restrict__ descs,
                                                      const Meta* __restrict__ metas, const uint32_t* __restrict__ chunk_off,
-                                                     uint8_t* __restrict__ out_base, size_t out_stride)
+                                                     uint8_t* __restrict__ out_base, size_t out_stride, BigList* __restrict__ big)
   {
   __shared__ uint32_t sc_out[EMIT_T], sc_in[EMIT_T];
+  __shared__ uint32_t wsum_out[EMIT_T / 64], wsum_in[EMIT_T / 64];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[EMIT_STAGE + 8];
   __shared__ uint32_t jobs[EMIT_T];
-  __shared__ uint32_t njobs;
+  __shared__ uint32_t njobs, big_slot;
   const uint32_t k = blockIdx.x, p = blockIdx.y;
   const size_t ck = (size_t)p * g.K + k;
   if (!metas[ck].accepted)
@@ -626,52 +635,79 @@ __global__ void __launch_bounds__(EMIT_T) k_lz4_emit(const uint8_t* __restrict__
       es = enc_size(d);
       is = d.lit + d.ml;
       }
-    sc_out[tid] = es;
-    sc_in[tid] = is;
+    // inclusive scans of the encoded and the source sizes: inside the wave with DPP shifts, across the four waves through LDS
+    {
+    uint32_t a = es, b = is;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1)
+      {
+      const uint32_t ua = (uint32_t)__shfl_up((int)a, o), ub = (uint32_t)__shfl_up((int)b, o);
+      if ((tid & 63) >= o) { a += ua; b += ub; }
+      }
+    if ((tid & 63) == 63) { wsum_out[tid >> 6] = a; wsum_in[tid >> 6] = b; }
     if (tid == 0) njobs = 0;
     __syncthreads();
-    for (int o = 1; o < EMIT_T; o <<= 1)
-      {
-      const uint32_t a = tid >= o ? sc_out[tid - o] : 0u, b = tid >= o ? sc_in[tid - o] : 0u;
-      __syncthreads();
-      sc_out[tid] += a;
-      sc_in[tid] += b;
-      __syncthreads();
-      }
+    for (int w = 0; w < (tid >> 6); ++w) { a += wsum_out[w]; b += wsum_in[w]; }
+    sc_out[tid] = a;
+    sc_in[tid] = b;
+    __syncthreads();
+    }
     const uint32_t opos = carry_out + sc_out[tid] - es, ipos = carry_in + sc_in[tid] - is;
-    if (i < nd)
+    const uint32_t mcode = d.ml ? d.ml - 4u : 0u;
+    const uint32_t le = ext_bytes(d.lit);
+    const bool long_job = i < nd && (d.lit > 96u || le > 96u || ext_bytes(mcode) > 96u);
+    if (long_job)
+      jobs[atomicAdd(&njobs, 1u)] = (uint32_t)tid;
+    __syncthreads();
+    // Short sequences (a plane of 7-byte sequences has 50,000 per chunk) are assembled in LDS and leave as aligned dwords:
+    // byte stores straight to memory made this pass 33 ms on the walk mesh.
+    const uint32_t total_out = sc_out[EMIT_T - 1];
+    const bool staged = njobs == 0u && total_out <= EMIT_STAGE;
+    if (i < nd && !long_job)
       {
-      uint8_t* o = out + opos;
-      const uint32_t mcode = d.ml ? d.ml - 4u : 0u;
+      uint8_t* o = staged ? stage + (opos - carry_out) : out + opos;
       const uint32_t tl = d.lit >= 15u ? 15u : d.lit, tm = d.ml ? (mcode >= 15u ? 15u : mcode) : 0u;
       *o++ = (uint8_t)((tl << 4) | tm);
-      const uint32_t le = ext_bytes(d.lit);
-      const bool long_job = d.lit > 96u || le > 96u || ext_bytes(mcode) > 96u;
-      if (long_job)
-        jobs[atomicAdd(&njobs, 1u)] = (uint32_t)tid;
-      else
+      if (le)
         {
-        if (le)
+        for (uint32_t q = 0; q + 1u < le; ++q) *o++ = 255;
+        *o++ = (uint8_t)((d.lit - 15u) % 255u);
+        }
+      for (uint32_t q = 0; q < d.lit; ++q) o[q] = src[ipos + q];
+      o += d.lit;
+      if (d.ml)
+        {
+        *o++ = (uint8_t)d.off;
+        *o++ = (uint8_t)(d.off >> 8);
+        const uint32_t me = ext_bytes(mcode);
+        if (me)
           {
-          for (uint32_t q = 0; q + 1u < le; ++q) *o++ = 255;
-          *o++ = (uint8_t)((d.lit - 15u) % 255u);
-          }
-        for (uint32_t q = 0; q < d.lit; ++q) o[q] = src[ipos + q];
-        o += d.lit;
-        if (d.ml)
-          {
-          *o++ = (uint8_t)d.off;
-          *o++ = (uint8_t)(d.off >> 8);
-          const uint32_t me = ext_bytes(mcode);
-          if (me)
-            {
-            for (uint32_t q = 0; q + 1u < me; ++q) *o++ = 255;
-            *o++ = (uint8_t)((mcode - 15u) % 255u);
-            }
+          for (uint32_t q = 0; q + 1u < me; ++q) *o++ = 255;
+          *o++ = (uint8_t)((mcode - 15u) % 255u);
           }
         }
       }
+    else if (long_job)
+      out[opos] = (uint8_t)(((d.lit >= 15u ? 15u : d.lit) << 4) | (d.ml ? (mcode >= 15u ? 15u : mcode) : 0u));
     __syncthreads();
+    if (staged)
+      {
+      uint8_t* dst = out + carry_out;
+      const uint32_t head0 = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u);
+      const uint32_t head = head0 < total_out ? head0 : total_out;
+      if ((uint32_t)tid < head)
+        dst[tid] = stage[tid];
+      const uint32_t body = (total_out - head) >> 2;                      // aligned dwords of the destination
+      const uint32_t* sw = (const uint32_t*)stage;
+      for (uint32_t j = (uint32_t)tid; j < body; j += EMIT_T)
+        {
+        const uint32_t q = head + 4u * j;                                  // stage byte offset of this dword
+        *(uint32_t*)(dst + q) = __builtin_amdgcn_alignbyte(sw[(q >> 2) + 1u], sw[q >> 2], q & 3u);
+        }
+      const uint32_t done = head + 4u * body;
+      if ((uint32_t)tid < total_out - done)
+        dst[done + tid] = stage[done + tid];
+      }
     // long runs: the whole block works on one descriptor at a time
     const uint32_t nj = njobs;
     for (uint32_t jn = 0; jn < nj; ++jn)
@@ -688,7 +724,22 @@ __global__ void __launch_bounds__(EMIT_T) k_lz4_emit(const uint8_t* __restrict__
         if (tid == 0) o[le - 1u] = (uint8_t)((dj.lit - 15u) % 255u);
         o += le;
         }
-      block_copy(o, src + ip_j, dj.lit, tid);
+      bool listed = false;
+      if (dj.lit >= BIG_RUN)
+        {
+        if (tid == 0)
+          {
+          const uint32_t slot = atomicAdd(&big->count, 1u);
+          if (slot < BIG_CAP)
+            big->job[slot] = BigJob{ p, ip_j, (uint32_t)(o - out), dj.lit };
+          big_slot = slot;
+          }
+        __syncthreads();
+        listed = big_slot < BIG_CAP;
+        __syncthreads();
+        }
+      if (!listed)
+        block_copy(o, src + ip_j, dj.lit, tid);
       o += dj.lit;
       if (dj.ml)
         {
@@ -706,6 +757,27 @@ __global__ void __launch_bounds__(EMIT_T) k_lz4_emit(const uint8_t* __restrict__
     carry_out += sc_out[EMIT_T - 1];
     carry_in += sc_in[EMIT_T - 1];
     __syncthreads();
+    }
+  }
+
+__global__ void __launch_bounds__(EMIT_T) k_lz4_bigcopy(const uint8_t* __restrict__ planes, size_t plane_stride, uint8_t* __restrict__ out_base,
+                                                        size_t out_stride, const BigList* __restrict__ big)
+  {
+  const uint32_t nj = big->count < BIG_CAP ? big->count : BIG_CAP;
+  uint32_t first = 0;                                            // global index of job j's first piece
+  for (uint32_t j = 0; j < nj; ++j)
+    {
+    const BigJob b = big->job[j];
+    const uint32_t pieces = (b.len + BIG_PIECE - 1u) / BIG_PIECE;
+    // pieces first .. first + pieces - 1 belong to this job; this workgroup takes those congruent to its index
+    uint32_t q = (blockIdx.x + gridDim.x - first % gridDim.x) % gridDim.x;
+    for (; q < pieces; q += gridDim.x)
+      {
+      const uint32_t o0 = q * BIG_PIECE;
+      const uint32_t len = b.len - o0 < BIG_PIECE ? b.len - o0 : BIG_PIECE;
+      block_copy(out_base + (size_t)b.plane * out_stride + b.dst + o0, planes + (size_t)b.plane * plane_stride + b.src + o0, len, threadIdx.x);
+      }
+    first += pieces;
     }
   }
 
@@ -754,7 +826,8 @@ Plan make_plan(uint32_t n, int nplanes, size_t plane_stride, int mode)
 // the probe's descriptors and chunk records live behind the larger of the two plans
 size_t probe_bytes(int nplanes)
   {
-  return align_up((size_t)nplanes * PROBE_S * (PROBE_DCAP * sizeof(Desc) + sizeof(Meta)), 256) + 256;
+  const size_t probe = align_up((size_t)nplanes * PROBE_S * (PROBE_DCAP * sizeof(Desc) + sizeof(Meta)), 256) + 256;
+  return probe > sizeof(BigList) + 256 ? probe : sizeof(BigList) + 256;                 // k_lz4_emit's list of big runs reuses the area
   }
 size_t plans_bytes(uint32_t n, int nplanes, size_t plane_stride)
   {
@@ -843,7 +916,12 @@ int launch_lz4_encode_chunked(const uint8_t* d_planes, size_t plane_stride, uint
     }
   hipLaunchKernelGGL(k_lz4_sizes, dim3(p.g.K, nplanes), dim3(256), 0, st, p.g, descs, metas, cbytes);
   hipLaunchKernelGGL(k_lz4_offsets, dim3(nplanes), dim3(1024), 0, st, p.g, cbytes, coff, d_sizes);
-  hipLaunchKernelGGL(k_lz4_emit, dim3(p.g.K, nplanes), dim3(EMIT_T), 0, st, d_planes, p.g, descs, metas, coff, d_out, out_stride);
+  // the list of big literal runs takes the place of the probe's records
+  BigList* big = (BigList*)(d_ws + plans_bytes(n, nplanes, plane_stride));
+  if (!hip_ok(hipMemsetAsync(big, 0, 16, st), "memset(big runs)"))
+    return 0;
+  hipLaunchKernelGGL(k_lz4_emit, dim3(p.g.K, nplanes), dim3(EMIT_T), 0, st, d_planes, p.g, descs, metas, coff, d_out, out_stride, big);
+  hipLaunchKernelGGL(k_lz4_bigcopy, dim3(2048), dim3(EMIT_T), 0, st, d_planes, plane_stride, d_out, out_stride, big);
   return hip_ok(hipGetLastError(), "lz4 chunked encode kernels") ? 1 : 0;
   }
 
