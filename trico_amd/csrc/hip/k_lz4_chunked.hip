@@ -439,6 +439,41 @@ __global__ void __launch_bounds__(64) k_lz4_probe(const uint8_t* __restrict__ pl
             PROBE_DCAP, meta, nullptr, nullptr, lane);
   }
 
+// The stitch pass below is one serial walk per plane; what it does for a chunk whose predecessor needed no re-parse is a
+// comparison of two tables the parse pass has already written, so that comparison is done here for all chunks at once:
+// pre[chunk] = 1 if the chunk's snapshot sits at the ip where the speculative parse of the chunk before it ended and the two
+// tables agree there (entry by entry, or both entries beyond the 64 KiB window: lz4.c:945-948).
+__global__ void __launch_bounds__(64) k_lz4_precompare(Geom g, const Meta* __restrict__ metas, const uint32_t* __restrict__ snapTs,
+                                                       const uint32_t* __restrict__ endTs, uint32_t* __restrict__ pre)
+  {
+  const int lane = threadIdx.x;
+  const uint32_t j = blockIdx.x, p = blockIdx.y;
+  const size_t cj = (size_t)p * g.K + j;
+  bool ok = false;
+  if (j > 0)
+    {
+    const Meta a = metas[cj - 1], b = metas[cj];
+    const uint32_t ip = a.end_ip;
+    uint32_t jj = ip / g.chunk;
+    if (jj >= g.K) jj = g.K - 1u;
+    ok = a.end_kind == END_MATCH && jj == j && b.snap_valid != 0u && b.snap_ip == ip && b.end_kind != END_NONE;
+    if (ok)
+      {
+      const uint32_t* curT = endTs + (cj - 1) * 4096;
+      const uint32_t* snT = snapTs + cj * 4096;
+      bool same = true;
+      for (int i = lane; i < 4096; i += 64)
+        {
+        const uint32_t x = curT[i], y = snT[i];
+        same = same && (x == y || (x + MAXD < ip && y + MAXD < ip));
+        }
+      ok = __ballot(!same) == 0ull;
+      }
+    }
+  if (lane == 0)
+    pre[cj] = ok ? 1u : 0u;
+  }
+
 // One workgroup per plane walks the chain: accept speculative chunks whose snapshot is equivalent to the true state, re-parse the
 // others.  Re-parsing is serial by nature (the next chunk needs this one's end state) and on periodic planes it consists of a
 // few dozen matches of tens of KiB per chunk, i.e. of counting equal bytes: STITCH_W waves run the same walk and the same
@@ -449,7 +484,8 @@ constexpr int STITCH_W = 1;
 
 __global__ void __launch_bounds__(64 * STITCH_W) k_lz4_stitch(const uint8_t* __restrict__ planes, Geom g, Desc* __restrict__ descs,
                                                               Meta* __restrict__ metas, uint32_t* __restrict__ snapTs,
-                                                              uint32_t* __restrict__ endTs, uint32_t* __restrict__ status)
+                                                              uint32_t* __restrict__ endTs, const uint32_t* __restrict__ pre,
+                                                              uint32_t* __restrict__ status)
   {
   __shared__ uint32_t tabs[STITCH_W][4096];
   __shared__ uint8_t dups[STITCH_W][4096];
@@ -461,6 +497,7 @@ __global__ void __launch_bounds__(64 * STITCH_W) k_lz4_stitch(const uint8_t* __r
   const uint8_t* src = planes + (size_t)p * g.plane_stride;
   Meta* pm = metas + (size_t)p * g.K;
   uint32_t cur = 0;                               // last accepted chunk
+  bool cur_spec = true;                           // its end state is the one the parse pass wrote (not a re-parse)
   if (threadIdx.x == 0) pm[0].accepted = 1u;
   for (uint32_t guard = 0; guard < g.K + 2u; ++guard)
     {
@@ -484,7 +521,9 @@ __global__ void __launch_bounds__(64 * STITCH_W) k_lz4_stitch(const uint8_t* __r
     const uint32_t* curT = endTs + ((size_t)p * g.K + cur) * 4096;
     const uint32_t* snT = snapTs + ((size_t)p * g.K + j) * 4096;
     bool ok = uni(pm[j].snap_valid) != 0u && uni(pm[j].snap_ip) == ip && uni(pm[j].end_kind) != END_NONE;
-    if (ok)
+    if (ok && j == cur + 1u && cur_spec)
+      ok = uni(pre[(size_t)p * g.K + j]) != 0u;    // compared by k_lz4_precompare against exactly this state
+    else if (ok)
       {
       bool same = true;
       for (int i = lane; i < 4096; i += 64)
@@ -514,6 +553,7 @@ __global__ void __launch_bounds__(64 * STITCH_W) k_lz4_stitch(const uint8_t* __r
       if (!ok) atomicAdd(status + 2, 1u);
       }
     cur = j;
+    cur_spec = ok;
     }
   if (threadIdx.x == 0) atomicOr(status, 64u);
   }
@@ -893,7 +933,8 @@ int launch_lz4_encode_chunked(const uint8_t* d_planes, size_t plane_stride, uint
   uint32_t* cbytes = (uint32_t*)(d_ws + p.off_cbytes);
   uint32_t* coff = (uint32_t*)(d_ws + p.off_coff);
   hipLaunchKernelGGL(k_lz4_parse, dim3(p.g.K, nplanes), dim3(64), 0, st, d_planes, p.g, descs, metas, snapTs, endTs);
-  hipLaunchKernelGGL(k_lz4_stitch, dim3(nplanes), dim3(64 * STITCH_W), 0, st, d_planes, p.g, descs, metas, snapTs, endTs, d_status);
+  hipLaunchKernelGGL(k_lz4_precompare, dim3(p.g.K, nplanes), dim3(64), 0, st, p.g, metas, snapTs, endTs, coff);     // coff is free until k_lz4_offsets
+  hipLaunchKernelGGL(k_lz4_stitch, dim3(nplanes), dim3(64 * STITCH_W), 0, st, d_planes, p.g, descs, metas, snapTs, endTs, coff, d_status);
   if (getenv("TRICO_LZ4_DEBUG"))
     {
     const size_t cells = (size_t)p.g.K * nplanes;
