@@ -35,8 +35,10 @@ sys.path.insert(0, ROOT)
 
 # ROCm maps HIP streams onto 4 hardware queues by default and kernels sharing a queue run one after the other; every stream of
 # an archive decodes on its own HIP stream, so the process asks for more BEFORE anything initialises HIP (torch gets there
-# before libtrico does, which only sets this when it makes the first HIP call itself).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+# before libtrico does, which only sets this when it makes the first HIP call itself).  16, not more: with every one of 24 or
+# 32 queues busy the hardware scheduler time-slices them, and a decoder chain that is saved and restored on another compute
+# unit loses the table it keeps in that unit's scalar cache (trico_amd/csrc/hip/shim.hip, "the chain decoders and their self-check").
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 

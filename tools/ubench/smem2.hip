@@ -35,6 +35,17 @@ __global__ void kcheck(uint32_t* tab, uint32_t* res, uint32_t n, int store_first
   if (threadIdx.x == 0) res[blockIdx.x] = acc;
 }
 __global__ void noise(uint32_t* p, uint32_t k) { p[blockIdx.x * 64 + threadIdx.x] += k; }
+// a neighbour that uses the scalar cache: every wave walks a big buffer with scalar loads (argv[4] = 1)
+__global__ void evictor(const uint32_t* big, uint32_t words, uint32_t* sink, uint32_t iters) {
+  uint32_t x = 99991u * (blockIdx.x + 1u), acc = 0;
+  for (uint32_t i = 0; i < iters; ++i) {
+    x = x * 1664525u + 1013904223u;
+    uint32_t off = __builtin_amdgcn_readfirstlane(((x >> 8) % words) * 4u), got;
+    asm volatile("s_load_dword %0, %1, %2\n s_waitcnt lgkmcnt(0)" : "=s"(got) : "s"(big), "s"(off) : "memory");
+    acc += got;
+  }
+  if (threadIdx.x == 0) sink[blockIdx.x] = acc;
+}
 static uint32_t host_ref(uint32_t n, uint32_t b) {
   std::vector<uint32_t> T(1024, 0); uint32_t x = 12345u + b, acc = 0;
   for (uint32_t i = 0; i < n; ++i) { x = x * 1664525u + 1013904223u; uint32_t aw = (x >> 10) & 1023u, ar = (x >> 20) & 1023u, val = x ^ acc; if ((x & 7u) == 0u) ar = aw; T[aw] = val; uint32_t got = T[ar]; acc = acc * 31u + got; }
@@ -47,6 +58,10 @@ static uint32_t host_ref_loadfirst(uint32_t n, uint32_t b) {
 }
 int main(int argc, char** argv) {
   const int NB = argc > 1 ? atoi(argv[1]) : 24; const uint32_t N = argc > 2 ? (uint32_t)atoi(argv[2]) : 8000000u;
+  const int LDS = argc > 3 ? atoi(argv[3]) : 0;     // dynamic LDS claimed per workgroup (88 KB: one chain per CU, as the decoder does)
+  if (LDS) (void)hipFuncSetAttribute((const void*)kcheck, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  const int EVICT = argc > 4 ? atoi(argv[4]) : 0;
+  uint32_t *big, *sink; (void)hipMalloc(&big, 32u << 20); (void)hipMemset(big, 1, 32u << 20); (void)hipMalloc(&sink, 4 * 8192);
   uint32_t *tab, *res, *np; (void)hipMalloc(&tab, 4096 * NB); (void)hipMalloc(&res, 4 * NB); (void)hipMalloc(&np, 4 * 64 * 1024);
   (void)hipMemset(np, 0, 4 * 64 * 1024);
   hipStream_t sa, sb; (void)hipStreamCreateWithFlags(&sa, hipStreamNonBlocking); (void)hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
@@ -54,10 +69,10 @@ int main(int argc, char** argv) {
     const int store_first = mode & 1, with_noise = mode >> 1;
     (void)hipMemset(tab, 0xff, 4096 * NB);
     (void)hipDeviceSynchronize();
-    kcheck<<<NB, 64, 0, sa>>>(tab, res, N, store_first);
+    kcheck<<<NB, 64, LDS, sa>>>(tab, res, N, store_first);
     int launches = 0;
     if (with_noise)
-      while (hipStreamQuery(sa) == hipErrorNotReady) { noise<<<1024, 64, 0, sb>>>(np, 1); (void)hipMemsetAsync(np, 0, 4096, sb); ++launches; if ((launches & 63) == 0) (void)hipStreamSynchronize(sb); }
+      while (hipStreamQuery(sa) == hipErrorNotReady) { if (EVICT) evictor<<<2048, 64, 0, sb>>>(big, 8u << 20, sink, 2000); else noise<<<1024, 64, 0, sb>>>(np, 1); (void)hipMemsetAsync(np, 0, 4096, sb); ++launches; if ((launches & 63) == 0) (void)hipStreamSynchronize(sb); }
     (void)hipDeviceSynchronize();
     std::vector<uint32_t> h(NB); (void)hipMemcpy(h.data(), res, 4 * NB, hipMemcpyDeviceToHost);
     int bad = 0;

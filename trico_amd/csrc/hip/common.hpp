@@ -39,6 +39,14 @@ struct trico_hip_ctx
   trico::DevBuf aux;       // small: sizes, status words, segment summaries
   trico::DevBuf ws;        // large kernel workspaces (chunked LZ4 descriptors / tables)
   trico::DevBuf unit;      // de-interleaved components / planes of the unit encoders (dist.hip)
+  trico::DevBuf vws;       // self-check of the chain decoders: workspace and payloads of the re-encode (shim.hip)
+  // the decode the self-check belongs to (it may have to be repeated)
+  bool chk_active = false;
+  const uint8_t* chk_pay[3] = { nullptr, nullptr, nullptr };
+  uint32_t chk_sizes[3] = { 0, 0, 0 };
+  int chk_arity = 0, chk_width = 0;
+  uint32_t chk_n = 0;
+  void* chk_dst = nullptr;
   size_t out_stride = 0;
   uint32_t out_sizes[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
   uint32_t out_sizes_raw[24] = { 0 };
@@ -99,6 +107,10 @@ int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
                         uint8_t* d_ws, size_t ws_bytes);
 int launch_fpc32_gather(uint32_t n, int arity, int c, const uint8_t* d_ws, uint8_t* d_dst);
 int launch_fpc32_gather_all(uint32_t n, int arity, const uint8_t* d_ws, uint8_t* const d_dst[3]);
+int launch_fpc32_compare(uint32_t n, int arity, const uint8_t* d_ws, const uint32_t* d_sizes, const uint8_t* const d_pay[3],
+                         const uint32_t sizes[3], uint32_t* d_status, uint32_t flag);
+// generic: sets bit `flag` of *d_status if *d_size != n_expected or the first n_expected bytes of a and b differ
+int launch_bytes_compare(const uint8_t* d_a, const uint8_t* d_b, uint32_t n_expected, const uint32_t* d_size, uint32_t* d_status, uint32_t flag);
 bool force_serial();              // TRICO_HIP_SERIAL: see shim.hip
 bool force_serial_stage(int bit);
 

@@ -665,6 +665,42 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
     d[done + threadIdx.x] = s[done + threadIdx.x];
   }
 
+// ---- compare: segment slots against an existing payload -------------------------------------------------
+// The decoders check themselves by coding what they decoded and comparing with what they were given (shim.hip): the coder is a
+// deterministic function of the values, so equal payloads mean equal values.  Same walk as the gather, reading both sides.
+struct ComparePay { const uint8_t* p[3]; uint32_t size[3]; };
+
+__global__ void __launch_bounds__(256) k_fpc32_compare(const uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap, uint32_t S,
+                                                       const uint32_t* __restrict__ segbytes, const uint32_t* __restrict__ segoff,
+                                                       const uint32_t* __restrict__ sizes, ComparePay pay, uint32_t* __restrict__ status,
+                                                       uint32_t flag)
+  {
+  const uint32_t g = blockIdx.x, c = blockIdx.y;
+  if (sizes[c] != pay.size[c])
+    {
+    if (g == 0 && threadIdx.x == 0) atomicOr(status, flag << c);
+    return;
+    }
+  const uint32_t len = segbytes[(size_t)c * S + g];
+  const uint8_t* a = slots + (size_t)c * slot_stride + (size_t)g * segcap;       // 256-byte aligned
+  const uint8_t* b = pay.p[c] + segoff[(size_t)c * S + g];
+  bool diff = false;
+  const uint32_t words = len >> 2;
+  const uint32_t sh = (uint32_t)((uintptr_t)b & 3u);
+  const uint32_t* bw = (const uint32_t*)(b - sh);                                // aligned dwords around b
+  for (uint32_t t = threadIdx.x; t < words; t += 256u)
+    {
+    const uint32_t x = ((const uint32_t*)a)[t];
+    // the high dword is only read when its first byte belongs to this segment (sh != 0): never a whole dword past the payload
+    const uint32_t y = __builtin_amdgcn_alignbyte(sh ? bw[t + 1u] : 0u, bw[t], sh);
+    diff = diff || x != y;
+    }
+  for (uint32_t t = 4u * words + threadIdx.x; t < len; t += 256u)
+    diff = diff || a[t] != b[t];
+  if (diff)
+    atomicOr(status, flag << c);
+  }
+
 // n == 0: undefined in the reference; defined as header + one full pad group
 __global__ void k_fpc32_empty(uint8_t* out, size_t out_stride, uint32_t* sizes)
   {
@@ -768,6 +804,27 @@ int launch_fpc32_gather(uint32_t n, int arity, int c, const uint8_t* d_ws, uint8
   hipLaunchKernelGGL(k_fpc32_gather, dim3(p.S, 1), dim3(256), 0, current_stream(), slots + (size_t)c * p.slot_stride, (size_t)0,
                      p.segcap, p.S, segbytes + (size_t)c * p.S, segoff + (size_t)c * p.S, dst);
   return hip_ok(hipGetLastError(), "k_fpc32_gather") ? 1 : 0;
+  }
+
+// Compares the payloads of the last launch_fpc32_encode (same n, arity, workspace) with `d_pay` / `sizes`, without moving them:
+// bit (flag << c) of *d_status is set if component c differs in size or bytes.
+int launch_fpc32_compare(uint32_t n, int arity, const uint8_t* d_ws, const uint32_t* d_sizes, const uint8_t* const d_pay[3],
+                         const uint32_t sizes[3], uint32_t* d_status, uint32_t flag)
+  {
+  if (n == 0)
+    return 1;
+  const Plan p = make_plan(n, arity);
+  const uint32_t* segbytes = (const uint32_t*)(d_ws + p.off_segbytes);
+  const uint32_t* segoff = (const uint32_t*)(d_ws + p.off_segoff);
+  ComparePay pay;
+  for (int c = 0; c < 3; ++c)
+    {
+    pay.p[c] = c < arity ? d_pay[c] : nullptr;
+    pay.size[c] = c < arity ? sizes[c] : 0u;
+    }
+  hipLaunchKernelGGL(k_fpc32_compare, dim3(p.S, arity), dim3(256), 0, current_stream(), d_ws + p.off_slots, p.slot_stride, p.segcap, p.S,
+                     segbytes, segoff, d_sizes, pay, d_status, flag);
+  return hip_ok(hipGetLastError(), "k_fpc32_compare") ? 1 : 0;
   }
 
 // All components in one launch, each to its own destination (the archive writer knows all of them up front).

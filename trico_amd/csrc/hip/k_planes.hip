@@ -200,4 +200,30 @@ int launch_interleave(const uint8_t* d_soa, size_t comp_stride, uint32_t n, int 
   return hip_ok(hipGetLastError(), "k_interleave") ? 1 : 0;
   }
 
+
+// ---- payload comparison (the decoders' self-check, shim.hip) ---------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256) k_bytes_compare(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint32_t n,
+                                                       const uint32_t* __restrict__ d_size, uint32_t* __restrict__ status, uint32_t flag)
+  {
+  if (*d_size != n)
+    {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(status, flag);
+    return;
+    }
+  bool diff = false;
+  const uint32_t stride = gridDim.x * 256u;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += stride)     // bytes: the two sides are aligned differently
+    diff = diff || a[i] != b[i];
+  if (diff)
+    atomicOr(status, flag);
+  }
+}
+
+int launch_bytes_compare(const uint8_t* d_a, const uint8_t* d_b, uint32_t n_expected, const uint32_t* d_size, uint32_t* d_status, uint32_t flag)
+  {
+  hipLaunchKernelGGL(k_bytes_compare, dim3(4096), dim3(256), 0, current_stream(), d_a, d_b, n_expected, d_size, d_status, flag);
+  return hip_ok(hipGetLastError(), "k_bytes_compare") ? 1 : 0;
+  }
+
 } // namespace trico

@@ -48,7 +48,7 @@ bool force_serial_stage(int bit) { return (serial_mask() & bit) != 0; }
 // Device workspaces are recycled across contexts (one context per archive handle): hipMalloc / hipFree of
 // multi-GB buffers cost hundreds of milliseconds and an implicit device sync each.
 struct PoolEntry { uint8_t* p; size_t cap; };
-static PoolEntry g_pool[160];   // eight archives read at once park ~8 x 2 streams x 5 buffers
+static PoolEntry g_pool[1024];  // eight archives read at once park ~8 x 2 streams x 5 buffers
 static int g_pool_n = 0;
 static std::mutex g_pool_mutex;
 
@@ -251,6 +251,7 @@ void trico_hip_ctx_destroy(trico_hip_ctx* ctx)
   ctx->aux.release();
   ctx->ws.release();
   ctx->unit.release();
+  ctx->vws.release();
   if (ctx->h_pinned)
     (void)hipHostFree(ctx->h_pinned);
   delete ctx;
@@ -436,6 +437,91 @@ int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int
   return 1;
   }
 
+// ---- the chain decoders and their self-check -----------------------------------------------------------------------------
+// k_fpc32_decode / k_fpc64_decode keep their predictor tables behind the scalar data cache, as dirty lines (scalar stores).  That
+// state belongs to the compute unit the wave runs on, and it does not travel: when a process has more hardware queues in use
+// than the GPU has queue slots (measured on the MI355X: all of GPU_MAX_HW_QUEUES=24 or 32 busy; 16 busy queues are fine), the
+// hardware scheduler time-slices the queues, long-running waves are saved and restored, and a chain that comes back on another
+// compute unit reads its table from memory while newer entries still sit in the cache it left.  The decode then goes wrong
+// from some value on — silently: the payload is well-formed.  (Twelve and more archives decoded at once with 32 queues: 20-40 %
+// of the noisy streams; eight archives, or sixteen queues: none in hundreds of runs; write-through stores (glc) cure it at eight
+// times the time per value.)  Therefore:
+//   * libtrico asks for 16 hardware queues when it initialises HIP itself (device_ready), and INTEGRATION.md tells a host
+//     application to stay at or below that;
+//   * every decode of these kernels is CHECKED: the decoded values are coded again with the throughput encoder (1 ms for 50 M
+//     float vertices, 25 ms for doubles) and the bytes compared with the payload on the device.  The coder is a deterministic
+//     function of the values and the decoder of the payload, so equal payloads mean the values are the payload's values.  A
+//     stream that fails is decoded again: twice more by the same kernel, then by the reference-order kernel of k_serial.hip,
+//     which does not use the scalar cache (20x slower; trico_hip_last_stats word 2 counts the repeats).
+//     TRICO_HIP_DECODE_CHECK=0 switches the check off (measurements only).
+
+static bool decode_check_enabled()
+  {
+  static int v = -1;
+  if (v < 0)
+    {
+    const char* e = getenv("TRICO_HIP_DECODE_CHECK");
+    v = (e && e[0] == '0') ? 0 : 1;
+    }
+  return v != 0;
+  }
+
+// status bits 0x100 << c: component c of the re-encode differs from the payload
+constexpr uint32_t CHECK_BITS = 0x700u;
+
+static int fpc_check_launch(trico_hip_ctx* ctx, uint32_t* d_status)
+  {
+  const int arity = ctx->chk_arity, width = ctx->chk_width;
+  const uint32_t n = ctx->chk_n;
+  if (n == 0 || !decode_check_enabled())
+    return 1;
+  uint32_t* d_vsizes = (uint32_t*)ctx->aux.p + 64;                 // the status words are at the start of aux
+  if (width == 4)
+    {
+    const size_t ws = fpc32_encode_workspace(n, arity);
+    if (!ctx->vws.reserve(ws))
+      return 0;
+    return launch_fpc32_encode(ctx->chk_dst, n, arity, nullptr, 0, d_vsizes, ctx->vws.p, ctx->vws.cap) &&
+           launch_fpc32_compare(n, arity, ctx->vws.p, d_vsizes, ctx->chk_pay, ctx->chk_sizes, d_status, 0x100u);
+    }
+  const size_t stride = align_up(fpc_bound(n, 8), 256);
+  const bool sorted = n >= fpc64_sorted_threshold() && n <= 0x7fffffffu;
+  const size_t wsb = sorted ? fpc64_sorted_workspace(n) : (size_t)arity * 2 * ((size_t)1 << 20) * 8;
+  if (!ctx->vws.reserve(stride * arity + wsb + 256))
+    return 0;
+  uint8_t* out = ctx->vws.p;
+  uint8_t* wsp = ctx->vws.p + stride * arity;
+  if (sorted)
+    {
+    if (!launch_fpc64_encode_sorted(ctx->chk_dst, n, arity, out, stride, d_vsizes, wsp, wsb))
+      return 0;
+    }
+  else
+    {
+    TRICO_HIP_TRY(hipMemsetAsync(wsp, 0, wsb, current_stream()));
+    if (!launch_fpc64_encode(ctx->chk_dst, n, arity, out, stride, d_vsizes, (uint64_t*)wsp))
+      return 0;
+    }
+  for (int c = 0; c < arity; ++c)
+    if (!launch_bytes_compare(out + (size_t)c * stride, ctx->chk_pay[c], ctx->chk_sizes[c], d_vsizes + c, d_status, 0x100u << c))
+      return 0;
+  return 1;
+  }
+
+// launches the chain decoder for the stream remembered in ctx->chk_* and its check
+static int fpc_chain_decode(trico_hip_ctx* ctx)
+  {
+  const int arity = ctx->chk_arity, width = ctx->chk_width;
+  const uint32_t n = ctx->chk_n;
+  uint32_t* d_status = (uint32_t*)ctx->aux.p;
+  const size_t tb = width == 8 ? (size_t)arity * 2 * ((size_t)1 << 20) * 8 + 3 * FPC64_DECODE_SCRATCH_BYTES : 3 * FPC32_DECODE_TABLE_BYTES;
+  if (!ctx->tmp.reserve(tb))
+    return 0;
+  const int ok = width == 4 ? launch_fpc32_decode(ctx->chk_pay, ctx->chk_sizes, arity, n, ctx->chk_dst, d_status, (uint32_t*)ctx->tmp.p)
+                            : launch_fpc64_decode(ctx->chk_pay, ctx->chk_sizes, arity, n, ctx->chk_dst, (uint64_t*)ctx->tmp.p, d_status);
+  return ok && fpc_check_launch(ctx, d_status);
+  }
+
 // Stages the payloads, launches the decode into d_dst (ctx->out when NULL) on current_stream() and queues the
 // read-back of the status word; nothing waits.  decode_complete() below does.
 static int fpc_decode_launch(trico_hip_ctx* ctx, const uint8_t* const payloads[3], const uint32_t sizes[3],
@@ -515,16 +601,21 @@ static int fpc_decode_launch(trico_hip_ctx* ctx, const uint8_t* const payloads[3
       TRICO_HIP_TRY(hipMemsetAsync(ctx->tmp.p, 0, tb, current_stream()));
     d_tables = (uint64_t*)ctx->tmp.p;
     }
-  if (width == 4 && standard && !force_serial_stage(2))
+  ctx->chk_active = false;
+  if (standard && !force_serial_stage(2))
     {
-    if (!ctx->tmp.reserve(3 * FPC32_DECODE_TABLE_BYTES))
-      return 0;
-    if (!launch_fpc32_decode(d_pay, sizes, arity, n, d_dst, d_status, (uint32_t*)ctx->tmp.p))
-      return 0;
-    }
-  else if (width == 8 && standard && !force_serial_stage(2))
-    {
-    if (!launch_fpc64_decode(d_pay, sizes, arity, n, d_dst, d_tables, d_status))
+    // the chain decoders: checked by coding what they decoded (fpc_chain_decode), repeated by decode_complete if that fails
+    ctx->chk_active = true;
+    for (int c = 0; c < 3; ++c)
+      {
+      ctx->chk_pay[c] = c < arity ? d_pay[c] : nullptr;
+      ctx->chk_sizes[c] = c < arity ? sizes[c] : 0u;
+      }
+    ctx->chk_arity = arity;
+    ctx->chk_width = width;
+    ctx->chk_n = n;
+    ctx->chk_dst = d_dst;
+    if (!fpc_chain_decode(ctx))
       return 0;
     }
   else if (!launch_fpc_decode_serial(d_pay, sizes, arity, width, n, d_dst, d_tables, table_stride, d_status))
@@ -538,9 +629,47 @@ static int fpc_decode_launch(trico_hip_ctx* ctx, const uint8_t* const payloads[3
 static int decode_complete(trico_hip_ctx* ctx, const char* what)
   {
   TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
-  if (ctx->h_pinned[0] != 0)
+  uint32_t st = ctx->h_pinned[0];
+  for (int attempt = 1; ctx->chk_active && st != 0 && (st & ~CHECK_BITS) == 0 && attempt <= 3; ++attempt)
     {
-    set_error(what);
+    // the payload parsed but the values do not code back to it: the chain went wrong (see fpc_chain_decode).  Twice more, then
+    // in reference order without the scalar cache (20x slower).
+    g_stats[2] += 1;
+    if (getenv("TRICO_HIP_DEBUG"))
+      fprintf(stderr, "trico_hip: decode self-check failed (status %#x, %d x %u values of %d bytes), attempt %d\n", st, ctx->chk_arity, ctx->chk_n,
+              ctx->chk_width, attempt + 1);
+    uint32_t* d_status = (uint32_t*)ctx->aux.p;
+    TRICO_HIP_TRY(hipMemsetAsync(d_status, 0, 64, current_stream()));
+    if (attempt <= 2)
+      {
+      if (!fpc_chain_decode(ctx))
+        return 0;
+      }
+    else
+      {
+      const int arity = ctx->chk_arity, width = ctx->chk_width;
+      uint64_t* d_tables = nullptr;
+      size_t table_stride = 16 + 1024;
+      if (width == 8)
+        {
+        table_stride = (size_t)2 << 20;
+        const size_t tb = (size_t)arity * table_stride * 8;
+        if (!ctx->tmp.reserve(tb))
+          return 0;
+        TRICO_HIP_TRY(hipMemsetAsync(ctx->tmp.p, 0, tb, current_stream()));
+        d_tables = (uint64_t*)ctx->tmp.p;
+        }
+      if (!launch_fpc_decode_serial(ctx->chk_pay, ctx->chk_sizes, arity, width, ctx->chk_n, ctx->chk_dst, d_tables, table_stride, d_status))
+        return 0;
+      }
+    TRICO_HIP_TRY(hipMemcpyAsync(ctx->h_pinned, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, current_stream()));
+    TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
+    st = ctx->h_pinned[0];
+    }
+  ctx->chk_active = false;
+  if (st != 0)
+    {
+    set_error((st & CHECK_BITS) && (st & ~CHECK_BITS) == 0 ? "trico decode: the decoded values do not code back to the payload" : what);
     return 0;
     }
   return 1;
@@ -642,6 +771,7 @@ int trico_hip_int_encode(trico_hip_ctx* ctx, const void* src, uint32_t count, in
 static int int_decode_launch(trico_hip_ctx* ctx, const uint8_t* const payloads[8], const uint32_t sizes[8],
                              int width, uint32_t count, void* d_dst)
   {
+  ctx->chk_active = false;
   size_t total = 0, offs[8];
   bool any_host = false;
   for (int c = 0; c < width; ++c)
