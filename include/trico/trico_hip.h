@@ -154,8 +154,10 @@ enum trico_hip_kernel_id
   TRICO_HIP_K_LZ4_DECODE   = 7,
   TRICO_HIP_K_COUNT        = 8
   };
-/* diagnostics of the last trico_hip_int_encode on this thread: out[0] = LZ4 chunks accepted by the stitch
- * pass, out[1] = of those re-parsed serially (speculation not provably equivalent); 0,0 for small planes */
+/* diagnostics of this thread: out[0] = LZ4 chunks accepted by the stitch pass of the last trico_hip_int_encode,
+ * out[1] = of those re-parsed serially (speculation not provably equivalent); 0,0 for small planes;
+ * out[2] = float / double stream decodes that this thread had to repeat because the decoded values did not code
+ * back to the payload (the decoders check themselves, see shim.hip; counts up, never reset) */
 TRICO_API void trico_hip_last_stats(uint32_t out[4]);
 TRICO_API void trico_hip_profile_enable(int on);
 TRICO_API void trico_hip_profile_reset(void);

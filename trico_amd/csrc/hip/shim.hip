@@ -508,8 +508,17 @@ static int fpc_check_launch(trico_hip_ctx* ctx, uint32_t* d_status)
   return 1;
   }
 
-// launches the chain decoder for the stream remembered in ctx->chk_* and its check
-static int fpc_chain_decode(trico_hip_ctx* ctx)
+// test hook: TRICO_HIP_DECODE_SABOTAGE=k damages the output of the first k chain decodes of every stream (one bit of the last
+// value) before the check sees it, so that the repeat path can be exercised on purpose (tests/test_gpu_selfcheck.py)
+__global__ void k_flip_bit(uint8_t* p) { p[0] ^= 1u; }
+static int sabotage_count()
+  {
+  const char* e = getenv("TRICO_HIP_DECODE_SABOTAGE");
+  return e ? atoi(e) : 0;
+  }
+
+// launches the chain decoder for the stream remembered in ctx->chk_* and its check (attempt 0, 1, 2)
+static int fpc_chain_decode(trico_hip_ctx* ctx, int attempt = 0)
   {
   const int arity = ctx->chk_arity, width = ctx->chk_width;
   const uint32_t n = ctx->chk_n;
@@ -519,6 +528,8 @@ static int fpc_chain_decode(trico_hip_ctx* ctx)
     return 0;
   const int ok = width == 4 ? launch_fpc32_decode(ctx->chk_pay, ctx->chk_sizes, arity, n, ctx->chk_dst, d_status, (uint32_t*)ctx->tmp.p)
                             : launch_fpc64_decode(ctx->chk_pay, ctx->chk_sizes, arity, n, ctx->chk_dst, (uint64_t*)ctx->tmp.p, d_status);
+  if (ok && n && attempt < sabotage_count())
+    hipLaunchKernelGGL(k_flip_bit, dim3(1), dim3(1), 0, current_stream(), (uint8_t*)ctx->chk_dst + ((size_t)n * arity - 1) * width);
   return ok && fpc_check_launch(ctx, d_status);
   }
 
@@ -642,7 +653,7 @@ static int decode_complete(trico_hip_ctx* ctx, const char* what)
     TRICO_HIP_TRY(hipMemsetAsync(d_status, 0, 64, current_stream()));
     if (attempt <= 2)
       {
-      if (!fpc_chain_decode(ctx))
+      if (!fpc_chain_decode(ctx, attempt))
         return 0;
       }
     else
