@@ -38,7 +38,7 @@ namespace trico {
 
 namespace {
 
-constexpr int WINW = 2048;                 // staging window, dwords (8 KiB)
+constexpr int WINW = 512;                  // staging window, dwords (2 KiB): a refill must fit into the slack of the ring (8 and 32 KiB windows cost the noisy stream 2-4 ns per value)
 constexpr uint32_t BATCH_BYTES = 8 * 35;   // a batch of 8 groups needs at most this many payload bytes
 
 struct DecodeArgs
