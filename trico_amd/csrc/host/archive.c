@@ -537,9 +537,11 @@ static uint64_t readahead_budget(void)
   return budget;
   }
 
+/* device memory a stream decoded ahead holds: its values, the staged payload, kernel workspaces, and for float / double
+ * streams the workspace of the self-check (the encoder's: ~1.3 x the values for floats, ~3 x for doubles) */
 static uint64_t readahead_cost(uint64_t decoded_bytes)
   {
-  return 3 * decoded_bytes + (64ull << 20);
+  return 5 * decoded_bytes + (64ull << 20);
   }
 
 /* drops the decode that was started ahead for the stream at the cursor (the caller skips it) */
