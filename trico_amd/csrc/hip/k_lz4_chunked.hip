@@ -378,7 +378,8 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
     }
   }
 
-struct Geom { uint32_t n, chunk, warm, K, dcap; size_t plane_stride; };
+struct Geom { uint32_t n, chunk, warm, K, dcap; size_t plane_stride; uint32_t alt_rounds, alt_dcap; };
+constexpr uint32_t ALT_R = 4;             // alternative parses kept per chunk (k_lz4_alt)
 
 __global__ void __launch_bounds__(64) k_lz4_parse(const uint8_t* __restrict__ planes, Geom g, Desc* __restrict__ descs, Meta* __restrict__ metas,
                                                   uint32_t* __restrict__ snapTs, uint32_t* __restrict__ endTs)
@@ -439,39 +440,84 @@ __global__ void __launch_bounds__(64) k_lz4_probe(const uint8_t* __restrict__ pl
             PROBE_DCAP, meta, nullptr, nullptr, lane);
   }
 
-// The stitch pass below is one serial walk per plane; what it does for a chunk whose predecessor needed no re-parse is a
-// comparison of two tables the parse pass has already written, so that comparison is done here for all chunks at once:
-// pre[chunk] = 1 if the chunk's snapshot sits at the ip where the speculative parse of the chunk before it ended and the two
-// tables agree there (entry by entry, or both entries beyond the 64 KiB window: lz4.c:945-948).
-__global__ void __launch_bounds__(64) k_lz4_precompare(Geom g, const Meta* __restrict__ metas, const uint32_t* __restrict__ snapTs,
-                                                       const uint32_t* __restrict__ endTs, uint32_t* __restrict__ pre)
+// The stitch pass below is one serial walk per plane.  Two things it would do chunk by chunk are done here for all chunks at
+// once, in ALT_R rounds of one launch each:
+//   * round 1 compares every chunk's snapshot with the SPECULATIVE end state of the chunk before it (entry by entry, or both
+//     entries beyond the 64 KiB window: lz4.c:945-948) and sets bit 0 of agree[chunk] when they match: the walk accepts such a
+//     chunk without touching the tables if the chunk before it was accepted as parsed;
+//   * a chunk that does not match is parsed again right here, from that end state, into alternative slot 1 of the chunk (a
+//     small descriptor buffer: planes that need re-parses are planes of long matches).  If the chunk before it was accepted
+//     as parsed, that state is the true state and the walk adopts the alternative instead of re-parsing.
+//   Round r > 1 does the same against the end state that round r - 1 produced for the chunk before (alternative slot r - 1):
+//   agree bit r - 1, alternative slot r.  The grid's periodic index plane rejects chunks in pairs (the second one still does
+//   not fit the re-parse of the first): 143 serial re-parses of 0.29 ms became two parallel rounds.
+//   An alternative is only ever used when the walk arrives at the chunk with exactly the state it was parsed from, so junk
+//   rounds (parsed from a state that turns out not to be the true one) cost time, never correctness.
+__global__ void __launch_bounds__(64) k_lz4_alt(const uint8_t* __restrict__ planes, Geom g, uint32_t r, const Meta* __restrict__ metas,
+                                                const uint32_t* __restrict__ snapTs, const uint32_t* __restrict__ endTs,
+                                                Desc* __restrict__ altDescs, Meta* __restrict__ altMetas, uint32_t* __restrict__ altEndTs,
+                                                uint32_t* __restrict__ agree)
   {
+  __shared__ uint32_t tab[4096];
+  __shared__ uint8_t dup[4096];
   const int lane = threadIdx.x;
   const uint32_t j = blockIdx.x, p = blockIdx.y;
-  const size_t cj = (size_t)p * g.K + j;
-  bool ok = false;
-  if (j > 0)
+  if (j == 0)
+    return;
+  const size_t ci = (size_t)p * g.K + j - 1, cj = ci + 1;
+  Meta a;
+  const uint32_t* T;
+  if (r == 1)
     {
-    const Meta a = metas[cj - 1], b = metas[cj];
-    const uint32_t ip = a.end_ip;
-    uint32_t jj = ip / g.chunk;
-    if (jj >= g.K) jj = g.K - 1u;
-    ok = a.end_kind == END_MATCH && jj == j && b.snap_valid != 0u && b.snap_ip == ip && b.end_kind != END_NONE;
-    if (ok)
-      {
-      const uint32_t* curT = endTs + (cj - 1) * 4096;
-      const uint32_t* snT = snapTs + cj * 4096;
-      bool same = true;
-      for (int i = lane; i < 4096; i += 64)
-        {
-        const uint32_t x = curT[i], y = snT[i];
-        same = same && (x == y || (x + MAXD < ip && y + MAXD < ip));
-        }
-      ok = __ballot(!same) == 0ull;
-      }
+    a = metas[ci];
+    T = endTs + ci * 4096;
     }
-  if (lane == 0)
-    pre[cj] = ok ? 1u : 0u;
+  else
+    {
+    a = altMetas[ci * ALT_R + (r - 2)];
+    if (!a.snap_valid)
+      return;
+    T = altEndTs + (ci * ALT_R + (r - 2)) * 4096;
+    }
+  if (a.end_kind != END_MATCH)
+    return;
+  const uint32_t ip = a.end_ip;
+  uint32_t jj = ip / g.chunk;
+  if (jj >= g.K) jj = g.K - 1u;
+  if (jj != j)
+    return;                                          // the walk goes elsewhere from there: left to it
+  const Meta b = metas[cj];
+  bool ok = b.snap_valid != 0u && b.snap_ip == ip && b.end_kind != END_NONE;
+  if (ok)
+    {
+    const uint32_t* snT = snapTs + cj * 4096;
+    bool same = true;
+    for (int i = lane; i < 4096; i += 64)
+      {
+      const uint32_t x = T[i], y = snT[i];
+      same = same && (x == y || (x + MAXD < ip && y + MAXD < ip));
+      }
+    ok = __ballot(!same) == 0ull;
+    }
+  if (ok)
+    {
+    if (lane == 0) atomicOr(&agree[cj], 1u << (r - 1));
+    return;
+    }
+  if (r > g.alt_rounds)
+    return;
+  // alternative parse of chunk j from that state, into slot r
+  for (int i = lane; i < 4096; i += 64)
+    tab[i] = T[i];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const size_t slot = cj * ALT_R + (r - 1);
+  Meta* am = altMetas + slot;
+  const uint32_t c_hi = (j + 1u == g.K) ? 0xffffffffu : (j + 1u) * g.chunk;
+  lz4_parse<1>(planes + (size_t)p * g.plane_stride, g.n, tab, dup, ip, true, false, true, j * g.chunk, c_hi, altDescs + slot * g.alt_dcap,
+            g.alt_dcap, am, nullptr, altEndTs + slot * 4096, lane);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (lane == 0 && am->end_kind != END_NONE)
+    am->snap_valid = 1u;                             // the slot holds a finished parse (END_NONE: descriptor buffer too small)
   }
 
 // One workgroup per plane walks the chain: accept speculative chunks whose snapshot is equivalent to the true state, re-parse the
@@ -484,7 +530,8 @@ constexpr int STITCH_W = 1;
 
 __global__ void __launch_bounds__(64 * STITCH_W) k_lz4_stitch(const uint8_t* __restrict__ planes, Geom g, Desc* __restrict__ descs,
                                                               Meta* __restrict__ metas, uint32_t* __restrict__ snapTs,
-                                                              uint32_t* __restrict__ endTs, const uint32_t* __restrict__ pre,
+                                                              uint32_t* __restrict__ endTs, const uint32_t* __restrict__ agree,
+                                                              const Meta* __restrict__ altMetas, const uint32_t* __restrict__ altEndTs,
                                                               uint32_t* __restrict__ status)
   {
   __shared__ uint32_t tabs[STITCH_W][4096];
@@ -497,7 +544,10 @@ __global__ void __launch_bounds__(64 * STITCH_W) k_lz4_stitch(const uint8_t* __r
   const uint8_t* src = planes + (size_t)p * g.plane_stride;
   Meta* pm = metas + (size_t)p * g.K;
   uint32_t cur = 0;                               // last accepted chunk
-  bool cur_spec = true;                           // its end state is the one the parse pass wrote (not a re-parse)
+  // where its true parse is: 0 = the parse pass's own (accepted as parsed), r = alternative slot r (k_lz4_alt), VER_SERIAL =
+  // re-parsed here into the chunk's own buffers
+  constexpr uint32_t VER_SERIAL = 99u;
+  uint32_t ver = 0;
   if (threadIdx.x == 0) pm[0].accepted = 1u;
   for (uint32_t guard = 0; guard < g.K + 2u; ++guard)
     {
@@ -518,11 +568,19 @@ __global__ void __launch_bounds__(64 * STITCH_W) k_lz4_stitch(const uint8_t* __r
       if (threadIdx.x == 0) atomicOr(status, 32u);      // no forward progress: must not happen
       return;
       }
-    const uint32_t* curT = endTs + ((size_t)p * g.K + cur) * 4096;
-    const uint32_t* snT = snapTs + ((size_t)p * g.K + j) * 4096;
+    const size_t ccur = (size_t)p * g.K + cur, cj = (size_t)p * g.K + j;
+    const uint32_t* curT = (ver >= 1u && ver <= ALT_R) ? altEndTs + (ccur * ALT_R + (ver - 1u)) * 4096 : endTs + ccur * 4096;
+    const uint32_t* snT = snapTs + cj * 4096;
     bool ok = uni(pm[j].snap_valid) != 0u && uni(pm[j].snap_ip) == ip && uni(pm[j].end_kind) != END_NONE;
-    if (ok && j == cur + 1u && cur_spec)
-      ok = uni(pre[(size_t)p * g.K + j]) != 0u;    // compared by k_lz4_precompare against exactly this state
+    const bool prepared = j == cur + 1u && ver != VER_SERIAL;          // k_lz4_alt has looked at this pair of states
+    uint32_t adopt = 0;                                                  // alternative slot to adopt (1 .. ALT_R)
+    if (prepared && ok && ((uni(agree[cj]) >> ver) & 1u))
+      ;                                                                  // compared by k_lz4_alt against exactly this state
+    else if (prepared && ver < ALT_R && uni(altMetas[cj * ALT_R + ver].snap_valid) != 0u)
+      {
+      adopt = ver + 1u;                                                  // parsed by k_lz4_alt from exactly this state
+      ok = false;
+      }
     else if (ok)
       {
       bool same = true;
@@ -534,14 +592,25 @@ __global__ void __launch_bounds__(64 * STITCH_W) k_lz4_stitch(const uint8_t* __r
       ok = __ballot(!same) == 0ull;
       }
     __syncthreads();                               // every wave has read chunk j's words
-    if (!ok)
+    if (adopt)
+      {
+      if (threadIdx.x == 0)
+        {
+        const Meta am = altMetas[cj * ALT_R + (adopt - 1u)];
+        pm[j].end_kind = am.end_kind;
+        pm[j].end_ip = am.end_ip;
+        pm[j].ndesc = am.ndesc;
+        pm[j].first_in = am.first_in;
+        pm[j].reparsed = 1u + adopt;               // k_lz4_sizes / k_lz4_emit take the descriptors of that slot
+        }
+      }
+    else if (!ok)
       {
       // exact re-parse of chunk j from the true state
       for (int i = lane; i < 4096; i += 64)
         tab[i] = curT[i];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       const uint32_t c_hi = (j + 1u == g.K) ? 0xffffffffu : (j + 1u) * g.chunk;
-      const size_t cj = (size_t)p * g.K + j;
       lz4_parse<STITCH_W>(src, g.n, tab, dups[wave], ip, true, false, true, j * g.chunk, c_hi, descs + cj * g.dcap, g.dcap, pm + j,
                           snapTs + cj * 4096, endTs + cj * 4096, lane, wave, xch);
       if (threadIdx.x == 0) pm[j].reparsed = 1u;
@@ -553,7 +622,7 @@ __global__ void __launch_bounds__(64 * STITCH_W) k_lz4_stitch(const uint8_t* __r
       if (!ok) atomicAdd(status + 2, 1u);
       }
     cur = j;
-    cur_spec = ok;
+    ver = adopt ? adopt : (ok ? 0u : VER_SERIAL);
     }
   if (threadIdx.x == 0) atomicOr(status, 64u);
   }
@@ -568,8 +637,14 @@ __device__ __forceinline__ uint32_t enc_size(const Desc& d)
   }
 
 // encoded bytes of every accepted chunk
-__global__ void __launch_bounds__(256) k_lz4_sizes(Geom g, const Desc* __restrict__ descs, const Meta* __restrict__ metas,
-                                                   uint32_t* __restrict__ chunk_bytes)
+// descriptors of an accepted chunk: its own buffer, or the alternative slot the stitch pass adopted (Meta::reparsed >= 2)
+__device__ __forceinline__ const Desc* chunk_descs(const Geom& g, const Desc* descs, const Desc* altDescs, const Meta& m, size_t ck)
+  {
+  return m.reparsed >= 2u ? altDescs + (ck * ALT_R + (m.reparsed - 2u)) * g.alt_dcap : descs + ck * g.dcap;
+  }
+
+__global__ void __launch_bounds__(256) k_lz4_sizes(Geom g, const Desc* __restrict__ descs, const Desc* __restrict__ altDescs,
+                                                   const Meta* __restrict__ metas, uint32_t* __restrict__ chunk_bytes)
   {
   __shared__ uint32_t red[256];
   const uint32_t k = blockIdx.x, p = blockIdx.y;
@@ -577,7 +652,7 @@ __global__ void __launch_bounds__(256) k_lz4_sizes(Geom g, const Desc* __restric
   uint32_t sum = 0;
   if (metas[ck].accepted)
     {
-    const Desc* d = descs + ck * g.dcap;
+    const Desc* d = chunk_descs(g, descs, altDescs, metas[ck], ck);
     const uint32_t nd = metas[ck].ndesc;
     for (uint32_t i = threadIdx.x; i < nd; i += 256u)
       sum += enc_size(d[i]);
@@ -646,8 +721,9 @@ struct BigJob { uint32_t plane, src, dst, len; };
 struct BigList { uint32_t count, pad[3]; BigJob job[BIG_CAP]; };
 
 __global__ void __launch_bounds__(EMIT_T) k_lz4_emit(const uint8_t* __restrict__ planes, Geom g, const Desc* __restrict__ descs,
-                                                     const Meta* __restrict__ metas, const uint32_t* __restrict__ chunk_off,
-                                                     uint8_t* __restrict__ out_base, size_t out_stride, BigList* __restrict__ big)
+                                                     const Desc* __restrict__ altDescs, const Meta* __restrict__ metas,
+                                                     const uint32_t* __restrict__ chunk_off, uint8_t* __restrict__ out_base, size_t out_stride,
+                                                     BigList* __restrict__ big)
   {
   __shared__ uint32_t sc_out[EMIT_T], sc_in[EMIT_T];
   __shared__ uint32_t wsum_out[EMIT_T / 64], wsum_in[EMIT_T / 64];
@@ -661,7 +737,7 @@ __global__ void __launch_bounds__(EMIT_T) k_lz4_emit(const uint8_t* __restrict__
   const int tid = threadIdx.x;
   const uint8_t* src = planes + (size_t)p * g.plane_stride;
   uint8_t* out = out_base + (size_t)p * out_stride;
-  const Desc* dl = descs + ck * g.dcap;
+  const Desc* dl = chunk_descs(g, descs, altDescs, metas[ck], ck);
   const uint32_t nd = metas[ck].ndesc;
   uint32_t carry_out = chunk_off[ck], carry_in = metas[ck].first_in;
   for (uint32_t base = 0; base < nd; base += EMIT_T)
@@ -821,7 +897,7 @@ __global__ void __launch_bounds__(EMIT_T) k_lz4_bigcopy(const uint8_t* __restric
     }
   }
 
-struct Plan { Geom g; size_t off_desc, off_meta, off_snap, off_end, off_cbytes, off_coff, total; };
+struct Plan { Geom g; size_t off_desc, off_meta, off_snap, off_end, off_cbytes, off_coff, off_altdesc, off_altmeta, off_altend, total; };
 
 // mode 0: long matches (1 MiB chunks, 384 KiB warm-up), mode 1: short sequences (384 KiB / 96 KiB); TRICO_LZ4_CHUNK / TRICO_LZ4_WARM
 // fix one geometry for both (tuning knobs)
@@ -859,6 +935,12 @@ Plan make_plan(uint32_t n, int nplanes, size_t plane_stride, int mode)
   p.off_end = o;    o += cells * 4096 * 4;
   p.off_cbytes = o; o += align_up(cells * 4, 256);
   p.off_coff = o;   o += align_up(cells * 4, 256);
+  // alternative parses (k_lz4_alt): only for the long-match geometry; 4096 descriptors per slot (such chunks have dozens)
+  p.g.alt_rounds = mode == 0 ? ALT_R : 0u;
+  p.g.alt_dcap = 4096;
+  p.off_altmeta = o; o += align_up(cells * ALT_R * sizeof(Meta), 256);
+  p.off_altdesc = o; o += p.g.alt_rounds ? align_up(cells * ALT_R * p.g.alt_dcap * sizeof(Desc), 256) : 0;
+  p.off_altend = o;  o += p.g.alt_rounds ? cells * ALT_R * 4096 * 4 : 0;
   p.total = o + 256;
   return p;
   }
@@ -933,8 +1015,20 @@ int launch_lz4_encode_chunked(const uint8_t* d_planes, size_t plane_stride, uint
   uint32_t* cbytes = (uint32_t*)(d_ws + p.off_cbytes);
   uint32_t* coff = (uint32_t*)(d_ws + p.off_coff);
   hipLaunchKernelGGL(k_lz4_parse, dim3(p.g.K, nplanes), dim3(64), 0, st, d_planes, p.g, descs, metas, snapTs, endTs);
-  hipLaunchKernelGGL(k_lz4_precompare, dim3(p.g.K, nplanes), dim3(64), 0, st, p.g, metas, snapTs, endTs, coff);     // coff is free until k_lz4_offsets
-  hipLaunchKernelGGL(k_lz4_stitch, dim3(nplanes), dim3(64 * STITCH_W), 0, st, d_planes, p.g, descs, metas, snapTs, endTs, coff, d_status);
+  Desc* altDescs = (Desc*)(d_ws + p.off_altdesc);
+  Meta* altMetas = (Meta*)(d_ws + p.off_altmeta);
+  uint32_t* altEndTs = (uint32_t*)(d_ws + p.off_altend);
+  uint32_t* agree = coff;                                            // free until k_lz4_offsets
+  {
+  const size_t cells = (size_t)p.g.K * nplanes;
+  if (!hip_ok(hipMemsetAsync(agree, 0, cells * 4, st), "memset(agree)") ||
+      !hip_ok(hipMemsetAsync(altMetas, 0, cells * ALT_R * sizeof(Meta), st), "memset(alt metas)"))
+    return 0;
+  }
+  for (uint32_t r = 1; r <= (p.g.alt_rounds ? p.g.alt_rounds + 1u : 1u) && r <= ALT_R; ++r)
+    hipLaunchKernelGGL(k_lz4_alt, dim3(p.g.K, nplanes), dim3(64), 0, st, d_planes, p.g, r, metas, snapTs, endTs, altDescs, altMetas, altEndTs, agree);
+  hipLaunchKernelGGL(k_lz4_stitch, dim3(nplanes), dim3(64 * STITCH_W), 0, st, d_planes, p.g, descs, metas, snapTs, endTs, agree, altMetas,
+                     altEndTs, d_status);
   if (getenv("TRICO_LZ4_DEBUG"))
     {
     const size_t cells = (size_t)p.g.K * nplanes;
@@ -955,13 +1049,13 @@ int launch_lz4_encode_chunked(const uint8_t* d_planes, size_t plane_stride, uint
       }
     free(h);
     }
-  hipLaunchKernelGGL(k_lz4_sizes, dim3(p.g.K, nplanes), dim3(256), 0, st, p.g, descs, metas, cbytes);
+  hipLaunchKernelGGL(k_lz4_sizes, dim3(p.g.K, nplanes), dim3(256), 0, st, p.g, descs, altDescs, metas, cbytes);
   hipLaunchKernelGGL(k_lz4_offsets, dim3(nplanes), dim3(1024), 0, st, p.g, cbytes, coff, d_sizes);
   // the list of big literal runs takes the place of the probe's records
   BigList* big = (BigList*)(d_ws + plans_bytes(n, nplanes, plane_stride));
   if (!hip_ok(hipMemsetAsync(big, 0, 16, st), "memset(big runs)"))
     return 0;
-  hipLaunchKernelGGL(k_lz4_emit, dim3(p.g.K, nplanes), dim3(EMIT_T), 0, st, d_planes, p.g, descs, metas, coff, d_out, out_stride, big);
+  hipLaunchKernelGGL(k_lz4_emit, dim3(p.g.K, nplanes), dim3(EMIT_T), 0, st, d_planes, p.g, descs, altDescs, metas, coff, d_out, out_stride, big);
   hipLaunchKernelGGL(k_lz4_bigcopy, dim3(2048), dim3(EMIT_T), 0, st, d_planes, plane_stride, d_out, out_stride, big);
   return hip_ok(hipGetLastError(), "lz4 chunked encode kernels") ? 1 : 0;
   }
