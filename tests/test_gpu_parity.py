@@ -446,3 +446,48 @@ def test_lz4_short_sequence_regimes(api, kind, n):
     assert r.read("attributes_uint8", back) == 1, api.last_error()
     r.close()
     assert back.tobytes() == data.tobytes()
+
+
+@pytest.mark.parametrize("kind", ["period30k", "period_drift", "two_regimes", "random_then_zero", "short_sequences", "ramp_u32_plane"])
+def test_lz4_chunked_compressor_regimes(api, kind):
+    """planes above the 4 MiB threshold of the chunk-speculative compressor (k_lz4_chunked.hip): long periodic matches whose
+    speculative chunks get rejected (parallel alternative parses, adoption by the stitch walk), literal runs above 1 MiB (the
+    big-run copy), short sequences (the small geometry chosen by the probe) - always the reference's bytes"""
+    n = 9 * (1 << 20) + 12345
+    rng = np.random.default_rng(4242 + len(kind))
+    if kind == "period30k":
+        base = rng.integers(0, 256, 30011, dtype=np.uint8)
+        data = np.tile(base, n // base.size + 1)[:n].copy()
+        hit = rng.integers(0, n, 40)
+        data[hit] ^= 0x55
+    elif kind == "period_drift":
+        parts, pos = [], 0
+        while pos < n:
+            per = int(rng.integers(2000, 50000))
+            reps = int(rng.integers(3, 40))
+            parts.append(np.tile(rng.integers(0, 256, per, dtype=np.uint8), reps))
+            pos += per * reps
+        data = np.concatenate(parts)[:n].copy()
+    elif kind == "two_regimes":
+        a = np.tile(np.arange(256, dtype=np.uint8), n // 512 + 1)[:n // 2]
+        steps = rng.integers(-1, 2, n - n // 2)
+        b = (np.cumsum(steps) & 15).astype(np.uint8)
+        data = np.concatenate([a, b])
+    elif kind == "random_then_zero":
+        data = np.concatenate([rng.integers(0, 256, 5 << 20, dtype=np.uint8), np.zeros(n - (5 << 20), np.uint8)])
+    elif kind == "short_sequences":
+        steps = rng.integers(-1, 2, n)
+        data = (np.cumsum(steps) & 31).astype(np.uint8)
+    else:
+        data = (np.arange(n, dtype=np.uint64) * 3 // 7).astype(np.uint8)
+    data = np.ascontiguousarray(data)
+    a = api.Archive.open_for_writing(1 << 16)
+    assert a.write("attributes_uint8", data, n) == 1, api.last_error()
+    got = a.tobytes()
+    a.close()
+    assert got == oracle_archive([("attributes_uint8", data, n)])
+    r = api.Archive.open_for_reading(got)
+    back = np.empty_like(data)
+    assert r.read("attributes_uint8", back) == 1, api.last_error()
+    r.close()
+    assert back.tobytes() == data.tobytes()
