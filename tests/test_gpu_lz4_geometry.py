@@ -1,0 +1,60 @@
+"""The chunk geometry of the speculative LZ4 compressor (k_lz4_chunked.hip) decides time, never bytes: the same mesh through small
+chunks with short warm-ups (many rejected chunks: alternative parses, adoptions, serial re-parses behind runs longer than the
+alternative rounds) must give the reference's archive.  The geometry is read once per process, hence the child processes."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import ctypes, hashlib, sys
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r + "/tests")
+from trico_amd import api
+from streams import mesh_streams
+L = api.lib()
+streams = mesh_streams("grid", 2000, 1000)
+a = api.Archive.open_for_writing(1 << 20)
+for name, data, count in streams:
+    assert a.write(name, data, count) == 1, api.last_error()
+st = (ctypes.c_uint32 * 4)()
+L.trico_hip_last_stats(st)
+blob = a.tobytes()
+a.close()
+print("RESULT", hashlib.sha256(blob).hexdigest(), len(blob), st[0], st[1])
+"""
+
+
+def run_child(chunk, warm):
+    env = dict(os.environ)
+    env.pop("TRICO_LZ4_CHUNK", None)
+    env.pop("TRICO_LZ4_WARM", None)
+    if chunk:
+        env["TRICO_LZ4_CHUNK"] = str(chunk)
+        env["TRICO_LZ4_WARM"] = str(warm)
+    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    return line[1], int(line[2]), int(line[3]), int(line[4])
+
+
+@pytest.mark.gpu
+def test_geometry_changes_time_not_bytes():
+    from oracle import oracle as O
+    from streams import mesh_streams
+    a = O.OracleArchive()
+    for name, data, count in mesh_streams("grid", 2000, 1000):
+        a.write(name, data, count)
+    want = a.tobytes()
+    a.close()
+    want_sha = hashlib.sha256(want).hexdigest()
+    rejected = 0
+    for chunk, warm in ((0, 0), (131072, 131072), (262144, 70000), (196608, 98304)):
+        sha, size, accepted, reparsed = run_child(chunk, warm)
+        assert (sha, size) == (want_sha, len(want)), (chunk, warm)
+        rejected += reparsed
+    assert rejected > 0          # the small geometries do reject chunks on this mesh (else the test exercises nothing)
