@@ -457,13 +457,8 @@ int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int
 
 static bool decode_check_enabled()
   {
-  static int v = -1;
-  if (v < 0)
-    {
-    const char* e = getenv("TRICO_HIP_DECODE_CHECK");
-    v = (e && e[0] == '0') ? 0 : 1;
-    }
-  return v != 0;
+  static const bool on = [] { const char* e = getenv("TRICO_HIP_DECODE_CHECK"); return !(e && e[0] == '0'); }();
+  return on;
   }
 
 // status bits 0x100 << c: component c of the re-encode differs from the payload
