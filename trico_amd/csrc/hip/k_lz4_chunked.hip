@@ -905,19 +905,22 @@ static bool geometry_forced() { return getenv("TRICO_LZ4_CHUNK") || getenv("TRIC
 
 Plan make_plan(uint32_t n, int nplanes, size_t plane_stride, int mode)
   {
-  static uint32_t env_chunk = 0, env_warm = 0;
-  static bool forced = false;
-  if (!env_chunk)
+  struct Env { uint32_t chunk, warm; bool forced; };
+  static const Env env = []
     {
-    forced = geometry_forced();
+    Env v;
+    v.forced = geometry_forced();
     const char* e = getenv("TRICO_LZ4_CHUNK");
-    env_chunk = e ? (uint32_t)atoi(e) : (1u << 20);
-    if (env_chunk < (1u << 17)) env_chunk = 1u << 17;
+    v.chunk = e ? (uint32_t)atoi(e) : (1u << 20);
+    if (v.chunk < (1u << 17)) v.chunk = 1u << 17;
     const char* w = getenv("TRICO_LZ4_WARM");
-    env_warm = w ? (uint32_t)atoi(w) : (384u << 10);
-    if (env_warm < 70000u) env_warm = 70000u;
-    if (env_warm > env_chunk) env_warm = env_chunk;
-    }
+    v.warm = w ? (uint32_t)atoi(w) : (384u << 10);
+    if (v.warm < 70000u) v.warm = 70000u;
+    if (v.warm > v.chunk) v.warm = v.chunk;
+    return v;
+    }();
+  const uint32_t env_chunk = env.chunk, env_warm = env.warm;
+  const bool forced = env.forced;
   const uint32_t chunk = forced || mode == 0 ? env_chunk : (384u << 10);
   const uint32_t warm = forced || mode == 0 ? env_warm : (96u << 10);
   Plan p;
