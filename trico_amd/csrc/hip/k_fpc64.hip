@@ -276,14 +276,18 @@ __device__ __forceinline__ void table_store(const u64* base, uint32_t byte_offse
   asm volatile("s_store_dwordx2 %0, %1, %2" :: "s"(v), "s"(base), "s"(byte_offset) : "memory");
   }
 
-// Two waves: wave 1 parses the group headers and the residuals of the next batches and stores the values of the finished ones;
-// wave 0 runs the chain.  They are coupled through two LDS counters and two rings in the stream's scratch (residuals in,
-// values out) that both waves access through the scalar cache (k_fpc32_decode.hip has the float version of the same design).
+// Two waves: wave 1 parses the group headers and the residuals of the next batches; wave 0 runs the chain and stores the values.
+// They are coupled through a ring of RING64 batches and two counters in the stream's scratch, all of it scalar memory
+// (k_fpc32_decode.hip has the float version of the same design and what was measured about scalar loads and stores).
 constexpr uint32_t RING64 = 4;                                   // batches the parser may run ahead
-constexpr uint32_t SCR64_DWORDS = 2048;                          // scratch per component: RING64 x 512 B of residuals, then of values
+constexpr uint32_t SLOT64_DWORDS = 256;                          // ring slot: 64 residuals (512 B), then the mask of DFCM-coded values
+constexpr uint32_t SCR64_DWORDS = 2048;                          // scratch per component (FPC64_DECODE_SCRATCH_BYTES)
+constexpr uint32_t SCR64_PRODUCED = RING64 * SLOT64_DWORDS, SCR64_CONSUMED = SCR64_PRODUCED + 16, SCR64_USED = SCR64_CONSUMED + 16;
+static_assert(SCR64_PRODUCED * 4 == 0x1000 && SCR64_CONSUMED * 4 == 0x1040 && SCR64_USED <= SCR64_DWORDS, "offsets are spelled out in the chain");
+constexpr uint32_t ABORT64 = 0xffffffffu;                        // `produced` when the parser gives up
 
-// lane l's 64-bit word -> dwords 2l, 2l + 1 of `slot` (512 bytes), with scalar stores
-__device__ __forceinline__ void put_words64(u64 w, const uint32_t* slot)
+// lane l's 64-bit word -> dwords 2l, 2l + 1 of `slot` (512 bytes) and the mask behind them, with scalar stores; complete on return
+__device__ __forceinline__ void put_batch64(u64 w, uint64_t dfcm, const uint32_t* slot)
   {
   const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
 #define P64_PUT2(J, R0, R1, R2, R3) \
@@ -292,69 +296,164 @@ __device__ __forceinline__ void put_words64(u64 w, const uint32_t* slot)
   "s_nop 0\n s_store_dwordx4 s[" #R0 ":" #R3 "], %[slot], 16 * (" #J ")\n"
 #define P64_4(J) P64_PUT2(J, 52, 53, 54, 55) P64_PUT2(J + 1, 56, 57, 58, 59) P64_PUT2(J + 2, 60, 61, 62, 63) P64_PUT2(J + 3, 64, 65, 66, 67)
   asm volatile(P64_4(0) P64_4(4) P64_4(8) P64_4(12) P64_4(16) P64_4(20) P64_4(24) P64_4(28)
+               "s_store_dwordx2 %[dfcm], %[slot], 0x200\n"
                "s_waitcnt lgkmcnt(0)\n"
-               :: [lo] "v"(lo), [hi] "v"(hi), [slot] "s"(slot)
+               :: [lo] "v"(lo), [hi] "v"(hi), [dfcm] "s"(dfcm), [slot] "s"(slot)
                : "memory", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67");
   }
 
-// dwords 2l, 2l + 1 of `slot` -> lane l, with scalar loads (the values were stored through the scalar cache)
-__device__ __forceinline__ u64 get_words64(const uint32_t* slot)
+__device__ __forceinline__ uint32_t counter_load64(const uint32_t* base, uint32_t dword)
   {
-  uint32_t lo = 0, hi = 0;
-#define G64_8(Q) \
-  "s_load_dwordx16 s[52:67], %[slot], 64 * (" #Q ")\n s_waitcnt lgkmcnt(0)\n" \
-  "v_writelane_b32 %[lo], s52, 8 * (" #Q ") + 0\n v_writelane_b32 %[hi], s53, 8 * (" #Q ") + 0\n" \
-  "v_writelane_b32 %[lo], s54, 8 * (" #Q ") + 1\n v_writelane_b32 %[hi], s55, 8 * (" #Q ") + 1\n" \
-  "v_writelane_b32 %[lo], s56, 8 * (" #Q ") + 2\n v_writelane_b32 %[hi], s57, 8 * (" #Q ") + 2\n" \
-  "v_writelane_b32 %[lo], s58, 8 * (" #Q ") + 3\n v_writelane_b32 %[hi], s59, 8 * (" #Q ") + 3\n" \
-  "v_writelane_b32 %[lo], s60, 8 * (" #Q ") + 4\n v_writelane_b32 %[hi], s61, 8 * (" #Q ") + 4\n" \
-  "v_writelane_b32 %[lo], s62, 8 * (" #Q ") + 5\n v_writelane_b32 %[hi], s63, 8 * (" #Q ") + 5\n" \
-  "v_writelane_b32 %[lo], s64, 8 * (" #Q ") + 6\n v_writelane_b32 %[hi], s65, 8 * (" #Q ") + 6\n" \
-  "v_writelane_b32 %[lo], s66, 8 * (" #Q ") + 7\n v_writelane_b32 %[hi], s67, 8 * (" #Q ") + 7\n"
-  asm volatile(G64_8(0) G64_8(1) G64_8(2) G64_8(3) G64_8(4) G64_8(5) G64_8(6) G64_8(7)
-               : [lo] "+v"(lo), [hi] "+v"(hi) : [slot] "s"(slot)
-               : "memory", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67");
-  return ((u64)hi << 32) | lo;
+  uint32_t r;
+  asm volatile("s_load_dword %0, %1, %2\n s_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(base), "s"(4u * dword) : "memory");
+  return r;
+  }
+__device__ __forceinline__ void counter_store64(const uint32_t* base, uint32_t dword, uint32_t v)
+  {
+  asm volatile("s_store_dword %0, %1, %2\n s_waitcnt lgkmcnt(0)" :: "s"(v), "s"(base), "s"(4u * dword) : "memory");
   }
 
-struct Oct64 { u64 v[8]; };
-#define OCT_REGS "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83"
-// eight 64-bit words at byte offset `off` of `slot`, through the scalar cache
-__device__ __forceinline__ void load_oct(const uint32_t* slot, uint32_t off, Oct64& o)
+// ---- the chain (wave 0) ------------------------------------------------------------------------------------------------
+// Per value ONE table entry is needed: the DFCM entry if the value is DFCM-coded, else the FCM entry (fpsc.c:977-978); both
+// tables are written for every value (fpsc.c:980-995).  With the API's exponents (20, 20) the FCM hash is the top 20 bits of the
+// previous value and the DFCM hash ((h2 << 10) ^ top 20 bits of the stride) & 0xfffff; both are kept as byte offsets (<< 3).
+// One value, all on the scalar unit, no branch (O = registers of the previous value, N = of this one; they alternate):
+//     lm = dfcm ? last : 0                                       s_bitcmp1_b64, s_cselect_b64
+//     e = forwarded ? value / stride just stored : loaded entry  s_cmp_lg, s_waitcnt, s_cselect_b64
+//     v = x ^ (e + lm); s = v - last                             s_add, s_addc, s_xor_b64, s_sub, s_subb      (fpsc.c:977-981)
+//     T1[o1] = v; T2[o2] = s                                     2 s_store_dwordx2                           (fpsc.c:982-995)
+//     o1' = (v.hi >> 9) & 0x7ffff8; o2' = ((o2 << 10) ^ (s.hi >> 9)) & 0x7ffff8                 2 + 4 instructions
+//     the entry the NEXT value needs (its kind is in the mask): table, offset, what was stored there if the hash did not
+//     change; load it                                            s_bitcmp1_b64, 2 s_cselect_b32, 2 s_cselect_b64, s_load_dwordx2
+//     forwarded' = (that offset == the offset just stored to)    s_cmp_eq, s_cselect      (a scalar load is not ordered behind a
+//                                                                scalar store to the same address that is still in flight)
+//     out lane K = v                                             2 v_writelane
+// 30 instructions (the compiled C++ chain of round 2a: ~35 and three branches of 26 cycles: 82-93 ns per value on smooth
+// streams; this one: see DESIGN.md).  On noisy doubles the DFCM entry is a miss into an 8 MiB table on top of that.
+// Fixed registers:  s[36:39] / s[40:43] {stride, value} of even / odd values   s[44:45] loaded entry   s[46:47] forwarded entry
+//   s[48:49] lm   s[50:51] prediction   s52 / s53 FCM offset (even / odd)   s54 / s55 DFCM offset   s56 forwarded   s57, s58 scratch
+//   s59 offset of the load   s[60:61] output address of the batch   s[62:63] table of the load   s[64:79] / s[80:95] residuals of
+//   the current / next eight values   s96 scratch   s97 batch counter   s[98:99] ring slot
+#define C64_X(K) "s[64 + 16 * (((" #K ") >> 3) & 1) + 2 * ((" #K ") & 7) : 65 + 16 * (((" #K ") >> 3) & 1) + 2 * ((" #K ") & 7)]"
+#define C64_XLOAD(K) "s_load_dwordx16 s[64 + 16 * (((((" #K ") >> 3) + 1)) & 1) : 79 + 16 * (((((" #K ") >> 3) + 1)) & 1)], s[98:99], 64 * (((" #K ") >> 3) + 1)\n"
+#define C64_NOX(K) ""
+#define C64_NEXT(K, NS, NV, O1O, O1N, O2O, O2N) \
+  "s_bitcmp1_b64 %[dm], (" #K ") + 1\n"                             \
+  "s_cselect_b32 s59, " O2N ", " O1N "\n"                           \
+  "s_cselect_b32 %[offo], " O2O ", " O1O "\n"                       \
+  "s_cselect_b64 s[62:63], %[T2], %[T1]\n"                          \
+  "s_cselect_b64 s[46:47], " NS ", " NV "\n"                        \
+  "s_load_dwordx2 s[44:45], s[62:63], s59\n"                        \
+  "s_cmp_eq_u32 s59, %[offo]\n"                                     \
+  "s_cselect_b32 s56, 1, 0\n"
+#define C64_LAST(K, NS, NV, O1O, O1N, O2O, O2N) ""
+#define C64_STEP(K, OV, OVLO, OVHI, NS, NSLO, NSHI, NV, NVLO, NVHI, O1O, O1N, O2O, O2N, XL, NEXT) \
+  "s_bitcmp1_b64 %[dm], (" #K ")\n"                                 \
+  "s_cselect_b64 s[48:49], " OV ", 0\n"                             \
+  "s_cmp_lg_u32 s56, 0\n"                                           \
+  "s_waitcnt lgkmcnt(0)\n"                                          \
+  "s_cselect_b64 s[50:51], s[46:47], s[44:45]\n"                    \
+  "s_add_u32 s50, s50, s48\n"                                       \
+  "s_addc_u32 s51, s51, s49\n"                                      \
+  "s_xor_b64 " NV ", " C64_X(K) ", s[50:51]\n"                      \
+  "s_sub_u32 " NSLO ", " NVLO ", " OVLO "\n"                        \
+  "s_subb_u32 " NSHI ", " NVHI ", " OVHI "\n"                       \
+  "s_store_dwordx2 " NV ", %[T1], " O1O "\n"                        \
+  "s_store_dwordx2 " NS ", %[T2], " O2O "\n"                        \
+  "s_lshr_b32 s57, " NVHI ", 9\n"                                   \
+  "s_and_b32 " O1N ", s57, 0x7ffff8\n"                              \
+  "s_lshl_b32 s58, " O2O ", 10\n"                                   \
+  "s_lshr_b32 s57, " NSHI ", 9\n"                                   \
+  "s_xor_b32 s58, s58, s57\n"                                       \
+  "s_and_b32 " O2N ", s58, 0x7ffff8\n"                              \
+  NEXT(K, NS, NV, O1O, O1N, O2O, O2N)                               \
+  XL(K)                                                             \
+  "v_writelane_b32 %[vlo], " NVLO ", " #K "\n"                      \
+  "v_writelane_b32 %[vhi], " NVHI ", " #K "\n"
+#define C64_EVEN(K, XL, NEXT) C64_STEP(K, "s[38:39]", "s38", "s39", "s[40:41]", "s40", "s41", "s[42:43]", "s42", "s43", "s52", "s53", "s54", "s55", XL, NEXT)
+#define C64_ODD(K, XL, NEXT) C64_STEP(K, "s[42:43]", "s42", "s43", "s[36:37]", "s36", "s37", "s[38:39]", "s38", "s39", "s53", "s52", "s55", "s54", XL, NEXT)
+#define C64_OCT(B, XL) C64_EVEN(B + 0, XL, C64_NEXT) C64_ODD(B + 1, C64_NOX, C64_NEXT) C64_EVEN(B + 2, C64_NOX, C64_NEXT) C64_ODD(B + 3, C64_NOX, C64_NEXT) \
+                       C64_EVEN(B + 4, C64_NOX, C64_NEXT) C64_ODD(B + 5, C64_NOX, C64_NEXT) C64_EVEN(B + 6, C64_NOX, C64_NEXT) C64_ODD(B + 7, C64_NOX, C64_NEXT)
+#define C64_OCT_LAST(B) C64_EVEN(B + 0, C64_NOX, C64_NEXT) C64_ODD(B + 1, C64_NOX, C64_NEXT) C64_EVEN(B + 2, C64_NOX, C64_NEXT) C64_ODD(B + 3, C64_NOX, C64_NEXT) \
+                        C64_EVEN(B + 4, C64_NOX, C64_NEXT) C64_ODD(B + 5, C64_NOX, C64_NEXT) C64_EVEN(B + 6, C64_NOX, C64_NEXT) C64_ODD(B + 7, C64_NOX, C64_LAST)
+
+// The whole chain of a stream: batches 0 .. nb-1 of 64 values (the last one may hold fewer: `last_mask` has a bit per value of
+// it; the slots beyond run too, nothing reads the tables or the state after them).  Per batch: wait until the parser has
+// published it, load its mask and first eight residuals, request the entry of its first value (nothing of the batch before is
+// still in flight then), 64 values, two vector stores of the 64 values straight to their place in the interleaved output,
+// publish `consumed`.
+__device__ __forceinline__ void chain64_run(const u64* T1, const u64* T2, const uint32_t* ring, uint32_t nb, uint64_t last_mask, u64* out0,
+                                            uint32_t voff, uint32_t out_step)
   {
-  asm volatile("s_load_dwordx16 s[68:83], %8, %9\n s_waitcnt lgkmcnt(0)\n"
-               "s_mov_b64 %0, s[68:69]\n s_mov_b64 %1, s[70:71]\n s_mov_b64 %2, s[72:73]\n s_mov_b64 %3, s[74:75]\n"
-               "s_mov_b64 %4, s[76:77]\n s_mov_b64 %5, s[78:79]\n s_mov_b64 %6, s[80:81]\n s_mov_b64 %7, s[82:83]"
-               : "=&s"(o.v[0]), "=&s"(o.v[1]), "=&s"(o.v[2]), "=&s"(o.v[3]), "=&s"(o.v[4]), "=&s"(o.v[5]), "=&s"(o.v[6]), "=&s"(o.v[7])
-               : "s"(slot), "s"(off) : "memory", OCT_REGS);
-  }
-__device__ __forceinline__ void store_oct(const uint32_t* slot, uint32_t off, const Oct64& o)
-  {
-  asm volatile("s_mov_b64 s[68:69], %0\n s_mov_b64 s[70:71], %1\n s_mov_b64 s[72:73], %2\n s_mov_b64 s[74:75], %3\n"
-               "s_mov_b64 s[76:77], %4\n s_mov_b64 s[78:79], %5\n s_mov_b64 s[80:81], %6\n s_mov_b64 s[82:83], %7\n"
-               "s_store_dwordx4 s[68:71], %8, %9\n s_store_dwordx4 s[72:75], %8, %10\n"
-               "s_store_dwordx4 s[76:79], %8, %11\n s_store_dwordx4 s[80:83], %8, %12\n"
-               "s_waitcnt lgkmcnt(0)"
-               :: "s"(o.v[0]), "s"(o.v[1]), "s"(o.v[2]), "s"(o.v[3]), "s"(o.v[4]), "s"(o.v[5]), "s"(o.v[6]), "s"(o.v[7]),
-                  "s"(slot), "s"(off), "s"(off + 16u), "s"(off + 32u), "s"(off + 48u) : "memory", OCT_REGS);
+  const uint64_t xb = (uint64_t)(uintptr_t)ring, ob = (uint64_t)(uintptr_t)out0;
+  const uint32_t xlo = (uint32_t)xb, xhi = (uint32_t)(xb >> 32), olo = (uint32_t)ob, ohi = (uint32_t)(ob >> 32);
+  uint32_t vlo, vhi, offo;
+  uint64_t dm;
+  asm volatile(
+    "s_mov_b64 s[36:37], 0\n s_mov_b64 s[38:39], 0\n s_mov_b64 s[40:41], 0\n s_mov_b64 s[42:43], 0\n"
+    "s_mov_b64 s[44:45], 0\n s_mov_b64 s[46:47], 0\n"
+    "s_mov_b32 s52, 0\n s_mov_b32 s53, 0\n s_mov_b32 s54, 0\n s_mov_b32 s55, 0\n s_mov_b32 s56, 0\n"
+    "s_mov_b32 s97, 0\n s_mov_b32 s60, %[olo]\n s_mov_b32 s61, %[ohi]\n"
+    "s_cmp_lt_u32 s97, %[nb]\n"
+    "s_cbranch_scc0 3f\n"
+    "0:\n"
+    "s_load_dword s96, %[ringp], 0x1000\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    "s_cmp_gt_u32 s96, s97\n"
+    "s_cbranch_scc1 1f\n"
+    "s_sleep 1\n"
+    "s_branch 0b\n"
+    "1:\n"
+    "s_cmp_eq_u32 s96, -1\n"
+    "s_cbranch_scc1 3f\n"
+    "s_and_b32 s96, s97, 3\n"
+    "s_lshl_b32 s96, s96, 10\n"
+    "s_add_u32 s98, %[xlo], s96\n"
+    "s_addc_u32 s99, %[xhi], 0\n"
+    "s_load_dwordx2 %[dm], s[98:99], 0x200\n"
+    "s_load_dwordx16 s[64:79], s[98:99], 0x0\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    /* the entry of the batch's first value: the stores of the batch before are complete (the poll waited for them) */
+    "s_bitcmp1_b64 %[dm], 0\n"
+    "s_cselect_b32 s59, s54, s52\n"
+    "s_cselect_b64 s[62:63], %[T2], %[T1]\n"
+    "s_load_dwordx2 s[44:45], s[62:63], s59\n"
+    "s_mov_b32 s56, 0\n"
+    C64_OCT(0, C64_XLOAD) C64_OCT(8, C64_XLOAD) C64_OCT(16, C64_XLOAD) C64_OCT(24, C64_XLOAD)
+    C64_OCT(32, C64_XLOAD) C64_OCT(40, C64_XLOAD) C64_OCT(48, C64_XLOAD) C64_OCT_LAST(56)
+    "s_add_u32 s97, s97, 1\n"
+    "s_cmp_eq_u32 s97, %[nb]\n"
+    "s_cselect_b64 exec, %[lastm], -1\n"
+    "global_store_dword %[voff], %[vlo], s[60:61]\n"
+    "global_store_dword %[voff], %[vhi], s[60:61] offset:4\n"
+    "s_mov_b64 exec, -1\n"
+    "s_add_u32 s60, s60, %[ostep]\n"
+    "s_addc_u32 s61, s61, 0\n"
+    "s_store_dword s97, %[ringp], 0x1040\n"
+    "s_cmp_lt_u32 s97, %[nb]\n"
+    "s_cbranch_scc1 0b\n"
+    "3:\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    : [vlo] "=&v"(vlo), [vhi] "=&v"(vhi), [offo] "=&s"(offo), [dm] "=&s"(dm)
+    : [T1] "s"(T1), [T2] "s"(T2), [ringp] "s"(ring), [xlo] "s"(xlo), [xhi] "s"(xhi), [olo] "s"(olo), [ohi] "s"(ohi), [voff] "v"(voff),
+      [ostep] "s"(out_step), [nb] "s"(nb), [lastm] "s"(last_mask)
+    : "scc", "memory", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
+      "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
+      "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",
+      "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
   }
 
 __global__ void __launch_bounds__(128) k_fpc64_decode(DecodeArgs args, int arity, uint32_t n, u64* __restrict__ dst, u64* __restrict__ tables,
                                                       uint32_t* __restrict__ scratch, uint32_t* __restrict__ status)
   {
   __shared__ uint32_t win[WINW + 8];
-  __shared__ uint32_t dmask[RING64][2];
-  __shared__ uint32_t sh_bad, produced, consumed;
+  __shared__ uint32_t sh_bad;
   const int lane = threadIdx.x & 63;
   const int wave = (int)rfl(threadIdx.x >> 6);
   const int comp = blockIdx.x;
   const uint8_t* in = args.pay[comp];
   if (threadIdx.x == 0)
-    {
     sh_bad = 0u;
-    produced = 0u;
-    consumed = 0u;
-    }
   const uint32_t len = args.size[comp];
   if (len < 5u)
     {
@@ -363,20 +462,26 @@ __global__ void __launch_bounds__(128) k_fpc64_decode(DecodeArgs args, int arity
     }
   const uint32_t e1 = (uint32_t)(in[0] >> 4) << 1, e2 = (uint32_t)(in[0] & 15) << 1;
   const uint32_t cnt = ((uint32_t)in[1] << 24) | ((uint32_t)in[2] << 16) | ((uint32_t)in[3] << 8) | in[4];
-  if (cnt != n || e1 == 0u || e2 == 0u || e1 > E || e2 > E)
+  if (cnt != n || e1 != E || e2 != E)                                    // other table shapes: k_serial.hip (shim.hip routes them)
     {
     if (threadIdx.x == 0) atomicOr(status, 2u);
     return;
     }
-  __syncthreads();
   const u64* T1 = tables + (size_t)comp * 2 * TSIZE;
   const u64* T2 = T1 + TSIZE;
-  const uint32_t* xring = scratch + SCR64_DWORDS * (uint32_t)comp;        // RING64 slots of 64 residuals
-  const uint32_t* oring = xring + 128u * RING64;                           // RING64 slots of 64 values
+  const uint32_t* ring = scratch + SCR64_DWORDS * (uint32_t)comp;         // RING64 slots, then the two counters
   const uint32_t nb = (n + 63u) / 64u;                                     // the last batch may be partial
+  if (wave == 0)
+    {
+    // ring and counters start at zero; scalar stores of whole lines, so that every line is in the scalar cache whatever it held
+    for (uint32_t off = 0; off < 4u * SCR64_USED; off += 16u)
+      asm volatile("s_mov_b64 s[40:41], 0\n s_mov_b64 s[42:43], 0\n s_store_dwordx4 s[40:43], %0, %1" :: "s"(ring), "s"(off) : "s40", "s41", "s42", "s43", "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  __syncthreads();
   if (wave == 1)
     {
-    // ---- parser: group headers and residuals of batch t, values of the finished batches to memory ----------------
+    // ---- parser: group headers and residuals of batch t ------------------------------------------------------------
     const uint32_t al = (uint32_t)((uintptr_t)in & 3u);
     const uint32_t* abase = (const uint32_t*)(in - al);
     const uint32_t total_q = len + al;
@@ -392,68 +497,58 @@ __global__ void __launch_bounds__(128) k_fpc64_decode(DecodeArgs args, int arity
       };
     refill(q);
     const uint8_t* wb = (const uint8_t*)win;
-    uint32_t t = 0, st = 0;
-    while (st < nb)
+    uint32_t t = 0;
+    bool failed = false;
+    while (t < nb)
       {
-      const uint32_t cdone = rfl(__hip_atomic_load(&consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-      bool progress = false;
-      for (; st < cdone; ++st)
+      if (t >= counter_load64(ring, SCR64_CONSUMED) + RING64)
         {
-        const u64 v = get_words64(oring + 128u * (st % RING64));
-        const uint32_t idx = 64u * st + (uint32_t)lane;
-        if (idx < n)
-          dst[(size_t)idx * arity + comp] = v;
-        progress = true;
-        }
-      if (t < nb && t < st + RING64)
-        {
-        progress = true;
-        if (q + BATCH_BYTES + 16u > 4u * (wd + (uint32_t)WINW))
-          refill(q);
-        const uint32_t i0 = 64u * t;
-        const uint32_t nvals = n - i0 < 64u ? n - i0 : 64u;
-        const uint32_t ngroups = (nvals + 1u) >> 1;
-        // positions of the groups: scalar walk over the header bytes
-        uint32_t lq = q - 4u * wd;
-        uint32_t myhdr = 0, myq = 0;
-        for (uint32_t g = 0; g < ngroups; ++g)
-          {
-          const uint32_t hdr = rfl((uint32_t)wb[lq]);
-          if (((uint32_t)lane >> 1) == g)
-            {
-            myhdr = hdr;
-            myq = lq;
-            }
-          lq += 1u + nib_len(hdr & 15u) + nib_len(hdr >> 4);
-          }
-        const uint32_t qend = 4u * wd + lq;
-        if (qend > total_q)
-          {
-          if (lane == 0)
-            __hip_atomic_store(&sh_bad, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-          break;
-          }
-        q = qend;
-        // all lanes fetch their residual
-        const uint32_t code = (lane & 1) ? (myhdr >> 4) : (myhdr & 15u);
-        const uint32_t nbytes = nib_len(code);
-        const uint32_t rp = myq + 1u + ((lane & 1) ? nib_len(myhdr & 15u) : 0u);
-        const uint32_t w0 = win[rp >> 2], w1 = win[(rp >> 2) + 1u], w2 = win[(rp >> 2) + 2u];
-        const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, rp & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, rp & 3u);
-        const u64 be = ((u64)__builtin_bswap32(lo) << 32) | __builtin_bswap32(hi);      // first stream byte on top
-        const u64 xr = nbytes ? be >> (8u * (8u - nbytes)) : 0ull;
-        const uint64_t dfcm = __ballot(code > 8u);
-        put_words64(xr, xring + 128u * (t % RING64));
-        if (lane == 0)
-          {
-          dmask[t % RING64][0] = (uint32_t)dfcm;
-          dmask[t % RING64][1] = (uint32_t)(dfcm >> 32);
-          __hip_atomic_store(&produced, t + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-        ++t;
-        }
-      if (!progress)
         __builtin_amdgcn_s_sleep(4);
+        continue;
+        }
+      if (q + BATCH_BYTES + 16u > 4u * (wd + (uint32_t)WINW))
+        refill(q);
+      const uint32_t i0 = 64u * t;
+      const uint32_t nvals = n - i0 < 64u ? n - i0 : 64u;
+      const uint32_t ngroups = (nvals + 1u) >> 1;
+      // positions of the groups: scalar walk over the header bytes
+      uint32_t lq = q - 4u * wd;
+      uint32_t myhdr = 0, myq = 0;
+      for (uint32_t g = 0; g < ngroups; ++g)
+        {
+        const uint32_t hdr = rfl((uint32_t)wb[lq]);
+        if (((uint32_t)lane >> 1) == g)
+          {
+          myhdr = hdr;
+          myq = lq;
+          }
+        lq += 1u + nib_len(hdr & 15u) + nib_len(hdr >> 4);
+        }
+      const uint32_t qend = 4u * wd + lq;
+      if (qend > total_q)
+        {
+        failed = true;
+        break;
+        }
+      q = qend;
+      // all lanes fetch their residual
+      const uint32_t code = (lane & 1) ? (myhdr >> 4) : (myhdr & 15u);
+      const uint32_t nbytes = nib_len(code);
+      const uint32_t rp = myq + 1u + ((lane & 1) ? nib_len(myhdr & 15u) : 0u);
+      const uint32_t w0 = win[rp >> 2], w1 = win[(rp >> 2) + 1u], w2 = win[(rp >> 2) + 2u];
+      const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, rp & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, rp & 3u);
+      const u64 be = ((u64)__builtin_bswap32(lo) << 32) | __builtin_bswap32(hi);      // first stream byte on top
+      const u64 xr = nbytes ? be >> (8u * (8u - nbytes)) : 0ull;
+      const uint64_t dfcm = __ballot(code > 8u);
+      put_batch64(xr, dfcm, ring + SLOT64_DWORDS * (t % RING64));
+      ++t;
+      counter_store64(ring, SCR64_PRODUCED, t);
+      }
+    if (failed)
+      {
+      counter_store64(ring, SCR64_PRODUCED, ABORT64);
+      if (lane == 0)
+        sh_bad = 1u;
       }
     }
   else
@@ -469,76 +564,9 @@ __global__ void __launch_bounds__(128) k_fpc64_decode(DecodeArgs args, int arity
                    :: "s"(T1), "s"(off), "s"(off + 16u), "s"(off + 32u), "s"(off + 48u) : "s40", "s41", "s42", "s43", "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_setprio(3);                        // the chain owns its SIMD's issue slots whenever it can issue
-    const u64 m1 = (1ull << e1) - 1ull, m2 = (1ull << e2) - 1ull;
-    const uint32_t sh1 = 64u - e1, sh2 = 64u - e2, e2h = e2 >> 1;
-    // fwd1 / fwd2: the hash did not change with the last value, so the entry of the current hash is the value / stride just
-    // stored and is taken from the register (p1 / t2v) instead of being loaded
-    uint32_t h1 = 0, h2 = 0;
-    u64 p1 = 0, last = 0, t2v = 0;
-    bool fwd1 = true, fwd2 = true;                        // zeroed tables: the entries of hash 0 are 0
-    for (uint32_t t = 0; t < nb; ++t)
-      {
-      bool stop = false;
-      while (rfl(__hip_atomic_load(&produced, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) <= t)
-        {
-        if (rfl(__hip_atomic_load(&sh_bad, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)))
-          {
-          stop = true;
-          break;
-          }
-        __builtin_amdgcn_s_sleep(1);
-        }
-      if (stop)
-        break;
-      const uint32_t b = t % RING64;
-      const uint64_t dfcm = ((uint64_t)rfl(dmask[b][1]) << 32) | rfl(dmask[b][0]);
-      const uint32_t nvals = n - 64u * t < 64u ? n - 64u * t : 64u;
-      // Per value ONE table entry is needed: the DFCM entry if the value is DFCM-coded, else the FCM entry
-      // (fpsc.c:977-978), and only if the hash changed with the previous value; both tables are written for every value
-      // (fpsc.c:980-995), fire and forget.  On noisy doubles that is one dependent miss into an 8 MiB table (Infinity
-      // Cache, ~230 ns) for the DFCM-coded values and a scalar-cache / L2 hit for the others.
-      for (uint32_t j = 0; 8u * j < nvals; ++j)
-        {
-        Oct64 xs, vs;
-        load_oct(xring + 128u * b, 64u * j, xs);
-#pragma unroll
-        for (uint32_t k8 = 0; k8 < 8u; ++k8)
-          {
-          const uint32_t k = 8u * j + k8;
-          u64 p;
-          if ((dfcm >> k) & 1ull)
-            {
-            if (!fwd2)
-              t2v = table_load(T2, h2 << 3);
-            p = last + t2v;                                         // prediction2 = value + table entry
-            }
-          else
-            {
-            if (!fwd1)
-              p1 = table_load(T1, h1 << 3);
-            p = p1;
-            }
-          const u64 v = xs.v[k8] ^ p;
-          const u64 s = v - last;
-          // (the padding slots of a partial last batch run too: nothing reads the tables or the state after them)
-          table_store(T1, h1 << 3, v);                              // hash_table_1[hash1] = value
-          table_store(T2, h2 << 3, s);                              // hash_table_2[hash2] = stride
-          const uint32_t nh1 = (uint32_t)((((u64)h1 << e1) ^ (v >> sh1)) & m1);
-          const uint32_t nh2 = (uint32_t)((((u64)h2 << e2h) ^ (s >> sh2)) & m2);
-          fwd1 = nh1 == h1;
-          fwd2 = nh2 == h2;
-          h1 = nh1;
-          h2 = nh2;
-          p1 = v;
-          t2v = s;
-          last = v;
-          vs.v[k8] = v;
-          }
-        store_oct(oring + 128u * b, 64u * j, vs);
-        }
-      if (lane == 0)
-        __hip_atomic_store(&consumed, t + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
+    const uint32_t nlast = n - 64u * (nb - 1u);           // values of the last batch, 1 .. 64
+    const uint64_t last_mask = nlast >= 64u ? ~0ull : (1ull << nlast) - 1ull;
+    chain64_run(T1, T2, ring, nb, last_mask, dst + comp, 8u * (uint32_t)lane * (uint32_t)arity, 512u * (uint32_t)arity);
     // no dirty line of the scalar cache may outlive the table buffer
     asm volatile("s_dcache_wb\n s_waitcnt lgkmcnt(0)" ::: "memory");
     }
