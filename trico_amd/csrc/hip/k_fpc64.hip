@@ -329,7 +329,7 @@ __device__ __forceinline__ void counter_store64(const uint32_t* base, uint32_t d
 //                                                                scalar store to the same address that is still in flight)
 //     out lane K = v                                             2 v_writelane
 // 30 instructions (the compiled C++ chain of round 2a: ~35 and three branches of 26 cycles: 82-93 ns per value on smooth
-// streams; this one: see DESIGN.md).  On noisy doubles the DFCM entry is a miss into an 8 MiB table on top of that.
+// streams, 166 on noisy ones; this one: 54 and 112).  On noisy doubles the DFCM entry is a miss into an 8 MiB table on top of that.
 // Fixed registers:  s[36:39] / s[40:43] {stride, value} of even / odd values   s[44:45] loaded entry   s[46:47] forwarded entry
 //   s[48:49] lm   s[50:51] prediction   s52 / s53 FCM offset (even / odd)   s54 / s55 DFCM offset   s56 forwarded   s57, s58 scratch
 //   s59 offset of the load   s[60:61] output address of the batch   s[62:63] table of the load   s[64:79] / s[80:95] residuals of
