@@ -198,6 +198,8 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
     {
     uint32_t cand = 0;
     bool have_match = false;
+    bool fast = false;                     // the search round has already seen where the match ends (see the search loop)
+    uint32_t fast_extra = 0;               // ... namely this many bytes behind its first four
     uint8_t tok_lit0 = 0;
     (void)tok_lit0;
     if (at_match_end)
@@ -259,6 +261,11 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
       const uint32_t start = ip;
       uint32_t t0 = 0;
       bool final = false;
+      // Short sequences (a mesh's second index plane: 7 bytes each) spent two more memory round trips per sequence on the
+      // catch-up and on counting a match of 4-7 bytes.  The round that tests the candidates fetches 8 bytes at the candidate
+      // instead of 4 and the 8 bytes before both positions, so the winner usually knows both answers already.
+      bool fast_pre = false;
+      uint32_t fast_eqb = 0;
       for (;;)
         {
         const uint32_t ta = t0 + (uint32_t)lane, tb = ta + 1u;
@@ -277,37 +284,72 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
           dup[h] = (uint8_t)lane;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const bool clash = active && dup[h] != (uint8_t)lane;
-        const uint32_t cnd = active ? tab[h] : 0u;
+        uint32_t cnd = active ? tab[h] : 0u;
+        uint64_t later_same = 0;                                                   // higher lanes of this round with my hash
         if (__ballot(clash))
           {
-          // two attempts of this batch share a hash: take ONE attempt exactly as the reference does, then batch again
-          const uint32_t h0 = uni(h), cur = uni(pos);
-          cand = uni(cnd);
-          ip = cur;
-          if (uni(nxt) > mfl1) { final = true; break; }
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          if (lane == 0) tab[h0] = cur;
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          if (cand + MAXD >= cur && uni(ld32(src + cand)) == (uint32_t)uni((uint32_t)w)) break;
-          t0 += 1u;
-          continue;
+          // Attempts of this round share a hash.  In the reference attempt l sees what the attempts before it wrote: its
+          // candidate is the position of the nearest lower lane with its hash (else the table's), and of the attempts that do
+          // write, the highest of a hash is what stays in the table.  The lanes of a hash find each other with one ballot per
+          // hash bit.  (Round 2a took ONE attempt the serial way here and batched again: on a plane of short sequences over
+          // a small alphabet that was most rounds.)
+          uint64_t same = __ballot(active);
+#pragma unroll
+          for (int b = 0; b < 12; ++b)
+            {
+            const bool bit = (h >> b) & 1u;
+            const uint64_t m = __ballot(bit);
+            same &= bit ? m : ~m;
+            }
+          if (!active)
+            same = 0;
+          const uint64_t lower = same & ((1ull << lane) - 1ull);
+          const uint32_t from = lower ? 63u - (uint32_t)__builtin_clzll(lower) : (uint32_t)lane;
+          const uint32_t ppos = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)pos);
+          if (lower)
+            cnd = ppos;
+          later_same = same & ~((2ull << lane) - 1ull);
           }
-        bool hit = false;
+        bool hit = false, pre = false;
+        uint64_t cw = 0, pw = 0, pcw = 0;
         if (active && !fin && cnd + MAXD >= pos)
-          hit = ld32(src + cnd) == (uint32_t)w;
+          {
+          cw = ld64(src + cnd);                                                    // cnd < pos <= n - 11: inside the block
+          hit = (uint32_t)cw == (uint32_t)w;
+          if (pos >= 8u && cnd >= 8u)
+            {
+            pw = ld64(src + pos - 8u);
+            pcw = ld64(src + cnd - 8u);
+            pre = true;
+            }
+          }
         const uint64_t stop = __ballot(fin || hit);
         const int first = stop ? __builtin_ctzll(stop) : 64;
         const bool first_fin = stop && ((__ballot(fin) >> first) & 1ull);
         // table writes: every attempt before the deciding one, and the deciding one too unless it is the final one
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (active && (lane < first || (lane == first && !first_fin)))
+        {
+        const int lastw = !stop ? 63 : (first_fin ? first - 1 : first);            // highest lane that writes
+        const uint64_t writers = lastw >= 63 ? ~0ull : (lastw < 0 ? 0ull : (2ull << lastw) - 1ull);
+        if (active && (lane < first || (lane == first && !first_fin)) && (later_same & writers) == 0ull)
           tab[h] = pos;
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (stop)
           {
           ip = (uint32_t)__builtin_amdgcn_readlane((int)pos, first);
           cand = (uint32_t)__builtin_amdgcn_readlane((int)cnd, first);
           final = first_fin;
+          if (!first_fin)
+            {
+            const uint64_t dx = (w ^ cw) >> 32, dp = pw ^ pcw;
+            const uint32_t extra = dx ? (uint32_t)__builtin_ctzll(dx) >> 3 : 4u;     // equal bytes behind the first four
+            const uint32_t eqb = dp ? (uint32_t)__builtin_clzll(dp) >> 3 : 8u;       // equal bytes right before the two positions
+            fast = true;
+            fast_extra = (uint32_t)__builtin_amdgcn_readlane((int)extra, first);
+            fast_eqb = (uint32_t)__builtin_amdgcn_readlane((int)eqb, first);
+            fast_pre = __builtin_amdgcn_readlane((int)pre, first) != 0;
+            }
           break;
           }
         t0 += 64u;
@@ -326,7 +368,14 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
       // catch up (lz4.c:960-961)
       const uint32_t maxback = ip - anchor < cand ? ip - anchor : cand;
       uint32_t back = 0;
-      while (back < maxback)
+      if (fast && maxback != 0u)
+        {
+        if (!fast_pre || (fast_eqb == 8u && maxback > 8u))
+          fast = false;                                                            // not decided by the 8 bytes at hand
+        else
+          back = fast_eqb < maxback ? fast_eqb : maxback;
+        }
+      while (!fast && back < maxback)
         {
         const uint32_t k = back + (uint32_t)lane + 1u;
         const bool eq = k <= maxback && src[ip - k] == src[cand - k];
@@ -341,6 +390,8 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
       if (back > maxback) back = maxback;
       ip -= back;
       cand -= back;
+      fast_extra += back;                                                          // equal bytes behind the first four of the moved match
+      fast = fast && fast_extra - back < 4u;                                       // a difference was seen
       }
     // ---- a match starts at ip against cand (lz4.c:1007-1077) ----
     if (!emit && ip + 4u >= c_hi)
@@ -353,7 +404,8 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
       const uint32_t cap = c_hi - (ip + 4u);
       if (cap < limit) limit = cap;
       }
-    const uint32_t m = wave_count<NW>(src + ip + 4u, src + cand + 4u, limit, lane, wave, xch);
+    // (have_match without a search - the test right behind a match - has no bytes at hand: fast is false there)
+    const uint32_t m = (fast && fast_extra < limit) ? fast_extra : wave_count<NW>(src + ip + 4u, src + cand + 4u, limit, lane, wave, xch);
     if (!emit && limit < room && m >= limit)
       break;                                                                       // ran past c_hi during warm-up
     if (emit)
