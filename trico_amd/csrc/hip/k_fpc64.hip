@@ -14,11 +14,12 @@
 //     payload.  4-bit codes, two values per header byte, residual bytes MSB first; bytes are staged in an
 //     LDS ring and flushed as aligned dwords straight to their final place (the wave writes sequentially).
 //     One global round trip per step bounds it: ~1 us per 64 values per stream.
-//   decoder: compressed bytes staged through LDS; batches of 64 values: a scalar walk over the 32 header
-//     bytes finds the group positions, all lanes fetch/align/byte-swap their residual, then the dependent
-//     chain runs wave-uniform on the scalar unit with the tables behind the scalar data cache.  A table read is
-//     skipped when the key did not change (then the entry is the value just written) — the common case on
-//     smooth data — and only the table the value's code asks for is read; otherwise it is a dependent miss.
+//   decoder: two waves.  The parser stages the compressed bytes through LDS and hands batches of 64 residuals (a scalar walk
+//     over the 32 header bytes finds the group positions, all lanes fetch / align / byte-swap their residual) to the chain
+//     through a ring in scalar memory; the chain is hand-written branch-free scalar code with the tables behind the scalar
+//     data cache: one table entry per value - only the table the value's code asks for, requested as soon as its hash is
+//     known, and replaced by the value / stride just stored when the hash did not change (the common case on smooth data);
+//     on noisy data the DFCM entry is a dependent miss into an 8 MiB table.
 // Latency-bound by construction; algorithmic bytes per value: 8 + its payload share.
 #include "common.hpp"
 
@@ -259,22 +260,6 @@ struct DecodeArgs
 
 __device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ uint32_t nib_len(uint32_t c) { return c <= 8u ? c : c - 8u; }
-
-// Table accesses of the chain go through the SCALAR data cache (s_load / s_store; see k_fpc32_decode.hip for what was
-// measured about them on gfx950): a scalar load costs ~6 cycles of issue against the ~16 of a vector load plus the
-// VGPR -> SGPR hop, it leaves the result where the wave-uniform chain wants it, and a store is fire-and-forget.  Every
-// access is preceded by s_waitcnt lgkmcnt(0), so a load is never in flight together with a store (a scalar load is not
-// reliably ordered behind an earlier scalar store to the same address while that store is still in flight).
-__device__ __forceinline__ u64 table_load(const u64* base, uint32_t byte_offset)
-  {
-  u64 r;
-  asm volatile("s_waitcnt lgkmcnt(0)\n s_load_dwordx2 %0, %1, %2\n s_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(base), "s"(byte_offset) : "memory");
-  return r;
-  }
-__device__ __forceinline__ void table_store(const u64* base, uint32_t byte_offset, u64 v)
-  {
-  asm volatile("s_store_dwordx2 %0, %1, %2" :: "s"(v), "s"(base), "s"(byte_offset) : "memory");
-  }
 
 // Two waves: wave 1 parses the group headers and the residuals of the next batches; wave 0 runs the chain and stores the values.
 // They are coupled through a ring of RING64 batches and two counters in the stream's scratch, all of it scalar memory
