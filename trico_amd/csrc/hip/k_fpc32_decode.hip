@@ -119,6 +119,54 @@ __device__ __forceinline__ uint32_t lens_sum(uint32_t x)
 #define CH4_OCT(B, D, DN, XL) CH4_EVEN(B + 0, D, D, XL) CH4_ODD(B + 1, D, D, CH4_NOX) CH4_EVEN(B + 2, D, D, CH4_NOX) CH4_ODD(B + 3, D, D, CH4_NOX) \
                               CH4_EVEN(B + 4, D, D, CH4_NOX) CH4_ODD(B + 5, D, D, CH4_NOX) CH4_EVEN(B + 6, D, D, CH4_NOX) CH4_ODD(B + 7, D, DN, CH4_NOX)
 
+// Runs of exact hits.  When the parser has flagged a batch (64 values FCM-coded without residual, or 64 values DFCM-coded with
+// a zero residual) and its first two values have come out with one stride S - zero for the FCM kind; for the DFCM kind with a
+// stationary hash (the entry the next value needs is the one just stored) - then every later value of the batch is its
+// predecessor plus S, the DFCM entry of that hash stays S, and of the FCM table only the entry of the values' common top four
+// bits changes (to the last value), provided those bits are common: |S| < 2^25 and first and last of the 62 in one class.
+// The 62 values are then one multiply-add on the vector unit instead of 62 x 20 scalar instructions (a smooth coordinate of a
+// regular grid decodes at the parser's speed, ~12 ns per value); anything else falls through to the steps.
+// After odd step 1: s52 = stride, s53 = value 1, s54 = stride of value 0, a2a = current DFCM address, a2b = the one before.
+#define CH4_RUN \
+  "s_cmp_eq_u32 %[kind], 0\n"                   \
+  "s_cbranch_scc1 5f\n"                         \
+  "s_cmp_eq_u32 s52, s54\n"                     \
+  "s_cbranch_scc0 5f\n"                         \
+  "s_cmp_eq_u32 %[kind], 1\n"                   \
+  "s_cselect_b32 %[q], s52, 0\n"                \
+  "s_cmp_eq_u32 %[q], 0\n"                      \
+  "s_cbranch_scc0 5f\n"                         \
+  "s_cmp_eq_u32 %[kind], 2\n"                   \
+  "s_cselect_b32 %[q], %[a2b], %[a2a]\n"        \
+  "s_cmp_eq_u32 %[q], %[a2a]\n"                 \
+  "s_cbranch_scc0 5f\n"                         \
+  "s_abs_i32 %[q], s52\n"                       \
+  "s_cmp_lt_u32 %[q], 0x2000000\n"              \
+  "s_cbranch_scc0 5f\n"                         \
+  "s_mul_i32 %[q], s52, 61\n"                   \
+  "s_add_u32 %[q], %[q], s53\n"                 \
+  "s_xor_b32 %[h], %[q], s53\n"                 \
+  "s_lshr_b32 %[h], %[h], 28\n"                 \
+  "s_cmp_eq_u32 %[h], 0\n"                      \
+  "s_cbranch_scc0 5f\n"                         \
+  "s_mov_b64 exec, -4\n"                        \
+  "v_mul_lo_u32 %[vt], %[lanem1], s52\n"        \
+  "v_add_u32 %[outv], s53, %[vt]\n"             \
+  "s_mov_b64 exec, -1\n"                        \
+  "s_lshr_b32 m0, %[q], 28\n"                   \
+  "s_add_u32 s53, %[q], s52\n"                  \
+  "s_movreld_b32 s84, s53\n"                    \
+  "s_lshr_b32 m0, s53, 28\n"                    \
+  "s_store_dword s52, %[T2b], %[a2a]\n"         \
+  "s_movrels_b32 s56, s84\n"                    \
+  "s_waitcnt lgkmcnt(0)\n"                      \
+  "s_load_dword %[t2], %[T2b], %[a2a]\n"        \
+  "s_cmp_eq_u32 s52, s52\n"                     \
+  "s_branch 6f\n"                               \
+  "5:\n"
+#define CH4_OCT0(D, XL) CH4_EVEN(0, D, D, XL) CH4_ODD(1, D, D, CH4_NOX) CH4_RUN CH4_EVEN(2, D, D, CH4_NOX) CH4_ODD(3, D, D, CH4_NOX) \
+                        CH4_EVEN(4, D, D, CH4_NOX) CH4_ODD(5, D, D, CH4_NOX) CH4_EVEN(6, D, D, CH4_NOX) CH4_ODD(7, D, D, CH4_NOX)
+
 // Scratch of one stream in global memory (FPC32_DECODE_TABLE_BYTES), touched by this workgroup only and only through the
 // scalar cache: DFCM table (4 KiB), FCM table for the tail (64 B), at SCRATCH_X RING slots of 512 B (64 residuals, then the
 // mask of DFCM-coded values), then the two counters that couple the waves, each in a cache line of its own.
@@ -138,11 +186,11 @@ struct ChainEnd { uint32_t last, a2; };       // what the tail loop needs: last 
 // rest of the state stay in their registers from the first value to the last.
 //   s[76:77] scratch / batch counter    s[78:79] ring slot of the batch    s[80:81] output address of the batch's value 0
 //   s82, s83 mask of DFCM-coded values
-__device__ __forceinline__ ChainEnd chain4_run(const uint32_t* T2b, uint32_t nb, uint32_t* out0, uint32_t voff, uint32_t out_step)
+__device__ __forceinline__ ChainEnd chain4_run(const uint32_t* T2b, uint32_t nb, uint32_t* out0, uint32_t voff, uint32_t out_step, uint32_t lanem1)
   {
   const uint64_t xb = (uint64_t)(uintptr_t)(T2b + SCRATCH_X), ob = (uint64_t)(uintptr_t)out0;
   const uint32_t xlo = (uint32_t)xb, xhi = (uint32_t)(xb >> 32), olo = (uint32_t)ob, ohi = (uint32_t)(ob >> 32);
-  uint32_t last, sprev, a2a, a2b, P, t2, fwd, outv, q, h, g;
+  uint32_t last, sprev, a2a, a2b, P, t2, fwd, outv, q, h, g, kind, vt;
   asm volatile(
     "s_mov_b64 s[84:85], 0\n s_mov_b64 s[86:87], 0\n s_mov_b64 s[88:89], 0\n s_mov_b64 s[90:91], 0\n"
     "s_mov_b64 s[92:93], 0\n s_mov_b64 s[94:95], 0\n s_mov_b64 s[96:97], 0\n s_mov_b64 s[98:99], 0\n"
@@ -166,12 +214,14 @@ __device__ __forceinline__ ChainEnd chain4_run(const uint32_t* T2b, uint32_t nb,
     "s_add_u32 s78, %[xlo], s76\n"
     "s_addc_u32 s79, %[xhi], 0\n"
     "s_load_dwordx2 s[82:83], s[78:79], 0x100\n"
+    "s_load_dword %[kind], s[78:79], 0x108\n"
     "s_load_dwordx8 s[60:67], s[78:79], 0x0\n"
     "s_cmp_eq_u32 %[fwd], 0\n"
     "s_waitcnt lgkmcnt(0)\n"
     "s_cselect_b32 %[g], s82, 0\n"
-    CH4_OCT(0, "s82", "s82", CH4_XLOAD) CH4_OCT(8, "s82", "s82", CH4_XLOAD) CH4_OCT(16, "s82", "s82", CH4_XLOAD) CH4_OCT(24, "s82", "s83", CH4_XLOAD)
+    CH4_OCT0("s82", CH4_XLOAD) CH4_OCT(8, "s82", "s82", CH4_XLOAD) CH4_OCT(16, "s82", "s82", CH4_XLOAD) CH4_OCT(24, "s82", "s83", CH4_XLOAD)
     CH4_OCT(32, "s83", "s83", CH4_XLOAD) CH4_OCT(40, "s83", "s83", CH4_XLOAD) CH4_OCT(48, "s83", "s83", CH4_XLOAD) CH4_OCT(56, "s83", "s83", CH4_NOX)
+    "6:\n"
     "s_cselect_b32 %[fwd], 0, 1\n"                     /* SCC still says whether the last load address differed from the last store address */
     "global_store_dword %[voff], %[outv], s[80:81]\n"
     "s_add_u32 s80, s80, %[ostep]\n"
@@ -189,8 +239,9 @@ __device__ __forceinline__ ChainEnd chain4_run(const uint32_t* T2b, uint32_t nb,
     "s_store_dwordx4 s[96:99], %[T2b], 0x1030\n"
     "s_waitcnt lgkmcnt(0)\n"
     : [last] "=&s"(last), [sprev] "=&s"(sprev), [a2a] "=&s"(a2a), [a2b] "=&s"(a2b), [P] "=&s"(P), [t2] "=&s"(t2), [fwd] "=&s"(fwd),
-      [outv] "=&v"(outv), [q] "=&s"(q), [h] "=&s"(h), [g] "=&s"(g)
-    : [T2b] "s"(T2b), [xlo] "s"(xlo), [xhi] "s"(xhi), [olo] "s"(olo), [ohi] "s"(ohi), [voff] "v"(voff), [ostep] "s"(out_step), [nb] "s"(nb)
+      [outv] "=&v"(outv), [q] "=&s"(q), [h] "=&s"(h), [g] "=&s"(g), [kind] "=&s"(kind), [vt] "=&v"(vt)
+    : [T2b] "s"(T2b), [xlo] "s"(xlo), [xhi] "s"(xhi), [olo] "s"(olo), [ohi] "s"(ohi), [voff] "v"(voff), [ostep] "s"(out_step), [nb] "s"(nb),
+      [lanem1] "v"(lanem1)
     : "scc", "memory", "m0", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
       "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87",
       "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
@@ -200,7 +251,7 @@ __device__ __forceinline__ ChainEnd chain4_run(const uint32_t* T2b, uint32_t nb,
 
 // parser wave: the 64 residuals of a batch (lane K = residual K) and the mask of its DFCM-coded values go to the ring slot with
 // scalar stores, through the scalar cache the chain reads; complete on return
-__device__ __forceinline__ void chain4_put_batch(uint32_t xr, uint64_t dfcm, const uint32_t* slot)
+__device__ __forceinline__ void chain4_put_batch(uint32_t xr, uint64_t dfcm, uint32_t kind, const uint32_t* slot)
   {
 #define CH4_PUT4(J, R0, R1, R2, R3) \
   "v_readlane_b32 s" #R0 ", %[xr], 4 * (" #J ")\n v_readlane_b32 s" #R1 ", %[xr], 4 * (" #J ") + 1\n" \
@@ -212,8 +263,9 @@ __device__ __forceinline__ void chain4_put_batch(uint32_t xr, uint64_t dfcm, con
     CH4_PUT4(8, 52, 53, 54, 55) CH4_PUT4(9, 56, 57, 58, 59) CH4_PUT4(10, 60, 61, 62, 63) CH4_PUT4(11, 64, 65, 66, 67)
     CH4_PUT4(12, 52, 53, 54, 55) CH4_PUT4(13, 56, 57, 58, 59) CH4_PUT4(14, 60, 61, 62, 63) CH4_PUT4(15, 64, 65, 66, 67)
     "s_store_dwordx2 %[dfcm], %[slot], 0x100\n"
+    "s_store_dword %[kind], %[slot], 0x108\n"
     "s_waitcnt lgkmcnt(0)\n"
-    :: [xr] "v"(xr), [dfcm] "s"(dfcm), [slot] "s"(slot)
+    :: [xr] "v"(xr), [dfcm] "s"(dfcm), [kind] "s"(kind), [slot] "s"(slot)
     : "memory", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67");
   }
 
@@ -369,7 +421,10 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
       const uint32_t raw = __builtin_amdgcn_alignbyte(win[(rp >> 2) + 1u], win[rp >> 2], rp & 3u);
       const uint32_t xr = nbytes ? __builtin_bswap32(raw) >> (8u * (4u - nbytes)) : 0u;
       const uint64_t dfcm = __ballot(code > 4u);
-      chain4_put_batch(xr, dfcm, T2g + SCRATCH_X + SLOT_DWORDS * (t % RING));
+      // batches of 64 exact hits (the chain extrapolates them, see CH4_RUN): 1 = all FCM-coded without residual, 2 = all
+      // DFCM-coded with a zero residual byte
+      const uint32_t kind = __ballot(code != 0u) == 0ull ? 1u : (__ballot(code != 5u || xr != 0u) == 0ull ? 2u : 0u);
+      chain4_put_batch(xr, dfcm, kind, T2g + SCRATCH_X + SLOT_DWORDS * (t % RING));
       ++t;
       counter_store(T2g, SCRATCH_PRODUCED, t);
       }
@@ -387,7 +442,7 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
     // the chain owns its SIMD's issue slots whenever it can issue: other kernels' waves (the sweeps of the LZ4 decoder, other
     // archives) may share the CU
     __builtin_amdgcn_s_setprio(3);
-    ce = chain4_run(T2g, nb, dst + comp, 4u * (uint32_t)lane * (uint32_t)arity, 256u * (uint32_t)arity);
+    ce = chain4_run(T2g, nb, dst + comp, 4u * (uint32_t)lane * (uint32_t)arity, 256u * (uint32_t)arity, (uint32_t)lane - 1u);
     }
   __syncthreads();
   bool bad = sh_bad != 0u;
