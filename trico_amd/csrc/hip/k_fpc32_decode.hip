@@ -251,6 +251,13 @@ __device__ __forceinline__ ChainEnd chain4_run(const uint32_t* T2b, uint32_t nb,
 
 // parser wave: the 64 residuals of a batch (lane K = residual K) and the mask of its DFCM-coded values go to the ring slot with
 // scalar stores, through the scalar cache the chain reads; complete on return
+// the mask and kind of a batch whose 64 residuals are zero, into a slot that already holds 64 zero residuals
+__device__ __forceinline__ void chain4_put_flags(uint64_t dfcm, uint32_t kind, const uint32_t* slot)
+  {
+  asm volatile("s_store_dwordx2 %[dfcm], %[slot], 0x100\n s_store_dword %[kind], %[slot], 0x108\n s_waitcnt lgkmcnt(0)\n"
+               :: [dfcm] "s"(dfcm), [kind] "s"(kind), [slot] "s"(slot) : "memory");
+  }
+
 __device__ __forceinline__ void chain4_put_batch(uint32_t xr, uint64_t dfcm, uint32_t kind, const uint32_t* slot)
   {
 #define CH4_PUT4(J, R0, R1, R2, R3) \
@@ -381,6 +388,7 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
       };
     refill(q);
     uint32_t t = 0;
+    uint32_t zero_slots = 0;                             // ring slots whose 64 residuals are all zero
     bool failed = false;
     while (t < nb)
       {
@@ -424,7 +432,14 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
       // batches of 64 exact hits (the chain extrapolates them, see CH4_RUN): 1 = all FCM-coded without residual, 2 = all
       // DFCM-coded with a zero residual byte
       const uint32_t kind = __ballot(code != 0u) == 0ull ? 1u : (__ballot(code != 5u || xr != 0u) == 0ull ? 2u : 0u);
-      chain4_put_batch(xr, dfcm, kind, T2g + SCRATCH_X + SLOT_DWORDS * (t % RING));
+      // (a slot that holds the zero residuals of an earlier flagged batch is not written again: on smooth streams the parser,
+      // not the chain, is what the stream waits for)
+      const uint32_t sl = t % RING;
+      if (kind != 0u && ((zero_slots >> sl) & 1u))
+        chain4_put_flags(dfcm, kind, T2g + SCRATCH_X + SLOT_DWORDS * sl);
+      else
+        chain4_put_batch(xr, dfcm, kind, T2g + SCRATCH_X + SLOT_DWORDS * sl);
+      zero_slots = kind != 0u ? zero_slots | (1u << sl) : zero_slots & ~(1u << sl);
       ++t;
       counter_store(T2g, SCRATCH_PRODUCED, t);
       }
