@@ -21,6 +21,14 @@ def _device_streams(streams):
     return [(name, torch.from_numpy(a.view(np.uint8)).cuda(), cnt) for name, a, cnt in streams]
 
 
+def _repeats(api):
+    """decodes this thread had to repeat because the self-check of the chain decoders failed (trico_hip_last_stats word 2)"""
+    import ctypes
+    st = (ctypes.c_uint32 * 4)()
+    api.lib().trico_hip_last_stats(st)
+    return int(st[2])
+
+
 def test_config2_full_size(api, hashes):
     """configs[1]: 50M float vertices + 100M uint32 triangles on one MI355X, bit-exact .trc vs the reference."""
     import torch
@@ -32,6 +40,7 @@ def test_config2_full_size(api, hashes):
     g = hashes["grid_10000x5000"]
     assert len(blob) == g["size"]
     assert hashlib.sha256(blob).hexdigest() == g["sha256"]
+    before = _repeats(api)
     r = api.Archive.open_for_reading(a.get_buffer_pointer(), a.get_size())
     for name, d, cnt in dev:
         out = torch.empty_like(d)
@@ -39,6 +48,7 @@ def test_config2_full_size(api, hashes):
         assert torch.equal(out, d), name
     r.close()
     a.close()
+    assert _repeats(api) == before            # the chains were right by themselves: the self-check had nothing to repeat
 
 
 class _Full:
@@ -94,8 +104,10 @@ def test_config3_full_size(api, hashes, full):
     assert hashlib.sha256(blob).hexdigest() == g["sha256"]
     del blob
     errs = []
+    before = _repeats(api)
     _decode_all(api, dev, a, errs, "multi")
     assert not errs, errs
+    assert _repeats(api) == before            # the double chains were right by themselves
 
 
 @pytest.mark.parametrize("k", range(1, 8))

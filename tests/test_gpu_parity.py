@@ -491,3 +491,45 @@ def test_lz4_chunked_compressor_regimes(api, kind):
     assert r.read("attributes_uint8", back) == 1, api.last_error()
     r.close()
     assert back.tobytes() == data.tobytes()
+
+
+@pytest.mark.parametrize("kind", ["ramp", "ramp_across_class", "ramp_wraps_zero", "big_stride", "constant", "constant_then_step",
+                                  "ramp_restarts", "two_strides"])
+def test_exact_hit_runs_of_the_float_decoder(api, kind):
+    """bit patterns that make whole batches of exact FCM / DFCM hits (k_fpc32_decode.hip extrapolates such batches in closed form)
+    and the cases where it must not: the common top four bits change inside a batch, the progression wraps, the stride is
+    large, the run breaks or changes stride mid-batch.  The chain itself must get them right: no repeat by the self-check."""
+    n = 64 * 41 + 17
+    k = np.arange(n, dtype=np.uint64)
+    if kind == "ramp":
+        bits = 0x41200000 + 3 * k
+    elif kind == "ramp_across_class":
+        bits = 0x3FFFFC00 + 0x20 * k                       # crosses 0x40000000 inside the first batches
+    elif kind == "ramp_wraps_zero":
+        bits = (0x00000400 - 0x30 * k.astype(np.int64)).astype(np.uint64)      # runs below zero: wraps to 0xffffffxx
+    elif kind == "big_stride":
+        bits = 0x10000000 + 0x04000000 * k                 # stride 2^26: one class change every four values
+    elif kind == "constant":
+        bits = np.full(n, 0x42F6E979, np.uint64)
+    elif kind == "constant_then_step":
+        bits = np.where(k < 64 * 7 + 31, 0x42F6E979, 0x42F6E979 + 5 * (k - (64 * 7 + 31)))
+    elif kind == "ramp_restarts":
+        bits = 0x41200000 + 7 * (k % 1000)
+    else:
+        bits = np.where((k // 500) % 2 == 0, 0x41200000 + 3 * k, 0x41200000 + 3 * k + 11 * (k % 500))
+    data = np.ascontiguousarray((np.asarray(bits, dtype=np.uint64) & 0xFFFFFFFF).astype(np.uint32).view(np.float32))
+    a = api.Archive.open_for_writing(1 << 16)
+    assert a.write("attributes_float", data, n) == 1, api.last_error()
+    got = a.tobytes()
+    a.close()
+    assert got == oracle_archive([("attributes_float", data, n)])
+    stats = (ctypes.c_uint32 * 4)()
+    api.lib().trico_hip_last_stats(stats)
+    before = stats[2]
+    r = api.Archive.open_for_reading(got)
+    back = r.read_alloc("attributes_float", n, np.float32)
+    assert back is not None, api.last_error()
+    r.close()
+    assert back.tobytes() == data.tobytes()
+    api.lib().trico_hip_last_stats(stats)
+    assert stats[2] == before                          # the decoder chain was right by itself
