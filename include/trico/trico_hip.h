@@ -85,6 +85,69 @@ TRICO_API int trico_hip_decode_begin(trico_hip_ctx* ctx, int is_int, const uint8
                                      int arity, int width, uint32_t n);
 TRICO_API int trico_hip_decode_finish(trico_hip_ctx* ctx, void* dst);
 
+/* ---- batched decode: one launch for all chains -------------------------------------------------
+ * The format leaves ONE serial chain per floating-point component (fpsc.c:308-326), so decode throughput is the number of
+ * chains in flight.  A job is one stream (what one trico_read_* call decodes, trico.c:943-1668); a batch may hold the streams
+ * of one archive or of many.  trico_hip_decode_jobs decodes them all: every float chain of the batch in ONE kernel launch,
+ * every double chain in one, the integer streams beside them, the chain decoders' self-checks behind them; it returns when
+ * everything is in place.  `payloads[c]` / `dst` may be host or device pointers; dst == NULL skips the job.
+ * fp: arity 1..3 components of `width` 4 / 8 bytes, n values per component, payloads[0..arity);
+ * int: `width` 1, 2, 4 or 8 byte planes, n integers, payloads[0..width).
+ * Returns 1 if every job succeeded; jobs[i].ok says which did (a malformed stream fails alone). */
+typedef struct trico_hip_decode_job
+  {
+  int32_t is_int, arity, width;
+  uint32_t n;
+  const uint8_t* payloads[8];
+  uint32_t sizes[8];
+  void* dst;
+  int32_t ok;              /* out */
+  int32_t reserved;
+  } trico_hip_decode_job;
+TRICO_API int trico_hip_decode_jobs(trico_hip_decode_job* jobs, int count);
+/* allocates (and keeps) the device workspaces a batch of this shape needs, without decoding: takes the allocation out of the
+ * latency of the first trico_hip_decode_jobs call.  Later batches of the same or a smaller shape allocate nothing either way. */
+TRICO_API int trico_hip_decode_jobs_reserve(const trico_hip_decode_job* jobs, int count);
+
+/* ---- whole archives at once --------------------------------------------------------------------
+ * trico_hip_list_streams: describes the streams from the cursor of a read archive to its end, without consuming them
+ * (at most `cap` entries; returns how many there are, -1 if the framing is broken before the end).
+ * trico_hip_read_archives: decodes the remaining streams of `count` read archives as ONE batch (trico_hip_decode_jobs).
+ * dsts[a][s] receives stream s (counted from the cursor) of archive a: caller-allocated like the `*ptr` of the trico_read_*
+ * calls (host or device), NULL skips the stream; nstreams[a] entries are given, streams beyond them stay unread.  On return
+ * every archive's cursor is behind the last stream that was decoded (or skipped) successfully, exactly as if the matching
+ * trico_read_* calls had been made one by one.  Returns 1 if all streams asked for were decoded. */
+typedef struct trico_hip_stream_info
+  {
+  int32_t type;            /* enum trico_stream_type */
+  int32_t is_int, arity, width;
+  uint32_t count;          /* the count field of the stream (what the trico_get_number_of_* peek returns) */
+  uint32_t n;              /* values per component / integers */
+  uint64_t decoded_bytes;  /* size of the buffer a trico_read_* call fills */
+  uint64_t payload_bytes;  /* compressed bytes of all its components */
+  } trico_hip_stream_info;
+TRICO_API int trico_hip_list_streams(void* archive, trico_hip_stream_info* out, int cap);
+TRICO_API int trico_hip_read_archives(void* const* archives, int count, void* const* const* dsts, const int* nstreams);
+
+/* ---- framing of a device-resident archive --------------------------------------------------------
+ * trico_open_archive_for_reading accepts a device pointer; its readers need the few framing bytes of every stream on the
+ * host (type byte, count, one size field per component: trico.c:100-124, 943-957 read them from host memory).  This walks up
+ * to `cap` streams on the device, starting at the type byte at position `pos`, and brings their framing bytes back with one
+ * copy.  ncomp_of_type[t] = components of stream type t (0: unknown, the walk stops).  head8 receives the 8 bytes of the file
+ * header.  Returns the number of streams described (a stream cut off by the end of the archive is described as far as it
+ * goes and ends the walk), -1 on a HIP error. */
+typedef struct trico_hip_frame_bytes
+  {
+  uint64_t tpos;            /* position of the stream's type byte */
+  uint64_t size_pos[8];     /* position of the size field of component c */
+  uint32_t ncomp;           /* size fields found */
+  uint32_t nbytes_head;     /* how many of the 5 bytes at tpos (type, count) lie inside the archive */
+  uint8_t  size_valid[8];
+  uint8_t  bytes[40];       /* type, count, then 4 bytes per size field */
+  } trico_hip_frame_bytes;
+TRICO_API int trico_hip_walk_frames(const uint8_t* d_data, uint64_t size, uint64_t pos, const uint8_t ncomp_of_type[21],
+                                    trico_hip_frame_bytes* out, int cap, uint8_t head8[8]);
+
 /* copy payload `c` of the last encode on this context to dst (host or device) */
 TRICO_API int trico_hip_fetch_payload(trico_hip_ctx* ctx, int c, void* dst);
 /* Vertex welding for the binary STL reader (trico_io/iostl.c:69-134): `corners` holds 3 * ntri positions (xyz floats, host

@@ -22,8 +22,8 @@ int trico_hip_int_encode(trico_hip_ctx* c, const void* s, uint32_t n, int w, uin
 int trico_hip_int_decode(trico_hip_ctx* c, const uint8_t* const p[8], const uint32_t z[8], int w, uint32_t n, void* d) { (void)c; (void)p; (void)z; (void)w; (void)n; (void)d; return 0; }
 int trico_hip_fetch_payload(trico_hip_ctx* c, int i, void* d) { (void)c; (void)i; (void)d; return 0; }
 int trico_hip_fetch_payloads(trico_hip_ctx* c, int n, void* const* d) { (void)c; (void)n; (void)d; return 0; }
-int trico_hip_decode_begin(trico_hip_ctx* c, int k, const uint8_t* const* p, const uint32_t* z, int a, int w, uint32_t n) { (void)c; (void)k; (void)p; (void)z; (void)a; (void)w; (void)n; return 0; }
-int trico_hip_decode_finish(trico_hip_ctx* c, void* d) { (void)c; (void)d; return 0; }
+int trico_hip_decode_jobs(trico_hip_decode_job* j, int n) { for (int i = 0; i < n; ++i) j[i].ok = j[i].dst == NULL; return 0; }
+int trico_hip_walk_frames(const uint8_t* d, uint64_t z, uint64_t p, const uint8_t t[21], trico_hip_frame_bytes* o, int c, uint8_t h[8]) { (void)d; (void)z; (void)p; (void)t; (void)o; (void)c; (void)h; return -1; }
 
 int main(int argc, char** argv)
   {
@@ -42,6 +42,18 @@ int main(int argc, char** argv)
     if (a)
       {
       float* dummy = (float*)malloc(16);
+      /* the whole-archive entry points walk the same frames: listing, then a batch of skips (NULL destinations) on a second handle */
+      trico_hip_stream_info infos[8];
+      const int listed = trico_hip_list_streams(a, infos, 8);
+      if (listed > 0)
+        {
+        void* b = trico_open_archive_for_reading(blob, (uint64_t)n);
+        void* dsts[8] = { NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL };
+        void* const* rows[1] = { dsts };
+        const int cnt = listed < 8 ? listed : 8;
+        (void)trico_hip_read_archives(&b, 1, rows, &cnt);
+        trico_close_archive(b);
+        }
       for (int guard = 0; guard < 1000; ++guard)
         {
         const enum trico_stream_type st = trico_get_next_stream_type(a);

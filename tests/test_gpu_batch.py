@@ -1,0 +1,185 @@
+"""GPU tier: the batched decode (trico_hip_decode_jobs / trico_hip_read_archives, trico_amd/csrc/hip/engine.hip): every
+chain of a batch in one kernel launch.  Results must be those of the one-by-one readers (trico.c:943-1668), bit for bit, for
+host- and device-resident archives, and a malformed stream must fail alone."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from streams import ALL_ORDER, mesh_streams
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def api(native_libs):
+    L = native_libs.lib()
+    assert L.trico_hip_available() == 1, "no HIP device: " + native_libs.last_error()
+    return native_libs
+
+
+def oracle_archive(streams):
+    a = O.OracleArchive()
+    for name, data, count in streams:
+        a.write(name, data, count)
+    b = a.tobytes()
+    a.close()
+    return b
+
+
+def some_archives(allstreams):
+    """(blob written by the ORACLE, its streams) for a mix of shapes: float chains of several lengths (tails of 0..63 values
+    behind the 64-value batches), doubles, u32 / u64 planes, and the archive with all twenty stream types."""
+    sets = [mesh_streams("grid", 256, 128), mesh_streams("walk", 100, 77), mesh_streams("multi", 64, 33),
+            mesh_streams("grid", 16, 8), mesh_streams("grid", 193, 50, seed=0x12345679),
+            [(name, allstreams[name], allstreams[name].size // div) for name, div, _ in ALL_ORDER]]
+    return [(oracle_archive(s), s) for s in sets]
+
+
+def empty_like_streams(streams):
+    return [np.zeros_like(d) for _, d, _ in streams]
+
+
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_read_archives_equals_one_by_one(api, allstreams, where):
+    import torch
+    sets = some_archives(allstreams)
+    keep, archives, outs = [], [], []
+    for blob, streams in sets:
+        if where == "device":
+            t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+            keep.append(t)
+            r = api.Archive.open_for_reading(t)
+        else:
+            r = api.Archive.open_for_reading(blob)
+        assert r is not None
+        infos = api.list_streams(r)
+        assert infos is not None and len(infos) == len(streams)
+        for inf, (name, data, count) in zip(infos, streams):
+            assert inf.decoded_bytes == data.nbytes, name
+            assert inf.count == (count * 3 if name == "uv_per_triangle" else count), name
+        archives.append(r)
+        if where == "device":
+            outs.append([torch.zeros(d.nbytes, dtype=torch.uint8, device="cuda") for _, d, _ in streams])
+        else:
+            outs.append(empty_like_streams(streams))
+    assert api.read_archives(archives, outs) == 1, api.last_error()
+    for r, (blob, streams), o in zip(archives, sets, outs):
+        assert r.get_next_stream_type() == api.trico_empty
+        for (name, data, _), got in zip(streams, o):
+            g = got.cpu().numpy().tobytes() if where == "device" else got.tobytes()
+            assert g == data.tobytes(), name
+        r.close()
+    stats = (ctypes.c_uint32 * 4)()
+    api.lib().trico_hip_last_stats(stats)
+    assert stats[2] == 0, "a chain decode had to be repeated"
+
+
+def test_read_archives_prefix_and_skips(api, allstreams):
+    """nstreams smaller than what is left: the rest stays unread; a NULL destination skips its stream."""
+    blob, streams = some_archives(allstreams)[5]
+    r = api.Archive.open_for_reading(blob)
+    outs = empty_like_streams(streams)
+    first = [outs[0], None, outs[2]]
+    assert api.read_archives([r], [first]) == 1, api.last_error()
+    assert outs[0].tobytes() == streams[0][1].tobytes() and outs[2].tobytes() == streams[2][1].tobytes()
+    assert not outs[1].any()
+    assert r.get_next_stream_type() == 4                       # triangles_long comes next, read the classic way
+    assert r.read("triangles_long", outs[3]) == 1, api.last_error()
+    assert outs[3].tobytes() == streams[3][1].tobytes()
+    r.close()
+
+
+def test_malformed_stream_fails_alone(api):
+    """Two archives in one batch; the second archive's x stream is cut short inside its groups: only that stream fails, the
+    cursor of its archive stays in front of it, everything else is decoded."""
+    good = mesh_streams("grid", 128, 64)
+    blob_a = oracle_archive(good)
+    blob_b = bytearray(oracle_archive(mesh_streams("walk", 128, 64)))
+    # framing: 8 header, type, count, then size of x at 13..16 and its payload; damage the value count inside the payload header
+    blob_b[18] ^= 0x40
+    ra = api.Archive.open_for_reading(blob_a)
+    rb = api.Archive.open_for_reading(bytes(blob_b))
+    oa, ob = empty_like_streams(good), empty_like_streams(good)
+    assert api.read_archives([ra, rb], [oa, ob]) == 0
+    assert ra.get_next_stream_type() == api.trico_empty
+    assert oa[0].tobytes() == good[0][1].tobytes() and oa[1].tobytes() == good[1][1].tobytes()
+    assert rb.get_next_stream_type() == 1                      # still in front of its vertices
+    ra.close()
+    rb.close()
+
+
+def test_decode_jobs_direct(api):
+    """trico_hip_decode_jobs on payloads taken out of an archive by hand: float + int job, host pointers."""
+    import struct
+    streams = mesh_streams("grid", 200, 100)
+    blob = oracle_archive(streams)
+    (v, t) = (streams[0][1], streams[1][1])
+    pos = 8
+    specs, keep = [], []
+    for is_int, ncomp, width, n, ref in ((0, 3, 4, 200 * 100, v), (1, 4, 4, 3 * 2 * 200 * 100, t)):
+        pos += 5
+        pays = []
+        for _ in range(ncomp):
+            nb = struct.unpack_from("<I", blob, pos)[0]
+            p = np.frombuffer(blob[pos + 4: pos + 4 + nb], np.uint8).copy()
+            keep.append(p)
+            pays.append((p, nb))
+            pos += 4 + nb
+        out = np.zeros_like(ref)
+        keep.append(out)
+        specs.append({"is_int": is_int, "arity": 3 if not is_int else 1, "width": width, "n": n, "payloads": pays, "dst": out})
+    jobs = api.make_jobs(specs)
+    assert api.lib().trico_hip_decode_jobs_reserve(jobs, len(specs)) == 1, api.last_error()
+    assert api.lib().trico_hip_decode_jobs(jobs, len(specs)) == 1, api.last_error()
+    assert all(j.ok == 1 for j in jobs)
+    assert specs[0]["dst"].tobytes() == v.tobytes() and specs[1]["dst"].tobytes() == t.tobytes()
+
+
+CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r + "/tests")
+from trico_amd import api
+from oracle import oracle as O
+from streams import mesh_streams
+sets = [mesh_streams("grid", 256, 128), mesh_streams("walk", 100, 77), mesh_streams("grid", 64, 64), mesh_streams("grid", 193, 50),
+        mesh_streams("walk", 64, 9)]
+archives, outs = [], []
+for s in sets:
+    a = O.OracleArchive()
+    for name, data, count in s:
+        a.write(name, data, count)
+    archives.append(api.Archive.open_for_reading(a.tobytes()))
+    a.close()
+    outs.append([np.zeros_like(d) for _, d, _ in s])
+assert api.read_archives(archives, outs) == 1, api.last_error()
+for s, o in zip(sets, outs):
+    for (name, data, _), got in zip(s, o):
+        assert got.tobytes() == data.tobytes(), name
+print("BATCH OK")
+"""
+
+
+@pytest.mark.parametrize("cpw", [2, 4])
+def test_several_chains_per_workgroup(cpw):
+    """TRICO_FPC32_CHAINS_PER_CU: the same batch with two and four chains per workgroup (15 float chains: the last workgroup is
+    partly empty)."""
+    env = dict(os.environ)
+    env["TRICO_FPC32_CHAINS_PER_CU"] = str(cpw)
+    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "BATCH OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_product_library_has_no_sabotage_switch():
+    env = dict(os.environ)
+    env["TRICO_HIP_DECODE_SABOTAGE"] = "3"
+    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "BATCH OK" in out.stdout, out.stdout + out.stderr

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtrico.so")
+# TRICO_AMD_LIB: another build of the same library (tests/test_gpu_selfcheck.py loads libtrico_testhooks.so through it)
+LIB_PATH = os.environ.get("TRICO_AMD_LIB") or os.path.join(_HERE, "lib", "libtrico.so")
 
 _lib = None
 
@@ -57,7 +58,24 @@ HIP_SYMBOLS = [
     "trico_hip_int_encode", "trico_hip_int_decode", "trico_hip_fetch_payload", "trico_hip_fetch_payloads", "trico_hip_payload_device_pointer",
     "trico_hip_open_archive_for_writing_device", "trico_hip_profile_enable", "trico_hip_profile_reset",
     "trico_hip_profile_ms", "trico_hip_last_stats",
+    "trico_hip_decode_jobs", "trico_hip_decode_jobs_reserve", "trico_hip_list_streams", "trico_hip_read_archives",
+    "trico_hip_walk_frames",
 ]
+
+
+class DecodeJob(ctypes.Structure):
+    """trico_hip_decode_job (include/trico/trico_hip.h): one stream of a batched decode."""
+    _fields_ = [("is_int", ctypes.c_int32), ("arity", ctypes.c_int32), ("width", ctypes.c_int32), ("n", ctypes.c_uint32),
+                ("payloads", ctypes.c_void_p * 8), ("sizes", ctypes.c_uint32 * 8), ("dst", ctypes.c_void_p),
+                ("ok", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class StreamInfo(ctypes.Structure):
+    """trico_hip_stream_info: what trico_hip_list_streams reports per stream."""
+    _fields_ = [("type", ctypes.c_int32), ("is_int", ctypes.c_int32), ("arity", ctypes.c_int32), ("width", ctypes.c_int32),
+                ("count", ctypes.c_uint32), ("n", ctypes.c_uint32), ("decoded_bytes", ctypes.c_uint64),
+                ("payload_bytes", ctypes.c_uint64)]
+
 KERNEL_IDS = {
     "fpc32_encode": 0, "fpc64_encode": 1, "fpc32_decode": 2, "fpc64_decode": 3,
     "planes_split": 4, "planes_merge": 5, "lz4_encode": 6, "lz4_decode": 7,
@@ -163,8 +181,50 @@ def lib():
     L.trico_hip_comm_destroy.restype = None
     L.trico_hip_comm_gather.argtypes = [vp, vp, u64, ci, vp, u64, ctypes.POINTER(u64)]
     L.trico_hip_comm_gather.restype = ci
+    # batched decode (engine.hip) and whole-archive reads
+    L.trico_hip_decode_jobs.argtypes = [ctypes.POINTER(DecodeJob), ci]
+    L.trico_hip_decode_jobs.restype = ci
+    L.trico_hip_decode_jobs_reserve.argtypes = [ctypes.POINTER(DecodeJob), ci]
+    L.trico_hip_decode_jobs_reserve.restype = ci
+    L.trico_hip_list_streams.argtypes = [vp, ctypes.POINTER(StreamInfo), ci]
+    L.trico_hip_list_streams.restype = ci
+    L.trico_hip_read_archives.argtypes = [ctypes.POINTER(vp), ci, ctypes.POINTER(ctypes.POINTER(vp)), ctypes.POINTER(ci)]
+    L.trico_hip_read_archives.restype = ci
     _lib = L
     return L
+
+
+def make_jobs(specs):
+    """specs: dicts with is_int, arity, width, n, payloads (list of (address-like, size)), dst -> ctypes array of DecodeJob.
+    The caller keeps the payload / dst objects alive."""
+    arr = (DecodeJob * len(specs))()
+    for j, sp in zip(arr, specs):
+        j.is_int, j.arity, j.width, j.n = int(sp["is_int"]), int(sp.get("arity", 1)), int(sp["width"]), int(sp["n"])
+        for c, (pp, sz) in enumerate(sp["payloads"]):
+            j.payloads[c] = ptr(pp)
+            j.sizes[c] = sz
+        j.dst = ptr(sp["dst"])
+    return arr
+
+
+def list_streams(archive, cap=64):
+    """trico_hip_list_streams: the streams from the cursor of a read archive to its end (list of StreamInfo), None if broken."""
+    buf = (StreamInfo * cap)()
+    n = lib().trico_hip_list_streams(archive.h, buf, cap)
+    if n < 0:
+        return None
+    return [buf[i] for i in range(min(n, cap))]
+
+
+def read_archives(archives, dsts):
+    """trico_hip_read_archives: dsts[a] = list of destinations (arrays / tensors / None) for the remaining streams of
+    archives[a]; ONE batched decode for all of them.  Returns 1 if every stream asked for was decoded."""
+    n = len(archives)
+    hs = (ctypes.c_void_p * n)(*[a.h for a in archives])
+    rows = [(ctypes.c_void_p * max(1, len(d)))(*[ptr(x) for x in d]) for d in dsts]
+    table = (ctypes.POINTER(ctypes.c_void_p) * n)(*[ctypes.cast(r, ctypes.POINTER(ctypes.c_void_p)) for r in rows])
+    counts = (ctypes.c_int * n)(*[len(d) for d in dsts])
+    return lib().trico_hip_read_archives(hs, n, table, counts)
 
 
 def ptr(x):

@@ -27,6 +27,8 @@ HIP_SRC = sorted(f for f in os.listdir(os.path.join(CSRC, "hip")) if f.endswith(
 HIP_HDR = sorted(f for f in os.listdir(os.path.join(CSRC, "hip")) if f.endswith(".hpp"))
 
 LIBTRICO = os.path.join(LIBDIR, "libtrico.so")
+LIBTRICO_HOOKS = os.path.join(LIBDIR, "libtrico_testhooks.so")    # same library + the decode sabotage switch (tests only)
+HOOKED = ("shim.hip",)                                             # sources that look at TRICO_HIP_TEST_HOOKS
 LIBMESHGEN = os.path.join(LIBDIR, "libtrico_meshgen.so")
 LIBIO = os.path.join(LIBDIR, "libtrico_io.so")
 BINDIR = os.path.join(HERE, "bin")
@@ -51,6 +53,7 @@ def build(force=False, verbose=True):
     headers = [os.path.join(INCLUDE, "trico", h) for h in ("trico.h", "trico_hip.h")]
     headers += [os.path.join(CSRC, "hip", h) for h in HIP_HDR]
     objs = []
+    hook_objs = {}
     for rel in HOST_C:
         src = os.path.join(CSRC, rel)
         obj = os.path.join(OBJDIR, os.path.basename(rel) + ".o")
@@ -66,8 +69,18 @@ def build(force=False, verbose=True):
                   "-Wall", "-Wno-unused-function", "-I" + INCLUDE, "-I" + os.path.join(CSRC, "hip"),
                   "-c", src, "-o", obj])
         objs.append(obj)
+        if f in HOOKED:
+            hobj = os.path.join(OBJDIR, f + ".hooks.o")
+            if force or _stale(hobj, [src] + headers):
+                _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DTRICO_HIP_TEST_HOOKS",
+                      "-Wall", "-Wno-unused-function", "-I" + INCLUDE, "-I" + os.path.join(CSRC, "hip"),
+                      "-c", src, "-o", hobj])
+            hook_objs[obj] = hobj
     if force or _stale(LIBTRICO, objs):
         _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIBTRICO] + objs + ["-ldl"])
+    hobjs = [hook_objs.get(o, o) for o in objs]
+    if force or _stale(LIBTRICO_HOOKS, hobjs):
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIBTRICO_HOOKS] + hobjs + ["-ldl"])
     mg = os.path.join(CSRC, "tools", "meshgen.c")
     if force or _stale(LIBMESHGEN, [mg]):
         _run([CC, "-O2", "-std=c11", "-fPIC", "-fvisibility=hidden", "-shared", mg, "-o", LIBMESHGEN])

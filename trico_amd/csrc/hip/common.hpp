@@ -16,6 +16,9 @@ bool hip_ok(hipError_t e, const char* what);
 #define TRICO_HIP_TRY(expr) do { if (!::trico::hip_ok((expr), #expr)) return 0; } while (0)
 
 hipStream_t current_stream();
+void set_current_stream(hipStream_t s);   // stream of this thread's later launches (what trico_hip_set_stream sets)
+bool device_ready();                      // false (and an error message) without a HIP device
+void stats_count_repeat();                // trico_hip_last_stats word 2
 
 // ---- growable device workspace --------------------------------------------------------------
 struct DevBuf
@@ -26,6 +29,9 @@ struct DevBuf
   void release();               // returns the memory to a process-wide pool
   };
 void trim_pool();               // hipFree everything the pool holds
+// stage `bytes` from src (host or device) so that kernels can read it: device sources are returned as they are, host sources
+// are copied to buf.p + offset on current_stream()
+const void* stage_in(DevBuf& buf, const void* src, size_t bytes, size_t offset = 0);
 
 } // namespace trico
 
@@ -111,14 +117,34 @@ int launch_fpc32_compare(uint32_t n, int arity, const uint8_t* d_ws, const uint3
                          const uint32_t sizes[3], uint32_t* d_status, uint32_t flag);
 // generic: sets bit `flag` of *d_status if *d_size != n_expected or the first n_expected bytes of a and b differ
 int launch_bytes_compare(const uint8_t* d_a, const uint8_t* d_b, uint32_t n_expected, const uint32_t* d_size, uint32_t* d_status, uint32_t flag);
+// the self-check of the chain decoders (shim.hip): re-encode + compare, bit 0x100 << c of *d_status where component c differs
+bool decode_check_enabled();
+int fpc_selfcheck_launch(const void* d_vals, uint32_t n, int arity, int width, const uint8_t* const d_pay[3], const uint32_t sizes[3],
+                         DevBuf& vws, uint32_t* d_vsizes, uint32_t* d_status);
+int decode_sabotage(int attempt, void* d_vals, uint32_t n, int arity, int width);   // test hook (no-op in the product library)
+void set_first_attempt(int a);    // the single-stream ladder of this thread starts at attempt a (engine.hip hands streams over at 1)
 bool force_serial();              // TRICO_HIP_SERIAL: see shim.hip
 bool force_serial_stage(int bit);
 
-// latency-optimised float decoder (k_fpc32_decode.hip): one wave per component stream
+// status bits of the chain decoders (k_fpc32_decode.hip, k_fpc64.hip), or-ed into a job's status word
+constexpr uint32_t FPC_STATUS_SHORT = 1u;        // payload shorter than its 5-byte header
+constexpr uint32_t FPC_STATUS_HEADER = 2u;       // value count or table exponents not what the launch was told
+constexpr uint32_t FPC_STATUS_MALFORMED = 4u;    // the groups run past the end of the payload
+constexpr uint32_t FPC_STATUS_TIMEOUT = 0x10u;   // the kernel's two waves lost each other (bounded wait): repeat the stream
+constexpr uint32_t FPC_STATUS_CHECK = 0x700u;    // 0x100 << c: component c of the re-encode differs from the payload (shim.hip)
+
+// One chain of a chain decoder: a component stream and where its values go.  `dst` points at the FIRST value of this component
+// inside the interleaved output, `stride` is the number of components of the output (distance between values, in elements).
+struct Fpc32ChainJob { const uint8_t* pay; uint32_t* dst; uint32_t* status; uint32_t size, n, stride, pad; };
+struct Fpc64ChainJob { const uint8_t* pay; uint64_t* dst; uint32_t* status; uint32_t size, n, stride, pad; };
+
+// latency-optimised float decoder (k_fpc32_decode.hip): one pair of waves per component stream
 // d_tables: 8 KiB of scratch per component (the predictor tables, reached through the scalar data cache)
 constexpr size_t FPC32_DECODE_TABLE_BYTES = 8192;
 int launch_fpc32_decode(const uint8_t* const d_payloads[3], const uint32_t sizes[3], int arity, uint32_t n, void* d_dst,
                         uint32_t* d_status, uint32_t* d_tables);
+// every chain of a batch in one launch: d_jobs = device table, d_scratch = FPC32_DECODE_TABLE_BYTES per chain
+int launch_fpc32_decode_batch(const Fpc32ChainJob* d_jobs, uint32_t njobs, uint32_t* d_scratch, int chains_per_group);
 
 // double-precision coder (k_fpc64.hip): one wave per component stream, 2 x 2^20-entry tables per stream in d_tables (zeroed)
 int launch_fpc64_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes, uint64_t* d_tables);
@@ -126,6 +152,9 @@ int launch_fpc64_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
 constexpr size_t FPC64_DECODE_SCRATCH_BYTES = 8192;
 int launch_fpc64_decode(const uint8_t* const d_payloads[3], const uint32_t sizes[3], int arity, uint32_t n, void* d_dst,
                         uint64_t* d_tables, uint32_t* d_status);
+// every chain of a batch in one launch: d_tables = FPC64_DECODE_CHAIN_BYTES per chain (2 x 2^20 entries, then the ring)
+constexpr size_t FPC64_DECODE_CHAIN_BYTES = 2 * ((size_t)1 << 20) * 8 + FPC64_DECODE_SCRATCH_BYTES;
+int launch_fpc64_decode_batch(const Fpc64ChainJob* d_jobs, uint32_t njobs, uint8_t* d_tables);
 
 // sort-based throughput encoder for doubles (k_fpc64_sort.hip): table lookups as stable sorts by hash
 uint32_t fpc64_sorted_threshold();

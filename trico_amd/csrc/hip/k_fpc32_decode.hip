@@ -41,13 +41,11 @@ namespace {
 constexpr int WINW = 512;                  // staging window, dwords (2 KiB): a refill must fit into the slack of the ring (8 and 32 KiB windows cost the noisy stream 2-4 ns per value)
 constexpr uint32_t BATCH_BYTES = 8 * 35;   // a batch of 8 groups needs at most this many payload bytes
 
-struct DecodeArgs
-  {
-  const uint8_t* pay[3];
-  uint32_t size[3];
-  };
+// (the descriptor of one chain, Fpc32ChainJob, is declared in common.hpp: the batch engine of shim.hip fills tables of them)
+struct ChainJobs3 { Fpc32ChainJob j[3]; };     // the single-stream launch passes its (at most three) chains by value
 
 __device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint64_t rfl64(uint64_t x) { return ((uint64_t)rfl((uint32_t)(x >> 32)) << 32) | rfl((uint32_t)x); }
 
 // sum of the residual lengths of the 3-bit codes packed in x (codes 0..4 -> 0..4 bytes, 5..7 -> 1..3 bytes)
 __device__ __forceinline__ uint32_t lens_sum(uint32_t x)
@@ -178,7 +176,14 @@ constexpr uint32_t SCRATCH_USED = SCRATCH_CONSUMED + 16;          // dwords zero
 static_assert(SCRATCH_PRODUCED * 4 == 0x1900 && SCRATCH_CONSUMED * 4 == 0x1940 && SCRATCH_USED <= SCRATCH_DWORDS, "offsets are spelled out in the chain");
 constexpr uint32_t ABORT = 0xffffffffu;       // `produced` when the parser gives up: the chain stops
 
-struct ChainEnd { uint32_t last, a2; };       // what the tail loop needs: last value, byte address of the current DFCM entry
+struct ChainEnd { uint32_t last, a2, timed_out; };   // what the tail loop needs: last value, byte address of the current DFCM entry
+
+// The two waves wait for each other by polling; neither waits forever.  A poll of the chain costs ~100 cycles (s_sleep 1 + a
+// scalar-cache hit), one of the parser ~300: both limits are seconds of no progress at all, which a healthy pair never sees
+// (the other wave publishes every few microseconds).  What it guards against: counters that went stale because the workgroup
+// was saved and restored on another compute unit (shim.hip, "the chain decoders and their self-check") - the kernel then
+// ends with status FPC_STATUS_TIMEOUT instead of spinning for ever, and the host repeats the stream.
+constexpr uint32_t SPIN_LIMIT_CHAIN = 1u << 25, SPIN_LIMIT_PARSER = 1u << 23;
 
 // The whole chain of a stream: batches 0 .. nb-1 of 64 values.  Per batch: wait until the parser has published it (scalar load
 // of `produced`), load its mask and first eight residuals, 64 values, one vector store of the 64 values straight to their
@@ -190,13 +195,14 @@ __device__ __forceinline__ ChainEnd chain4_run(const uint32_t* T2b, uint32_t nb,
   {
   const uint64_t xb = (uint64_t)(uintptr_t)(T2b + SCRATCH_X), ob = (uint64_t)(uintptr_t)out0;
   const uint32_t xlo = (uint32_t)xb, xhi = (uint32_t)(xb >> 32), olo = (uint32_t)ob, ohi = (uint32_t)(ob >> 32);
-  uint32_t last, sprev, a2a, a2b, P, t2, fwd, outv, q, h, g, kind, vt;
+  uint32_t last, sprev, a2a, a2b, P, t2, fwd, outv, q, h, g, kind, vt, spin, tmo;
   asm volatile(
     "s_mov_b64 s[84:85], 0\n s_mov_b64 s[86:87], 0\n s_mov_b64 s[88:89], 0\n s_mov_b64 s[90:91], 0\n"
     "s_mov_b64 s[92:93], 0\n s_mov_b64 s[94:95], 0\n s_mov_b64 s[96:97], 0\n s_mov_b64 s[98:99], 0\n"
     "s_mov_b64 s[52:53], 0\n s_mov_b64 s[56:57], 0\n s_mov_b32 m0, 0\n"
     "s_mov_b32 %[a2a], 0\n s_mov_b32 %[P], 0\n s_mov_b32 %[t2], 0\n s_mov_b32 %[fwd], 1\n"
     "s_mov_b32 s77, 0\n s_mov_b32 s80, %[olo]\n s_mov_b32 s81, %[ohi]\n"
+    "s_mov_b32 %[spin], 0\n s_mov_b32 %[tmo], 0\n"
     "s_cmp_lt_u32 s77, %[nb]\n"
     "s_cbranch_scc0 3f\n"
     "0:\n"
@@ -204,9 +210,19 @@ __device__ __forceinline__ ChainEnd chain4_run(const uint32_t* T2b, uint32_t nb,
     "s_waitcnt lgkmcnt(0)\n"
     "s_cmp_gt_u32 s76, s77\n"
     "s_cbranch_scc1 1f\n"
+    /* bounded wait: a parser that does not publish for SPIN_LIMIT polls (seconds) will not publish at all */
+    "s_add_u32 %[spin], %[spin], 1\n"
+    "s_cmp_lt_u32 %[spin], %[limit]\n"
+    "s_cbranch_scc0 7f\n"
     "s_sleep 1\n"
     "s_branch 0b\n"
+    "7:\n"
+    "s_mov_b32 %[tmo], 1\n"
+    "s_mov_b32 s76, -1\n"
+    "s_store_dword s76, %[T2b], 0x1940\n"            /* consumed = ABORT: the parser stops too */
+    "s_branch 3f\n"
     "1:\n"
+    "s_mov_b32 %[spin], 0\n"
     "s_cmp_eq_u32 s76, -1\n"
     "s_cbranch_scc1 3f\n"
     "s_and_b32 s76, s77, 3\n"
@@ -239,14 +255,14 @@ __device__ __forceinline__ ChainEnd chain4_run(const uint32_t* T2b, uint32_t nb,
     "s_store_dwordx4 s[96:99], %[T2b], 0x1030\n"
     "s_waitcnt lgkmcnt(0)\n"
     : [last] "=&s"(last), [sprev] "=&s"(sprev), [a2a] "=&s"(a2a), [a2b] "=&s"(a2b), [P] "=&s"(P), [t2] "=&s"(t2), [fwd] "=&s"(fwd),
-      [outv] "=&v"(outv), [q] "=&s"(q), [h] "=&s"(h), [g] "=&s"(g), [kind] "=&s"(kind), [vt] "=&v"(vt)
+      [outv] "=&v"(outv), [q] "=&s"(q), [h] "=&s"(h), [g] "=&s"(g), [kind] "=&s"(kind), [vt] "=&v"(vt), [spin] "=&s"(spin), [tmo] "=&s"(tmo)
     : [T2b] "s"(T2b), [xlo] "s"(xlo), [xhi] "s"(xhi), [olo] "s"(olo), [ohi] "s"(ohi), [voff] "v"(voff), [ostep] "s"(out_step), [nb] "s"(nb),
-      [lanem1] "v"(lanem1)
+      [lanem1] "v"(lanem1), [limit] "s"(SPIN_LIMIT_CHAIN)
     : "scc", "memory", "m0", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
       "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87",
       "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
   (void)sprev;
-  return ChainEnd{ last, a2a };
+  return ChainEnd{ last, a2a, tmo };
   }
 
 // parser wave: the 64 residuals of a batch (lane K = residual K) and the mask of its DFCM-coded values go to the ring slot with
@@ -320,42 +336,58 @@ __device__ void serial_values(const uint8_t* __restrict__ in, uint32_t len, uint
     }
   }
 
-__global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity, uint32_t n, uint32_t* __restrict__ dst,
-                                                      uint32_t* __restrict__ status, uint32_t* __restrict__ scratch)
+// LDS of one chain: the parser's staging window and the tables of the tail loop
+struct ChainLds
   {
-  __shared__ uint32_t win[WINW + 4];
-  __shared__ uint32_t T2[1024], T1[16];          // tail loop only
-  __shared__ uint32_t sh_bad, sh_q;
-  const int lane = threadIdx.x & 63;
-  const int wave = (int)rfl(threadIdx.x >> 6);
-  const int comp = blockIdx.x;
-  for (int i = threadIdx.x; i < 1024; i += 128)
-    T2[i] = 0u;
-  if (threadIdx.x < 16)
-    T1[threadIdx.x] = 0u;
-  if (threadIdx.x == 0)
+  uint32_t win[WINW + 4];
+  uint32_t T2[1024], T1[16];          // tail loop only
+  uint32_t bad, q;
+  };
+
+// One chain = two waves of a workgroup (role 0: chain, role 1: parser; `t2` = threadIdx within the pair, 0..127).  Every wave of
+// the workgroup reaches every barrier, whatever its chain looks like: a workgroup may carry several chains (CPW), and chains
+// beyond the end of the job table or with unusable headers only wait.
+__device__ __forceinline__ void decode_pair(const Fpc32ChainJob& job, bool exists, uint32_t* __restrict__ T2gw, ChainLds& L, int role, int lane)
+  {
+  const uint32_t t2 = (uint32_t)role * 64u + (uint32_t)lane;
+  for (uint32_t i = t2; i < 1024u; i += 128u)
+    L.T2[i] = 0u;
+  if (t2 < 16u)
+    L.T1[t2] = 0u;
+  if (t2 == 0u)
     {
-    sh_bad = 0u;
-    sh_q = 5u;
+    L.bad = 0u;
+    L.q = 5u;
     }
-  const uint8_t* in = args.pay[comp];
-  const uint32_t len = args.size[comp];
-  if (len < 5u)
+  const uint8_t* in = job.pay;
+  const uint32_t len = exists ? job.size : 0u;
+  const uint32_t n = job.n;
+  const int arity = (int)job.stride;
+  uint32_t* dst = job.dst;
+  uint32_t early = 0;                               // status bits known before any work
+  uint32_t e1 = 4u, e2 = 10u;
+  if (exists)
     {
-    if (threadIdx.x == 0) atomicOr(status, 1u);
-    return;
+    if (len < 5u)
+      early = FPC_STATUS_SHORT;
+    else
+      {
+      e1 = (uint32_t)(in[0] >> 4) << 1;
+      e2 = (uint32_t)(in[0] & 15) << 1;
+      const uint32_t cnt = ((uint32_t)in[1] << 24) | ((uint32_t)in[2] << 16) | ((uint32_t)in[3] << 8) | in[4];
+      if (cnt != n || e1 == 0u || e2 == 0u || e1 > 4u || e2 > 10u)
+        early = FPC_STATUS_HEADER;
+      }
     }
-  const uint32_t e1 = (uint32_t)(in[0] >> 4) << 1, e2 = (uint32_t)(in[0] & 15) << 1;
-  const uint32_t cnt = ((uint32_t)in[1] << 24) | ((uint32_t)in[2] << 16) | ((uint32_t)in[3] << 8) | in[4];
-  if (cnt != n || e1 == 0u || e2 == 0u || e1 > 4u || e2 > 10u)
-    {
-    if (threadIdx.x == 0) atomicOr(status, 2u);
-    return;
-    }
+  // (header bytes come through vector loads; what is derived from them is wave-uniform all the same)
+  early = rfl(early);
+  e1 = rfl(e1);
+  e2 = rfl(e2);
+  const bool work = exists && early == 0u;
   const bool standard = (e1 == 4u && e2 == 10u);
-  const uint32_t nb = standard ? n / 64u : 0u;
-  const uint32_t* T2g = scratch + SCRATCH_DWORDS * (uint32_t)comp;
-  if (wave == 0 && nb)
+  const uint32_t nb = (work && standard) ? n / 64u : 0u;
+  const uint32_t* T2g = T2gw;
+  if (role == 0 && nb)
     {
     // the tables start at zero (fpsc.c:219-228) and so do the counters; scalar stores of whole lines, so that every line is in
     // the scalar cache whatever it held
@@ -364,12 +396,12 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   __syncthreads();
-  ChainEnd ce = { 0u, 0u };
+  ChainEnd ce = { 0u, 0u, 0u };
   // The two waves run decoupled through a ring of RING batches in the scratch: `produced` = batches parsed (slot t % RING holds
   // batch t's residuals and mask), `consumed` = batches decoded; both counters are scalar-memory words, so the chain wave
   // never touches LDS or a VGPR-to-SGPR path.  (First version of round 2: one barrier per batch, the chain lost 2-10 % waiting
   // at it; second: LDS counters and the parser storing the values, ~400 cycles of chain time per batch.)
-  if (wave == 1 && nb)
+  if (role == 1 && nb)
     {
     // ---- parser: window over the payload, in units of aligned dwords of the underlying buffer --------------------------
     const uint32_t al = (uint32_t)((uintptr_t)in & 3u);
@@ -378,6 +410,7 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
     const uint32_t ndw = (total_q + 3u) >> 2;
     uint32_t wd = 0;                                     // first dword of the window
     uint32_t q = 5u + al;                                // read cursor, aligned-byte coordinates
+    uint32_t* win = L.win;
     auto refill = [&](uint32_t from_q)
       {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -389,14 +422,24 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
     refill(q);
     uint32_t t = 0;
     uint32_t zero_slots = 0;                             // ring slots whose 64 residuals are all zero
-    bool failed = false;
+    uint32_t failed = 0;                                 // 1: malformed payload, 2: the chain stopped answering
+    uint32_t spins = 0;
     while (t < nb)
       {
-      if (t >= counter_load(T2g, SCRATCH_CONSUMED) + RING)
+      const uint32_t cons = counter_load(T2g, SCRATCH_CONSUMED);
+      if (cons == ABORT)                                 // the chain gave up waiting (it reports the timeout itself)
+        break;
+      if (t >= cons + RING)
         {
+        if (++spins > SPIN_LIMIT_PARSER)
+          {
+          failed = 2u;
+          break;
+          }
         __builtin_amdgcn_s_sleep(4);
         continue;
         }
+      spins = 0;
       if (q + BATCH_BYTES + 8u > 4u * (wd + (uint32_t)WINW))
         refill(q);
       // ---- positions of the 8 groups: scalar walk over the headers -----------------------------------
@@ -417,7 +460,7 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
       const uint32_t qend = 4u * wd + lq;
       if (qend > total_q)
         {
-        failed = true;
+        failed = 1u;
         break;
         }
       q = qend;
@@ -447,44 +490,98 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
       counter_store(T2g, SCRATCH_PRODUCED, ABORT);
     if (lane == 0)
       {
-      sh_q = q - al;
+      L.q = q - al;
       if (failed)
-        sh_bad = 1u;
+        atomicOr(&L.bad, failed);
       }
     }
-  else if (wave == 0 && nb)
+  else if (role == 0 && nb)
     {
     // the chain owns its SIMD's issue slots whenever it can issue: other kernels' waves (the sweeps of the LZ4 decoder, other
     // archives) may share the CU
     __builtin_amdgcn_s_setprio(3);
-    ce = chain4_run(T2g, nb, dst + comp, 4u * (uint32_t)lane * (uint32_t)arity, 256u * (uint32_t)arity, (uint32_t)lane - 1u);
+    ce = chain4_run(T2g, nb, dst, 4u * (uint32_t)lane * (uint32_t)arity, 256u * (uint32_t)arity, (uint32_t)lane - 1u);
+    __builtin_amdgcn_s_setprio(0);
+    if (ce.timed_out && lane == 0)
+      atomicOr(&L.bad, 2u);
     }
   __syncthreads();
-  bool bad = sh_bad != 0u;
   const uint32_t i0 = 64u * nb;
   if (nb)
     {
     // no dirty line of the scalar cache may outlive the scratch buffer; the tail loop below works on LDS copies of the tables
-    if (wave == 0)
+    if (role == 0)
       asm volatile("s_dcache_wb\n s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (i0 < n && !bad)
-      {
-      for (int i = threadIdx.x; i < 1024; i += 128)
-        T2[i] = __builtin_nontemporal_load(T2g + i);
-      if (threadIdx.x < 16)
-        T1[threadIdx.x] = __builtin_nontemporal_load(T2g + SCRATCH_T1 + threadIdx.x);
-      }
-    __syncthreads();
     }
-  if (!bad && i0 < n && threadIdx.x == 0)
+  __syncthreads();
+  bool bad = L.bad != 0u;
+  if (nb && i0 < n && !bad)
+    {
+    for (uint32_t i = t2; i < 1024u; i += 128u)
+      L.T2[i] = __builtin_nontemporal_load(T2g + i);
+    if (t2 < 16u)
+      L.T1[t2] = __builtin_nontemporal_load(T2g + SCRATCH_T1 + t2);
+    }
+  __syncthreads();
+  uint32_t st = early | ((L.bad & 1u) ? FPC_STATUS_MALFORMED : 0u) | ((L.bad & 2u) ? FPC_STATUS_TIMEOUT : 0u);
+  if (work && !bad && i0 < n && t2 == 0u)
     {
     // tail of the stream (fewer than 64 values, fpsc.c:329-414), or a stream with smaller tables than the API's
-    uint32_t pos = sh_q, h1 = ce.last >> 28, h2 = ce.a2 >> 2, last = ce.last;
-    serial_values(in, len, pos, i0, n, e1, e2, h1, h2, last, T1, T2, dst, arity, comp, bad);
+    uint32_t pos = L.q, h1 = ce.last >> 28, h2 = ce.a2 >> 2, last = ce.last;
+    bool tail_bad = false;
+    serial_values(in, len, pos, i0, n, e1, e2, h1, h2, last, L.T1, L.T2, dst, arity, 0, tail_bad);
+    if (tail_bad)
+      st |= FPC_STATUS_MALFORMED;
     }
-  if (bad && lane == 0)
-    atomicOr(status, 4u);
+  if (exists && st != 0u && t2 == 0u)
+    atomicOr(job.status, st);
+  }
+
+// chains per workgroup: waves 0 .. CPW-1 run the chains (SIMDs 0 .. CPW-1 when the dispatcher places a workgroup's waves round
+// robin), waves CPW .. 2 CPW-1 the parsers
+template <int CPW>
+__device__ __forceinline__ void decode_group(const Fpc32ChainJob* __restrict__ jobs, uint32_t njobs, uint32_t first, uint32_t* __restrict__ scratch)
+  {
+  __shared__ ChainLds lds[CPW];
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)rfl(threadIdx.x >> 6);
+  const int role = wave >= CPW ? 1 : 0;
+  const int slot = wave - role * CPW;
+  const uint32_t id = first + (uint32_t)slot;
+  const bool exists = id < njobs;
+  // everything about the chain is wave-uniform, and the scalar code needs it in SGPRs
+  const Fpc32ChainJob* jp = jobs + (exists ? id : 0u);
+  Fpc32ChainJob job;
+  job.pay = (const uint8_t*)rfl64((uint64_t)(uintptr_t)jp->pay);
+  job.dst = (uint32_t*)rfl64((uint64_t)(uintptr_t)jp->dst);
+  job.status = (uint32_t*)rfl64((uint64_t)(uintptr_t)jp->status);
+  job.size = rfl(jp->size);
+  job.n = rfl(jp->n);
+  job.stride = rfl(jp->stride);
+  job.pad = 0u;
+  uint32_t* sc = (uint32_t*)rfl64((uint64_t)(uintptr_t)(scratch + (size_t)SCRATCH_DWORDS * id));
+  decode_pair(job, exists, sc, lds[slot], role, lane);
+  }
+
+__global__ void __launch_bounds__(128) k_fpc32_decode(ChainJobs3 args, uint32_t njobs, uint32_t* __restrict__ scratch)
+  {
+  decode_group<1>(args.j, njobs, blockIdx.x, scratch);
+  }
+
+template <int CPW>
+__global__ void __launch_bounds__(128 * CPW) k_fpc32_decode_batch(const Fpc32ChainJob* __restrict__ jobs, uint32_t njobs, uint32_t* __restrict__ scratch)
+  {
+  decode_group<CPW>(jobs, njobs, blockIdx.x * (uint32_t)CPW, scratch);
+  }
+
+// One chain per CU: the chain wave needs its SIMD's issue slots and its CU's scalar cache; the workgroup asks for more than
+// half of the CU's LDS (it uses a fraction of it) so that no second workgroup of this kernel can be placed beside it.
+constexpr size_t CLAIM = 88u << 10;
+
+template <typename K>
+bool claim_lds(K kernel)
+  {
+  return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLAIM) == hipSuccess;
   }
 
 } // namespace
@@ -492,19 +589,37 @@ __global__ void __launch_bounds__(128) k_fpc32_decode(DecodeArgs args, int arity
 int launch_fpc32_decode(const uint8_t* const d_payloads[3], const uint32_t sizes[3], int arity, uint32_t n, void* d_dst,
                         uint32_t* d_status, uint32_t* d_scratch)
   {
-  DecodeArgs a;
+  ChainJobs3 a;
   for (int c = 0; c < 3; ++c)
-    {
-    a.pay[c] = c < arity ? d_payloads[c] : nullptr;
-    a.size[c] = c < arity ? sizes[c] : 0;
-    }
-  // One chain per CU: the chain wave needs its SIMD's issue slots and its CU's scalar cache; the workgroup asks for more than
-  // half of the CU's LDS (it uses 14 KB of it) so that no second workgroup of this kernel can be placed beside it.
-  constexpr size_t CLAIM = 88u << 10;
-  static const bool claimed = hipFuncSetAttribute((const void*)k_fpc32_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLAIM) == hipSuccess;
-  hipLaunchKernelGGL(k_fpc32_decode, dim3(arity), dim3(128), claimed ? CLAIM : 0, current_stream(), a, arity, n, (uint32_t*)d_dst, d_status,
-                     d_scratch);
+    a.j[c] = Fpc32ChainJob{ c < arity ? d_payloads[c] : nullptr, (uint32_t*)d_dst + c, d_status, c < arity ? sizes[c] : 0u, n, (uint32_t)arity, 0u };
+  static const bool claimed = claim_lds(k_fpc32_decode);
+  hipLaunchKernelGGL(k_fpc32_decode, dim3(arity), dim3(128), claimed ? CLAIM : 0, current_stream(), a, (uint32_t)arity, d_scratch);
   return hip_ok(hipGetLastError(), "k_fpc32_decode") ? 1 : 0;
+  }
+
+// All chains of a batch in ONE launch (`d_jobs`: device table of njobs descriptors, `d_scratch`: FPC32_DECODE_TABLE_BYTES per chain):
+// throughput no longer depends on how many hardware queues the process has.  chains_per_group 1, 2 or 4.
+int launch_fpc32_decode_batch(const Fpc32ChainJob* d_jobs, uint32_t njobs, uint32_t* d_scratch, int chains_per_group)
+  {
+  if (njobs == 0)
+    return 1;
+  hipStream_t st = current_stream();
+  if (chains_per_group >= 4)
+    {
+    static const bool claimed = claim_lds(k_fpc32_decode_batch<4>);
+    hipLaunchKernelGGL(k_fpc32_decode_batch<4>, dim3((njobs + 3u) / 4u), dim3(512), claimed ? CLAIM : 0, st, d_jobs, njobs, d_scratch);
+    }
+  else if (chains_per_group >= 2)
+    {
+    static const bool claimed = claim_lds(k_fpc32_decode_batch<2>);
+    hipLaunchKernelGGL(k_fpc32_decode_batch<2>, dim3((njobs + 1u) / 2u), dim3(256), claimed ? CLAIM : 0, st, d_jobs, njobs, d_scratch);
+    }
+  else
+    {
+    static const bool claimed = claim_lds(k_fpc32_decode_batch<1>);
+    hipLaunchKernelGGL(k_fpc32_decode_batch<1>, dim3(njobs), dim3(128), claimed ? CLAIM : 0, st, d_jobs, njobs, d_scratch);
+    }
+  return hip_ok(hipGetLastError(), "k_fpc32_decode_batch") ? 1 : 0;
   }
 
 } // namespace trico

@@ -367,18 +367,22 @@ __device__ __forceinline__ void counter_store64(const uint32_t* base, uint32_t d
 // published it, load its mask and first eight residuals, request the entry of its first value (nothing of the batch before is
 // still in flight then), 64 values, two vector stores of the 64 values straight to their place in the interleaved output,
 // publish `consumed`.
-__device__ __forceinline__ void chain64_run(const u64* T1, const u64* T2, const uint32_t* ring, uint32_t nb, uint64_t last_mask, u64* out0,
+constexpr uint32_t SPIN64_LIMIT_CHAIN = 1u << 25, SPIN64_LIMIT_PARSER = 1u << 23;
+
+// returns 1 if the wait for the parser ran into its bound
+__device__ __forceinline__ uint32_t chain64_run(const u64* T1, const u64* T2, const uint32_t* ring, uint32_t nb, uint64_t last_mask, u64* out0,
                                             uint32_t voff, uint32_t out_step)
   {
   const uint64_t xb = (uint64_t)(uintptr_t)ring, ob = (uint64_t)(uintptr_t)out0;
   const uint32_t xlo = (uint32_t)xb, xhi = (uint32_t)(xb >> 32), olo = (uint32_t)ob, ohi = (uint32_t)(ob >> 32);
-  uint32_t vlo, vhi, offo;
+  uint32_t vlo, vhi, offo, spin, tmo;
   uint64_t dm;
   asm volatile(
     "s_mov_b64 s[36:37], 0\n s_mov_b64 s[38:39], 0\n s_mov_b64 s[40:41], 0\n s_mov_b64 s[42:43], 0\n"
     "s_mov_b64 s[44:45], 0\n s_mov_b64 s[46:47], 0\n"
     "s_mov_b32 s52, 0\n s_mov_b32 s53, 0\n s_mov_b32 s54, 0\n s_mov_b32 s55, 0\n s_mov_b32 s56, 0\n"
     "s_mov_b32 s97, 0\n s_mov_b32 s60, %[olo]\n s_mov_b32 s61, %[ohi]\n"
+    "s_mov_b32 %[spin], 0\n s_mov_b32 %[tmo], 0\n"
     "s_cmp_lt_u32 s97, %[nb]\n"
     "s_cbranch_scc0 3f\n"
     "0:\n"
@@ -386,9 +390,19 @@ __device__ __forceinline__ void chain64_run(const u64* T1, const u64* T2, const 
     "s_waitcnt lgkmcnt(0)\n"
     "s_cmp_gt_u32 s96, s97\n"
     "s_cbranch_scc1 1f\n"
+    /* bounded wait (see SPIN_LIMIT_CHAIN in k_fpc32_decode.hip): seconds without a published batch = the waves lost each other */
+    "s_add_u32 %[spin], %[spin], 1\n"
+    "s_cmp_lt_u32 %[spin], %[limit]\n"
+    "s_cbranch_scc0 7f\n"
     "s_sleep 1\n"
     "s_branch 0b\n"
+    "7:\n"
+    "s_mov_b32 %[tmo], 1\n"
+    "s_mov_b32 s96, -1\n"
+    "s_store_dword s96, %[ringp], 0x1040\n"          /* consumed = ABORT: the parser stops too */
+    "s_branch 3f\n"
     "1:\n"
+    "s_mov_b32 %[spin], 0\n"
     "s_cmp_eq_u32 s96, -1\n"
     "s_cbranch_scc1 3f\n"
     "s_and_b32 s96, s97, 3\n"
@@ -419,42 +433,48 @@ __device__ __forceinline__ void chain64_run(const u64* T1, const u64* T2, const 
     "s_cbranch_scc1 0b\n"
     "3:\n"
     "s_waitcnt lgkmcnt(0)\n"
-    : [vlo] "=&v"(vlo), [vhi] "=&v"(vhi), [offo] "=&s"(offo), [dm] "=&s"(dm)
+    : [vlo] "=&v"(vlo), [vhi] "=&v"(vhi), [offo] "=&s"(offo), [dm] "=&s"(dm), [spin] "=&s"(spin), [tmo] "=&s"(tmo)
     : [T1] "s"(T1), [T2] "s"(T2), [ringp] "s"(ring), [xlo] "s"(xlo), [xhi] "s"(xhi), [olo] "s"(olo), [ohi] "s"(ohi), [voff] "v"(voff),
-      [ostep] "s"(out_step), [nb] "s"(nb), [lastm] "s"(last_mask)
+      [ostep] "s"(out_step), [nb] "s"(nb), [lastm] "s"(last_mask), [limit] "s"(SPIN64_LIMIT_CHAIN)
     : "scc", "memory", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
       "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
       "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",
       "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+  return tmo;
   }
 
-__global__ void __launch_bounds__(128) k_fpc64_decode(DecodeArgs args, int arity, uint32_t n, u64* __restrict__ dst, u64* __restrict__ tables,
-                                                      uint32_t* __restrict__ scratch, uint32_t* __restrict__ status)
+__device__ __forceinline__ uint64_t rfl64(uint64_t x) { return ((uint64_t)rfl((uint32_t)(x >> 32)) << 32) | rfl((uint32_t)x); }
+
+// one chain = one workgroup of two waves; `tables`: 2 x TSIZE entries of this chain, `scratch`: its ring and counters
+__device__ __forceinline__ void decode64_pair(const Fpc64ChainJob& job, u64* __restrict__ tables, uint32_t* __restrict__ scratch)
   {
   __shared__ uint32_t win[WINW + 8];
   __shared__ uint32_t sh_bad;
   const int lane = threadIdx.x & 63;
   const int wave = (int)rfl(threadIdx.x >> 6);
-  const int comp = blockIdx.x;
-  const uint8_t* in = args.pay[comp];
+  const uint8_t* in = job.pay;
+  const uint32_t n = job.n;
+  const int arity = (int)job.stride;
+  u64* dst = (u64*)job.dst;
+  uint32_t* status = job.status;
   if (threadIdx.x == 0)
     sh_bad = 0u;
-  const uint32_t len = args.size[comp];
+  const uint32_t len = job.size;
   if (len < 5u)
     {
-    if (threadIdx.x == 0) atomicOr(status, 1u);
+    if (threadIdx.x == 0) atomicOr(status, FPC_STATUS_SHORT);
     return;
     }
-  const uint32_t e1 = (uint32_t)(in[0] >> 4) << 1, e2 = (uint32_t)(in[0] & 15) << 1;
-  const uint32_t cnt = ((uint32_t)in[1] << 24) | ((uint32_t)in[2] << 16) | ((uint32_t)in[3] << 8) | in[4];
+  const uint32_t e1 = rfl((uint32_t)(in[0] >> 4) << 1), e2 = rfl((uint32_t)(in[0] & 15) << 1);
+  const uint32_t cnt = rfl(((uint32_t)in[1] << 24) | ((uint32_t)in[2] << 16) | ((uint32_t)in[3] << 8) | in[4]);
   if (cnt != n || e1 != E || e2 != E)                                    // other table shapes: k_serial.hip (shim.hip routes them)
     {
-    if (threadIdx.x == 0) atomicOr(status, 2u);
+    if (threadIdx.x == 0) atomicOr(status, FPC_STATUS_HEADER);
     return;
     }
-  const u64* T1 = tables + (size_t)comp * 2 * TSIZE;
+  const u64* T1 = tables;
   const u64* T2 = T1 + TSIZE;
-  const uint32_t* ring = scratch + SCR64_DWORDS * (uint32_t)comp;         // RING64 slots, then the two counters
+  const uint32_t* ring = scratch;                                          // RING64 slots, then the two counters
   const uint32_t nb = (n + 63u) / 64u;                                     // the last batch may be partial
   if (wave == 0)
     {
@@ -483,14 +503,24 @@ __global__ void __launch_bounds__(128) k_fpc64_decode(DecodeArgs args, int arity
     refill(q);
     const uint8_t* wb = (const uint8_t*)win;
     uint32_t t = 0;
-    bool failed = false;
+    uint32_t failed = 0;                                 // 1: malformed payload, 2: the chain stopped answering
+    uint32_t spins = 0;
     while (t < nb)
       {
-      if (t >= counter_load64(ring, SCR64_CONSUMED) + RING64)
+      const uint32_t cons = counter_load64(ring, SCR64_CONSUMED);
+      if (cons == ABORT64)                               // the chain gave up waiting (it reports the timeout itself)
+        break;
+      if (t >= cons + RING64)
         {
+        if (++spins > SPIN64_LIMIT_PARSER)
+          {
+          failed = 2u;
+          break;
+          }
         __builtin_amdgcn_s_sleep(4);
         continue;
         }
+      spins = 0;
       if (q + BATCH_BYTES + 16u > 4u * (wd + (uint32_t)WINW))
         refill(q);
       const uint32_t i0 = 64u * t;
@@ -512,7 +542,7 @@ __global__ void __launch_bounds__(128) k_fpc64_decode(DecodeArgs args, int arity
       const uint32_t qend = 4u * wd + lq;
       if (qend > total_q)
         {
-        failed = true;
+        failed = 1u;
         break;
         }
       q = qend;
@@ -533,7 +563,7 @@ __global__ void __launch_bounds__(128) k_fpc64_decode(DecodeArgs args, int arity
       {
       counter_store64(ring, SCR64_PRODUCED, ABORT64);
       if (lane == 0)
-        sh_bad = 1u;
+        atomicOr(&sh_bad, failed);
       }
     }
   else
@@ -551,13 +581,46 @@ __global__ void __launch_bounds__(128) k_fpc64_decode(DecodeArgs args, int arity
     __builtin_amdgcn_s_setprio(3);                        // the chain owns its SIMD's issue slots whenever it can issue
     const uint32_t nlast = n - 64u * (nb - 1u);           // values of the last batch, 1 .. 64
     const uint64_t last_mask = nlast >= 64u ? ~0ull : (1ull << nlast) - 1ull;
-    chain64_run(T1, T2, ring, nb, last_mask, dst + comp, 8u * (uint32_t)lane * (uint32_t)arity, 512u * (uint32_t)arity);
+    const uint32_t tmo = chain64_run(T1, T2, ring, nb, last_mask, dst, 8u * (uint32_t)lane * (uint32_t)arity, 512u * (uint32_t)arity);
+    __builtin_amdgcn_s_setprio(0);
+    if (tmo && lane == 0)
+      atomicOr(&sh_bad, 2u);
     // no dirty line of the scalar cache may outlive the table buffer
     asm volatile("s_dcache_wb\n s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   __syncthreads();
   if (sh_bad && threadIdx.x == 0)
-    atomicOr(status, 4u);
+    atomicOr(status, ((sh_bad & 1u) ? FPC_STATUS_MALFORMED : 0u) | ((sh_bad & 2u) ? FPC_STATUS_TIMEOUT : 0u));
+  }
+
+struct ChainJobs3d { Fpc64ChainJob j[3]; };
+
+__device__ __forceinline__ Fpc64ChainJob uniform_job(const Fpc64ChainJob* jp)
+  {
+  Fpc64ChainJob job;
+  job.pay = (const uint8_t*)rfl64((uint64_t)(uintptr_t)jp->pay);
+  job.dst = (uint64_t*)rfl64((uint64_t)(uintptr_t)jp->dst);
+  job.status = (uint32_t*)rfl64((uint64_t)(uintptr_t)jp->status);
+  job.size = rfl(jp->size);
+  job.n = rfl(jp->n);
+  job.stride = rfl(jp->stride);
+  job.pad = 0u;
+  return job;
+  }
+
+// single stream: tables of component c at c * 2 * TSIZE entries, the rings behind all tables (launch_fpc64_decode)
+__global__ void __launch_bounds__(128) k_fpc64_decode(ChainJobs3d args, u64* __restrict__ tables, uint32_t* __restrict__ scratch)
+  {
+  const uint32_t c = blockIdx.x;
+  decode64_pair(uniform_job(&args.j[c]), tables + (size_t)c * 2 * TSIZE, scratch + SCR64_DWORDS * c);
+  }
+
+// batch: FPC64_DECODE_CHAIN_BYTES per chain = its two tables, then its ring
+__global__ void __launch_bounds__(128) k_fpc64_decode_batch(const Fpc64ChainJob* __restrict__ jobs, uint8_t* __restrict__ chain_mem)
+  {
+  const uint32_t c = blockIdx.x;
+  uint8_t* mem = (uint8_t*)rfl64((uint64_t)(uintptr_t)(chain_mem + (size_t)c * FPC64_DECODE_CHAIN_BYTES));
+  decode64_pair(uniform_job(jobs + c), (u64*)mem, (uint32_t*)(mem + 2 * (size_t)TSIZE * 8));
   }
 
 } // namespace
@@ -569,23 +632,30 @@ int launch_fpc64_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
   return hip_ok(hipGetLastError(), "k_fpc64_encode") ? 1 : 0;
   }
 
+// one chain per CU (see launch_fpc32_decode): the workgroup claims more than half of the CU's LDS
+constexpr size_t CLAIM64 = 72u << 10;
+
 int launch_fpc64_decode(const uint8_t* const d_payloads[3], const uint32_t sizes[3], int arity, uint32_t n, void* d_dst,
                         uint64_t* d_tables, uint32_t* d_status)
   {
-  DecodeArgs a;
+  ChainJobs3d a;
   for (int c = 0; c < 3; ++c)
-    {
-    a.pay[c] = c < arity ? d_payloads[c] : nullptr;
-    a.size[c] = c < arity ? sizes[c] : 0;
-    }
-  // one chain per CU (see launch_fpc32_decode): the workgroup claims more than half of the CU's LDS
-  constexpr size_t CLAIM = 72u << 10;
-  static const bool claimed = hipFuncSetAttribute((const void*)k_fpc64_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLAIM) == hipSuccess;
+    a.j[c] = Fpc64ChainJob{ c < arity ? d_payloads[c] : nullptr, (uint64_t*)d_dst + c, d_status, c < arity ? sizes[c] : 0u, n, (uint32_t)arity, 0u };
+  static const bool claimed = hipFuncSetAttribute((const void*)k_fpc64_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLAIM64) == hipSuccess;
   // the rings of the two waves live behind the tables: FPC64_DECODE_SCRATCH_BYTES per component
   uint32_t* scratch = (uint32_t*)(d_tables + (size_t)arity * 2 * TSIZE);
-  hipLaunchKernelGGL(k_fpc64_decode, dim3(arity), dim3(128), claimed ? CLAIM : 0, current_stream(), a, arity, n, (u64*)d_dst, (u64*)d_tables,
-                     scratch, d_status);
+  hipLaunchKernelGGL(k_fpc64_decode, dim3(arity), dim3(128), claimed ? CLAIM64 : 0, current_stream(), a, (u64*)d_tables, scratch);
   return hip_ok(hipGetLastError(), "k_fpc64_decode") ? 1 : 0;
+  }
+
+int launch_fpc64_decode_batch(const Fpc64ChainJob* d_jobs, uint32_t njobs, uint8_t* d_tables)
+  {
+  if (njobs == 0)
+    return 1;
+  static_assert(FPC64_DECODE_CHAIN_BYTES == 2 * (size_t)TSIZE * 8 + SCR64_DWORDS * 4, "chain memory layout");
+  static const bool claimed = hipFuncSetAttribute((const void*)k_fpc64_decode_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLAIM64) == hipSuccess;
+  hipLaunchKernelGGL(k_fpc64_decode_batch, dim3(njobs), dim3(128), claimed ? CLAIM64 : 0, current_stream(), d_jobs, d_tables);
+  return hip_ok(hipGetLastError(), "k_fpc64_decode_batch") ? 1 : 0;
   }
 
 } // namespace trico

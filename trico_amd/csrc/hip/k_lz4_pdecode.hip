@@ -20,7 +20,13 @@
 //     log2(longest chain) rounds without any ordering between threads (k_pd_jump), and a gather produces the plane
 //     (k_pd_gather).
 // Nothing waits on the host: the jump rounds are launched up front and return at once when the previous round changed
-// nothing.  Traffic: ~4 B written + 12 B per round and output byte; planes are decoded one after the other in one workspace.
+// nothing.  Traffic: ~4 B written + 12 B per round and output byte.
+// Round 3: (1) a match that overlaps itself (offset < length: LZ4's way of writing a periodic run, lz4.c:1840-1870) points every
+// byte at the FIRST period, src = op - off + (k mod off), instead of at the byte `off` before it: the run is resolved in one
+// round whatever its length (the two upper byte planes of a grid's indices are ONE run of 300 MB each: 28 rounds before).
+// (2) All planes of a stream go through every phase together (grid.y = plane, one workspace per plane): the serial phases
+// (k_pd_chain: one wave per plane) overlap instead of adding up, and a round of jumps is one launch.  (3) The last workgroup
+// of a jump round closes it (k_pd_round_end is gone).
 #include "common.hpp"
 #include <stdlib.h>
 
@@ -39,8 +45,17 @@ constexpr uint32_t PD_FINAL = 0x80000000u;    // src word: low 31 bits index the
 constexpr int PD_ROUNDS = 31;                 // chains are shorter than 2^31
 
 struct Tile { uint32_t first, exit, nseq, pad; unsigned long long obytes; };
-struct Job { uint32_t op, len, kind, a; };    // kind 0: literals from input position a; 1: match at offset a
-struct Ctl { uint32_t error, njobs, changed, done, total_seq, pad[3]; };
+struct Job { uint32_t op, len, a, b; };       // b == PD_NONE: literals from input position a; else match: offset a, its first period starts at output b
+struct Ctl { uint32_t error, njobs, changed, done, total_seq, arrived, pad[2]; };
+
+// One plane of a stream and its workspace
+struct PdPlane
+  {
+  const uint8_t* in; uint8_t* out;
+  Tile* tiles; Tile* tiles0; uint32_t* onpath; uint32_t* out_base; Ctl* ctl; Job* jobs; uint32_t* src;
+  uint32_t clen, nt;
+  };
+struct PdPlanes { PdPlane p[8]; };
 
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
@@ -207,23 +222,33 @@ __device__ __forceinline__ void walk_tile(const Bytes& b, uint32_t start, uint32
     }
   }
 
-__global__ void __launch_bounds__(64) k_pd_tiles(const uint8_t* __restrict__ in, uint32_t clen, uint32_t ntiles, Tile* __restrict__ tiles,
-                                                 uint32_t* __restrict__ onpath, const Tile* __restrict__ prev)
+__global__ void __launch_bounds__(64) k_pd_tiles(PdPlanes P, int second)
   {
   __shared__ uint32_t lds[PD_STAGE / 4 + 2];
   const int lane = threadIdx.x;
+  const PdPlane& pl = P.p[blockIdx.y];
   const uint32_t t = blockIdx.x;
+  if (t >= pl.nt)
+    return;
+  const uint8_t* in = pl.in;
+  const uint32_t clen = pl.clen;
   const uint32_t lo = t * PD_TILE, hi = lo + PD_TILE;
   uint32_t start = lo > PD_LEAD ? lo - PD_LEAD : 0u;
-  if (prev)
+  Tile* dst = second ? pl.tiles : pl.tiles0;
+  if (second)
     {
     // second round: where the predecessor's walk of the first round left its tile.  Even if that walk started at a wrong
     // byte, it has normally fallen into step with the real chain within its 8 KiB, so this is a real token.
-    if (t == 0)
+    const uint32_t e = t ? pl.tiles0[t - 1].exit : PD_NONE;
+    if (t == 0 || e < lo || e >= hi)
+      {
+      if (lane == 0)
+        {
+        dst[t] = pl.tiles0[t];                        // nothing (known) starts here: keep the record of the first round
+        pl.onpath[t] = 0u;
+        }
       return;
-    const uint32_t e = prev[t - 1].exit;
-    if (e < lo || e >= hi)
-      return;                                       // nothing (known) starts here: keep the record of the first round
+      }
     start = e;
     }
   Bytes b;
@@ -232,17 +257,21 @@ __global__ void __launch_bounds__(64) k_pd_tiles(const uint8_t* __restrict__ in,
   walk_tile(b, start, lo, hi, r, lane);           // every lane walks the same chain (uniform control flow, LDS broadcast reads)
   if (lane == 0)
     {
-    tiles[t] = r;
-    onpath[t] = 0u;
+    dst[t] = r;
+    pl.onpath[t] = 0u;
     }
-  (void)ntiles;
   }
 
 // One wave follows the chain of tiles from position 0.  seq_base / out_base: sequences and output bytes before the tile.
-__global__ void __launch_bounds__(64) k_pd_chain(const uint8_t* __restrict__ in, uint32_t clen, uint32_t n, uint32_t ntiles, Tile* __restrict__ tiles,
-                                                 uint32_t* __restrict__ onpath, uint32_t* __restrict__ out_base, Ctl* __restrict__ ctl,
-                                                 uint32_t* __restrict__ status)
+__global__ void __launch_bounds__(64) k_pd_chain(PdPlanes P, uint32_t n, uint32_t* __restrict__ status)
   {
+  const PdPlane& pl = P.p[blockIdx.x];
+  const uint8_t* in = pl.in;
+  const uint32_t clen = pl.clen, ntiles = pl.nt;
+  Tile* tiles = pl.tiles;
+  uint32_t* onpath = pl.onpath;
+  uint32_t* out_base = pl.out_base;
+  Ctl* ctl = pl.ctl;
   constexpr uint32_t WIN = 512;                   // tiles whose records are staged in LDS at a time
   __shared__ Tile win[WIN];
   __shared__ uint32_t lds[PD_STAGE / 4 + 2];
@@ -302,14 +331,22 @@ __global__ void __launch_bounds__(64) k_pd_chain(const uint8_t* __restrict__ in,
   }
 
 // one wave per tile on the chain: source words of its output bytes
-__global__ void __launch_bounds__(64) k_pd_fill(const uint8_t* __restrict__ in, uint32_t clen, uint32_t n, const Tile* __restrict__ tiles,
-                                                const uint32_t* __restrict__ onpath, const uint32_t* __restrict__ out_base,
-                                                uint32_t* __restrict__ src, Job* __restrict__ jobs, uint32_t job_cap, Ctl* __restrict__ ctl,
-                                                uint32_t* __restrict__ status)
+__global__ void __launch_bounds__(64) k_pd_fill(PdPlanes P, uint32_t n, uint32_t job_cap, uint32_t* __restrict__ status)
   {
   __shared__ uint32_t lds[PD_STAGE / 4 + 2];
   const int lane = threadIdx.x;
+  const PdPlane& pl = P.p[blockIdx.y];
   const uint32_t t = blockIdx.x;
+  if (t >= pl.nt)
+    return;
+  const uint8_t* in = pl.in;
+  const uint32_t clen = pl.clen;
+  const Tile* tiles = pl.tiles;
+  const uint32_t* onpath = pl.onpath;
+  const uint32_t* out_base = pl.out_base;
+  uint32_t* src = pl.src;
+  Job* jobs = pl.jobs;
+  Ctl* ctl = pl.ctl;
   if (ctl->error || !onpath[t])
     return;
   const Tile r = tiles[t];
@@ -336,7 +373,7 @@ __global__ void __launch_bounds__(64) k_pd_fill(const uint8_t* __restrict__ in, 
       j0 = uni(j0);
       for (uint32_t k = (uint32_t)lane; k < np; k += 64u)
         if (j0 + k < job_cap)
-          jobs[j0 + k] = Job{ op + k * PD_PIECE, (k + 1u == np) ? s.lit_len - k * PD_PIECE : PD_PIECE, 0u, s.lit_pos + k * PD_PIECE };
+          jobs[j0 + k] = Job{ op + k * PD_PIECE, (k + 1u == np) ? s.lit_len - k * PD_PIECE : PD_PIECE, s.lit_pos + k * PD_PIECE, PD_NONE };
       }
     else
       for (uint32_t k = (uint32_t)lane; k < s.lit_len; k += 64u)
@@ -355,11 +392,15 @@ __global__ void __launch_bounds__(64) k_pd_fill(const uint8_t* __restrict__ in, 
       j0 = uni(j0);
       for (uint32_t k = (uint32_t)lane; k < np; k += 64u)
         if (j0 + k < job_cap)
-          jobs[j0 + k] = Job{ op + k * PD_PIECE, (k + 1u == np) ? s.mlen - k * PD_PIECE : PD_PIECE, 1u, s.off };
+          jobs[j0 + k] = Job{ op + k * PD_PIECE, (k + 1u == np) ? s.mlen - k * PD_PIECE : PD_PIECE, s.off, op - s.off };
       }
-    else
+    else if (s.mlen <= s.off)
       for (uint32_t k = (uint32_t)lane; k < s.mlen; k += 64u)
         src[op + k] = op + k - s.off;
+    else
+      // the match overlaps itself: a periodic run.  Every byte points at the first period (which lies before the match).
+      for (uint32_t k = (uint32_t)lane; k < s.mlen; k += 64u)
+        src[op + k] = op - s.off + k % s.off;
     op += s.mlen;
     p = s.next;
     }
@@ -371,10 +412,12 @@ __global__ void __launch_bounds__(64) k_pd_fill(const uint8_t* __restrict__ in, 
   }
 
 // long runs: whole workgroups, grid-stride over the job list
-__global__ void __launch_bounds__(256) k_pd_jobs(const Job* __restrict__ jobs, uint32_t job_cap, uint32_t* __restrict__ src, Ctl* __restrict__ ctl,
-                                                 uint32_t* __restrict__ status)
+__global__ void __launch_bounds__(256) k_pd_jobs(PdPlanes P, uint32_t job_cap, uint32_t* __restrict__ status)
   {
-  if (ctl->error)
+  const PdPlane& pl = P.p[blockIdx.y];
+  Ctl* ctl = pl.ctl;
+  uint32_t* src = pl.src;
+  if (pl.clen == 0u || ctl->error)
     return;
   const uint32_t nj = ctl->njobs;
   if (nj > job_cap)
@@ -384,20 +427,40 @@ __global__ void __launch_bounds__(256) k_pd_jobs(const Job* __restrict__ jobs, u
     }
   for (uint32_t j = blockIdx.x; j < nj; j += gridDim.x)
     {
-    const Job q = jobs[j];
-    if (q.kind == 0u)
+    const Job q = pl.jobs[j];
+    if (q.b == PD_NONE)
       for (uint32_t k = threadIdx.x; k < q.len; k += 256u)
         src[q.op + k] = PD_FINAL | (q.a + k);
     else
-      for (uint32_t k = threadIdx.x; k < q.len; k += 256u)
-        src[q.op + k] = q.op + k - q.a;
+      {
+      // piece of a match that starts at output b + a: byte i of the match comes from b + (i mod a), the first period
+      const uint32_t first = q.op - (q.b + q.a);          // index of the piece's first byte inside the match
+      if (first + q.len <= q.a)
+        for (uint32_t k = threadIdx.x; k < q.len; k += 256u)
+          src[q.op + k] = q.b + first + k;
+      else
+        {
+        uint32_t r = (first + threadIdx.x) % q.a;
+        const uint32_t step = 256u % q.a;
+        for (uint32_t k = threadIdx.x; k < q.len; k += 256u)
+          {
+          src[q.op + k] = q.b + r;
+          r += step;
+          r = r >= q.a ? r - q.a : r;
+          }
+        }
+      }
     }
   }
 
-// one round of pointer jumping; returns at once when the previous round changed nothing
-__global__ void __launch_bounds__(256) k_pd_jump(uint32_t* __restrict__ src, uint32_t n, Ctl* __restrict__ ctl)
+// one round of pointer jumping; returns at once when the previous round changed nothing.  The last workgroup to finish closes
+// the round (done = nothing changed).
+__global__ void __launch_bounds__(256) k_pd_jump(PdPlanes P, uint32_t n)
   {
-  if (ctl->done || ctl->error)
+  const PdPlane& pl = P.p[blockIdx.y];
+  Ctl* ctl = pl.ctl;
+  uint32_t* src = pl.src;
+  if (pl.clen == 0u || ctl->done || ctl->error)
     return;
   bool changed = false;
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
@@ -411,20 +474,38 @@ __global__ void __launch_bounds__(256) k_pd_jump(uint32_t* __restrict__ src, uin
       changed = true;
       }
     }
+  __shared__ uint32_t any;
+  if (threadIdx.x == 0)
+    any = 0u;
+  __syncthreads();
   if (__ballot(changed) && (threadIdx.x & 63) == 0)
-    ctl->changed = 1u;
+    any = 1u;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    {
+    if (any)
+      __hip_atomic_store(&ctl->changed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    const uint32_t arrived = atomicAdd(&ctl->arrived, 1u);
+    if (arrived == gridDim.x - 1u)
+      {
+      __threadfence();
+      const uint32_t ch = __hip_atomic_load(&ctl->changed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ctl->done = ch ? 0u : 1u;
+      ctl->changed = 0u;
+      ctl->arrived = 0u;
+      }
+    }
   }
 
-__global__ void k_pd_round_end(Ctl* __restrict__ ctl)
+__global__ void __launch_bounds__(256) k_pd_gather(PdPlanes P, uint32_t n, uint32_t* __restrict__ status)
   {
-  ctl->done = ctl->changed ? 0u : 1u;
-  ctl->changed = 0u;
-  }
-
-__global__ void __launch_bounds__(256) k_pd_gather(const uint8_t* __restrict__ in, uint32_t clen, const uint32_t* __restrict__ src, uint32_t n,
-                                                   uint8_t* __restrict__ out, Ctl* __restrict__ ctl, uint32_t* __restrict__ status)
-  {
-  if (ctl->error)
+  const PdPlane& pl = P.p[blockIdx.y];
+  const uint8_t* in = pl.in;
+  const uint32_t clen = pl.clen;
+  const uint32_t* src = pl.src;
+  uint8_t* out = pl.out;
+  if (clen == 0u || pl.ctl->error)
     return;
   bool bad = false;
   for (uint32_t i0 = 4u * (blockIdx.x * 256u + threadIdx.x); i0 < n; i0 += 4u * gridDim.x * 256u)
@@ -489,7 +570,7 @@ size_t lz4_pdecode_workspace(uint32_t plane_bytes, const uint32_t* sizes, int np
   uint32_t mx = 0;
   for (int c = 0; c < nplanes; ++c)
     mx = sizes[c] > mx ? sizes[c] : mx;
-  return pd_plan(plane_bytes, mx).total;
+  return pd_plan(plane_bytes, mx).total * (size_t)nplanes;       // every plane has a workspace of its own: they are decoded together
   }
 
 int launch_lz4_decode_parallel(const uint8_t* const d_payloads[8], const uint32_t sizes[8], int nplanes, uint8_t* d_planes, size_t plane_stride,
@@ -499,48 +580,45 @@ int launch_lz4_decode_parallel(const uint8_t* const d_payloads[8], const uint32_
   for (int c = 0; c < nplanes; ++c)
     mx = sizes[c] > mx ? sizes[c] : mx;
   const PdPlan p = pd_plan(plane_bytes, mx);
-  if (p.total > ws_bytes)
+  if (nplanes < 1 || nplanes > 8 || p.total * (size_t)nplanes > ws_bytes)
     {
     set_error("lz4 parallel decode: workspace too small");
     return 0;
     }
   hipStream_t st = current_stream();
-  Tile* tiles = (Tile*)(d_ws + p.tiles);
-  Tile* tiles0 = (Tile*)(d_ws + p.tiles0);
-  uint32_t* onpath = (uint32_t*)(d_ws + p.onpath);
-  uint32_t* out_base = (uint32_t*)(d_ws + p.out_base);
-  Ctl* ctl = (Ctl*)(d_ws + p.ctl);
-  Job* jobs = (Job*)(d_ws + p.jobs);
-  uint32_t* src = (uint32_t*)(d_ws + p.src);
-  const unsigned sweep = 2048;                                     // blocks of the element-wise sweeps (grid-stride)
-  for (int c = 0; c < nplanes; ++c)
+  PdPlanes P;
+  uint32_t max_nt = 1;
+  for (int c = 0; c < 8; ++c)
     {
-    const uint8_t* in = d_payloads[c];
-    const uint32_t clen = sizes[c];
-    uint8_t* out = d_planes + (size_t)c * plane_stride;
-    const uint32_t nt = (clen + PD_TILE - 1) / PD_TILE;
-    if (!hip_ok(hipMemsetAsync(ctl, 0, sizeof(Ctl), st), "memset(lz4 decode control)"))
+    PdPlane& q = P.p[c];
+    uint8_t* w = d_ws + (size_t)(c < nplanes ? c : 0) * p.total;
+    q.in = c < nplanes ? d_payloads[c] : nullptr;
+    q.clen = c < nplanes ? sizes[c] : 0u;
+    q.nt = (q.clen + PD_TILE - 1) / PD_TILE;
+    q.out = d_planes + (size_t)(c < nplanes ? c : 0) * plane_stride;
+    q.tiles = (Tile*)(w + p.tiles);
+    q.tiles0 = (Tile*)(w + p.tiles0);
+    q.onpath = (uint32_t*)(w + p.onpath);
+    q.out_base = (uint32_t*)(w + p.out_base);
+    q.ctl = (Ctl*)(w + p.ctl);
+    q.jobs = (Job*)(w + p.jobs);
+    q.src = (uint32_t*)(w + p.src);
+    max_nt = q.nt > max_nt ? q.nt : max_nt;
+    if (c < nplanes && !hip_ok(hipMemsetAsync(q.ctl, 0, sizeof(Ctl), st), "memset(lz4 decode control)"))
       return 0;
-    if (clen == 0)
-      {
-      // no block at all (an empty plane is the one-byte block 0x00, lz4.c:1146-1172 with n = 0): the chain kernel reports it
-      hipLaunchKernelGGL(k_pd_chain, dim3(1), dim3(64), 0, st, in, clen, plane_bytes, 0u, tiles, onpath, out_base, ctl, d_status);
-      continue;
-      }
-    hipLaunchKernelGGL(k_pd_tiles, dim3(nt), dim3(64), 0, st, in, clen, nt, tiles0, onpath, (const Tile*)nullptr);
-    if (!hip_ok(hipMemcpyAsync(tiles, tiles0, sizeof(Tile) * (size_t)nt, hipMemcpyDeviceToDevice, st), "copy(tile records)"))
-      return 0;
-    hipLaunchKernelGGL(k_pd_tiles, dim3(nt), dim3(64), 0, st, in, clen, nt, tiles, onpath, (const Tile*)tiles0);
-    hipLaunchKernelGGL(k_pd_chain, dim3(1), dim3(64), 0, st, in, clen, plane_bytes, nt, tiles, onpath, out_base, ctl, d_status);
-    hipLaunchKernelGGL(k_pd_fill, dim3(nt), dim3(64), 0, st, in, clen, plane_bytes, tiles, onpath, out_base, src, jobs, p.job_cap, ctl, d_status);
-    hipLaunchKernelGGL(k_pd_jobs, dim3(1024), dim3(256), 0, st, jobs, p.job_cap, src, ctl, d_status);
-    for (int r = 0; r < PD_ROUNDS; ++r)
-      {
-      hipLaunchKernelGGL(k_pd_jump, dim3(sweep), dim3(256), 0, st, src, plane_bytes, ctl);
-      hipLaunchKernelGGL(k_pd_round_end, dim3(1), dim3(1), 0, st, ctl);
-      }
-    hipLaunchKernelGGL(k_pd_gather, dim3(sweep), dim3(256), 0, st, in, clen, src, plane_bytes, out, ctl, d_status);
     }
+  const unsigned sweep = 2048;                                     // blocks of the element-wise sweeps (grid-stride)
+  const unsigned np = (unsigned)nplanes;
+  // (a plane with no block at all - an empty plane is the one-byte block 0x00, lz4.c:1146-1172 with n = 0 - is reported by
+  // the chain kernel; the other phases skip it)
+  hipLaunchKernelGGL(k_pd_tiles, dim3(max_nt, np), dim3(64), 0, st, P, 0);
+  hipLaunchKernelGGL(k_pd_tiles, dim3(max_nt, np), dim3(64), 0, st, P, 1);
+  hipLaunchKernelGGL(k_pd_chain, dim3(np), dim3(64), 0, st, P, plane_bytes, d_status);
+  hipLaunchKernelGGL(k_pd_fill, dim3(max_nt, np), dim3(64), 0, st, P, plane_bytes, p.job_cap, d_status);
+  hipLaunchKernelGGL(k_pd_jobs, dim3(1024, np), dim3(256), 0, st, P, p.job_cap, d_status);
+  for (int r = 0; r < PD_ROUNDS; ++r)
+    hipLaunchKernelGGL(k_pd_jump, dim3(sweep, np), dim3(256), 0, st, P, plane_bytes);
+  hipLaunchKernelGGL(k_pd_gather, dim3(sweep, np), dim3(256), 0, st, P, plane_bytes, d_status);
   return hip_ok(hipGetLastError(), "lz4 parallel decode kernels") ? 1 : 0;
   }
 

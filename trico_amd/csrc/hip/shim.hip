@@ -165,14 +165,16 @@ ProfSpan::~ProfSpan()
 static int g_device_state = 0;   // 0 unknown, 1 ok, -1 none
 static thread_local uint32_t g_stats[4] = { 0, 0, 0, 0 };
 
-static bool device_ready()
+void stats_count_repeat() { g_stats[2] += 1; }
+void set_current_stream(hipStream_t s) { g_stream = s; }
+
+bool device_ready()
   {
   if (g_device_state == 0)
     {
-    // ROCm multiplexes HIP streams onto 4 hardware queues by default, and kernels sharing a queue run one after the
-    // other.  The decoders run one long kernel per stream of an archive (read-ahead) and per archive, so more
-    // queues are asked for — effective when this is the first HIP call of the process, never overriding the user.
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    // (No process setting is touched here.  Round 2 asked for GPU_MAX_HW_QUEUES=16 because every stream of an archive was a
+    // kernel launch of its own on a HIP stream of its own; the decode engine (engine.hip) launches all chains of a batch as one
+    // grid and needs three HIP streams whatever the batch holds.)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
       {
@@ -188,7 +190,7 @@ static bool device_ready()
   }
 
 // stage `bytes` from src (host or device) so that kernels can read it; returns a device pointer
-static const void* stage_in(DevBuf& buf, const void* src, size_t bytes, size_t offset = 0)
+const void* stage_in(DevBuf& buf, const void* src, size_t bytes, size_t offset)
   {
   if (trico_hip_pointer_is_device(src))
     return src;
@@ -350,6 +352,86 @@ int trico_hip_copy(void* dst, const void* src, size_t bytes)
   return 1;
   }
 
+// ---- framing of a device-resident archive -----------------------------------------------------------
+struct NcompTable { uint8_t n[21]; };
+
+__global__ void k_walk_frames(const uint8_t* __restrict__ data, uint64_t size, uint64_t pos, NcompTable nc, trico_hip_frame_bytes* __restrict__ out,
+                              int cap, uint32_t* __restrict__ tail)
+  {
+  // one thread: a frame is found only through the size fields of the frames before it
+  uint8_t* head = (uint8_t*)(tail + 1);
+  for (uint32_t k = 0; k < 8u; ++k)
+    head[k] = k < size ? data[k] : 0u;
+  int n = 0;
+  while (n < cap && pos < size)
+    {
+    trico_hip_frame_bytes f;
+    f.tpos = pos;
+    f.ncomp = 0;
+    for (int c = 0; c < 8; ++c) { f.size_pos[c] = 0; f.size_valid[c] = 0; }
+    for (int k = 0; k < 40; ++k) f.bytes[k] = 0;
+    f.nbytes_head = size - pos < 5u ? (uint32_t)(size - pos) : 5u;
+    for (uint32_t k = 0; k < f.nbytes_head; ++k)
+      f.bytes[k] = data[pos + k];
+    const uint32_t type = f.bytes[0];
+    const uint32_t want = (f.nbytes_head == 5u && type <= 20u) ? nc.n[type] : 0u;
+    uint64_t q = pos + 5u;
+    bool whole = want != 0u;
+    for (uint32_t c = 0; c < want; ++c)
+      {
+      if (q + 4u > size) { whole = false; break; }
+      uint32_t sz = 0;
+      for (uint32_t k = 0; k < 4u; ++k)
+        {
+        f.bytes[5u + 4u * c + k] = data[q + k];
+        sz |= (uint32_t)data[q + k] << (8u * k);
+        }
+      f.size_pos[c] = q;
+      f.size_valid[c] = 1;
+      f.ncomp = c + 1u;
+      q += 4u + (uint64_t)sz;
+      if (q > size) { whole = false; break; }
+      }
+    out[n++] = f;
+    if (!whole)
+      break;
+    pos = q;
+    }
+  tail[0] = (uint32_t)n;
+  }
+
+int trico_hip_walk_frames(const uint8_t* d_data, uint64_t size, uint64_t pos, const uint8_t ncomp_of_type[21],
+                          trico_hip_frame_bytes* out, int cap, uint8_t head8[8])
+  {
+  if (!device_ready() || !d_data || !ncomp_of_type || !out || cap < 1 || cap > 256)
+    return -1;
+  static std::mutex mu;
+  static uint8_t* d_buf = nullptr;            // 256 frame records + count + header bytes
+  std::lock_guard<std::mutex> lock(mu);
+  const size_t rec = sizeof(trico_hip_frame_bytes) * 256;
+  if (!d_buf && !hip_ok(hipMalloc((void**)&d_buf, rec + 64), "hipMalloc(frame records)"))
+    return -1;
+  NcompTable nc;
+  memcpy(nc.n, ncomp_of_type, 21);
+  uint32_t* d_tail = (uint32_t*)(d_buf + rec);
+  hipStream_t st = current_stream();
+  hipLaunchKernelGGL(k_walk_frames, dim3(1), dim3(1), 0, st, d_data, size, pos, nc, (trico_hip_frame_bytes*)d_buf, cap, d_tail);
+  if (!hip_ok(hipGetLastError(), "k_walk_frames"))
+    return -1;
+  // records and tail are adjacent when cap == 256; otherwise two ranges -> copy the used records and the tail together through
+  // one staging image: the tail is copied to sit right behind the `cap` records
+  static uint8_t h_img[sizeof(trico_hip_frame_bytes) * 256 + 64];
+  if (!hip_ok(hipMemcpyAsync(h_img, d_buf, rec + 64, hipMemcpyDeviceToHost, st), "D2H(frame records)") ||
+      !hip_ok(hipStreamSynchronize(st), "D2H(frame records)"))
+    return -1;
+  const uint32_t n = *(const uint32_t*)(h_img + rec);
+  if (head8)
+    memcpy(head8, h_img + rec + 4, 8);
+  const int got = (int)(n > (uint32_t)cap ? (uint32_t)cap : n);
+  memcpy(out, h_img, sizeof(trico_hip_frame_bytes) * (size_t)got);
+  return got;
+  }
+
 // ---- floating point -----------------------------------------------------------------------------
 
 int trico_hip_fpc_encode(trico_hip_ctx* ctx, const void* src, uint32_t n, int arity, int width, uint32_t sizes[3])
@@ -455,65 +537,100 @@ int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int
 //     which does not use the scalar cache (20x slower; trico_hip_last_stats word 2 counts the repeats).
 //     TRICO_HIP_DECODE_CHECK=0 switches the check off (measurements only).
 
-static bool decode_check_enabled()
+} // extern "C"
+
+namespace trico {
+
+bool decode_check_enabled()
   {
   static const bool on = [] { const char* e = getenv("TRICO_HIP_DECODE_CHECK"); return !(e && e[0] == '0'); }();
   return on;
   }
 
 // status bits 0x100 << c: component c of the re-encode differs from the payload
-constexpr uint32_t CHECK_BITS = 0x700u;
+constexpr uint32_t CHECK_BITS = FPC_STATUS_CHECK;
 
-static int fpc_check_launch(trico_hip_ctx* ctx, uint32_t* d_status)
+// Codes the n x arity values at d_vals again (throughput encoders, workspace `vws`, payload sizes to d_vsizes[0..2]) and compares
+// the bytes with the payloads the values were decoded from: bit 0x100 << c of *d_status is set where component c differs.
+// Everything is queued on current_stream(); nothing waits.
+int fpc_selfcheck_launch(const void* d_vals, uint32_t n, int arity, int width, const uint8_t* const d_pay[3], const uint32_t sizes[3],
+                         DevBuf& vws, uint32_t* d_vsizes, uint32_t* d_status)
   {
-  const int arity = ctx->chk_arity, width = ctx->chk_width;
-  const uint32_t n = ctx->chk_n;
   if (n == 0 || !decode_check_enabled())
     return 1;
-  uint32_t* d_vsizes = (uint32_t*)ctx->aux.p + 64;                 // the status words are at the start of aux
   if (width == 4)
     {
     const size_t ws = fpc32_encode_workspace(n, arity);
-    if (!ctx->vws.reserve(ws))
+    if (!vws.reserve(ws))
       return 0;
-    return launch_fpc32_encode(ctx->chk_dst, n, arity, nullptr, 0, d_vsizes, ctx->vws.p, ctx->vws.cap) &&
-           launch_fpc32_compare(n, arity, ctx->vws.p, d_vsizes, ctx->chk_pay, ctx->chk_sizes, d_status, 0x100u);
+    return launch_fpc32_encode(d_vals, n, arity, nullptr, 0, d_vsizes, vws.p, vws.cap) &&
+           launch_fpc32_compare(n, arity, vws.p, d_vsizes, d_pay, sizes, d_status, 0x100u);
     }
   const size_t stride = align_up(fpc_bound(n, 8), 256);
   const bool sorted = n >= fpc64_sorted_threshold() && n <= 0x7fffffffu;
   const size_t wsb = sorted ? fpc64_sorted_workspace(n) : (size_t)arity * 2 * ((size_t)1 << 20) * 8;
-  if (!ctx->vws.reserve(stride * arity + wsb + 256))
+  if (!vws.reserve(stride * arity + wsb + 256))
     return 0;
-  uint8_t* out = ctx->vws.p;
-  uint8_t* wsp = ctx->vws.p + stride * arity;
+  uint8_t* out = vws.p;
+  uint8_t* wsp = vws.p + stride * arity;
   if (sorted)
     {
-    if (!launch_fpc64_encode_sorted(ctx->chk_dst, n, arity, out, stride, d_vsizes, wsp, wsb))
+    if (!launch_fpc64_encode_sorted(d_vals, n, arity, out, stride, d_vsizes, wsp, wsb))
       return 0;
     }
   else
     {
     TRICO_HIP_TRY(hipMemsetAsync(wsp, 0, wsb, current_stream()));
-    if (!launch_fpc64_encode(ctx->chk_dst, n, arity, out, stride, d_vsizes, (uint64_t*)wsp))
+    if (!launch_fpc64_encode(d_vals, n, arity, out, stride, d_vsizes, (uint64_t*)wsp))
       return 0;
     }
   for (int c = 0; c < arity; ++c)
-    if (!launch_bytes_compare(out + (size_t)c * stride, ctx->chk_pay[c], ctx->chk_sizes[c], d_vsizes + c, d_status, 0x100u << c))
+    if (!launch_bytes_compare(out + (size_t)c * stride, d_pay[c], sizes[c], d_vsizes + c, d_status, 0x100u << c))
       return 0;
   return 1;
   }
 
-// test hook: TRICO_HIP_DECODE_SABOTAGE=k damages the output of the first k chain decodes of every stream (one bit of the last
-// value) before the check sees it, so that the repeat path can be exercised on purpose (tests/test_gpu_selfcheck.py)
-__global__ void k_flip_bit(uint8_t* p) { p[0] ^= 1u; }
-static int sabotage_count()
+} // namespace trico
+
+extern "C" {
+
+static int fpc_check_launch(trico_hip_ctx* ctx, uint32_t* d_status)
   {
-  const char* e = getenv("TRICO_HIP_DECODE_SABOTAGE");
-  return e ? atoi(e) : 0;
+  uint32_t* d_vsizes = (uint32_t*)ctx->aux.p + 64;                 // the status words are at the start of aux
+  return fpc_selfcheck_launch(ctx->chk_dst, ctx->chk_n, ctx->chk_arity, ctx->chk_width, ctx->chk_pay, ctx->chk_sizes, ctx->vws, d_vsizes, d_status);
   }
 
+} // extern "C"
+
+namespace trico {
+
+// Test hook, compiled only into libtrico_testhooks.so (-DTRICO_HIP_TEST_HOOKS, trico_amd/build.py): TRICO_HIP_DECODE_SABOTAGE=k
+// damages the output of the first k chain decodes of every stream (one bit of the last value) before the check sees it, so that
+// the repeat path can be exercised on purpose (tests/test_gpu_selfcheck.py).  The product library has no such switch.
+#ifdef TRICO_HIP_TEST_HOOKS
+__global__ void k_flip_bit(uint8_t* p) { p[0] ^= 1u; }
+int decode_sabotage(int attempt, void* d_vals, uint32_t n, int arity, int width)
+  {
+  static const int count = [] { const char* e = getenv("TRICO_HIP_DECODE_SABOTAGE"); return e ? atoi(e) : 0; }();
+  if (n && attempt < count)
+    hipLaunchKernelGGL(k_flip_bit, dim3(1), dim3(1), 0, current_stream(), (uint8_t*)d_vals + ((size_t)n * arity - 1) * width);
+  return 1;
+  }
+#else
+int decode_sabotage(int, void*, uint32_t, int, int) { return 1; }
+#endif
+
+// Attempt number of the chain decode the single-stream path starts with: 0, or 1 when the decode engine (engine.hip) has
+// already made attempt 0 as part of a batch and hands the stream over to be repeated.
+static thread_local int g_first_attempt = 0;
+void set_first_attempt(int a) { g_first_attempt = a; }
+
+} // namespace trico
+
+extern "C" {
+
 // launches the chain decoder for the stream remembered in ctx->chk_* and its check (attempt 0, 1, 2)
-static int fpc_chain_decode(trico_hip_ctx* ctx, int attempt = 0)
+static int fpc_chain_decode(trico_hip_ctx* ctx, int attempt)
   {
   const int arity = ctx->chk_arity, width = ctx->chk_width;
   const uint32_t n = ctx->chk_n;
@@ -523,9 +640,7 @@ static int fpc_chain_decode(trico_hip_ctx* ctx, int attempt = 0)
     return 0;
   const int ok = width == 4 ? launch_fpc32_decode(ctx->chk_pay, ctx->chk_sizes, arity, n, ctx->chk_dst, d_status, (uint32_t*)ctx->tmp.p)
                             : launch_fpc64_decode(ctx->chk_pay, ctx->chk_sizes, arity, n, ctx->chk_dst, (uint64_t*)ctx->tmp.p, d_status);
-  if (ok && n && attempt < sabotage_count())
-    hipLaunchKernelGGL(k_flip_bit, dim3(1), dim3(1), 0, current_stream(), (uint8_t*)ctx->chk_dst + ((size_t)n * arity - 1) * width);
-  return ok && fpc_check_launch(ctx, d_status);
+  return ok && decode_sabotage(attempt, ctx->chk_dst, n, arity, width) && fpc_check_launch(ctx, d_status);
   }
 
 // Stages the payloads, launches the decode into d_dst (ctx->out when NULL) on current_stream() and queues the
@@ -621,7 +736,7 @@ static int fpc_decode_launch(trico_hip_ctx* ctx, const uint8_t* const payloads[3
     ctx->chk_width = width;
     ctx->chk_n = n;
     ctx->chk_dst = d_dst;
-    if (!fpc_chain_decode(ctx))
+    if (!fpc_chain_decode(ctx, g_first_attempt))
       return 0;
     }
   else if (!launch_fpc_decode_serial(d_pay, sizes, arity, width, n, d_dst, d_tables, table_stride, d_status))
@@ -636,7 +751,7 @@ static int decode_complete(trico_hip_ctx* ctx, const char* what)
   {
   TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
   uint32_t st = ctx->h_pinned[0];
-  for (int attempt = 1; ctx->chk_active && st != 0 && (st & ~CHECK_BITS) == 0 && attempt <= 3; ++attempt)
+  for (int attempt = g_first_attempt + 1; ctx->chk_active && st != 0 && (st & ~(CHECK_BITS | FPC_STATUS_TIMEOUT)) == 0 && attempt <= 3; ++attempt)
     {
     // the payload parsed but the values do not code back to it: the chain went wrong (see fpc_chain_decode).  Twice more, then
     // in reference order without the scalar cache (20x slower).
@@ -665,7 +780,9 @@ static int decode_complete(trico_hip_ctx* ctx, const char* what)
         TRICO_HIP_TRY(hipMemsetAsync(ctx->tmp.p, 0, tb, current_stream()));
         d_tables = (uint64_t*)ctx->tmp.p;
         }
-      if (!launch_fpc_decode_serial(ctx->chk_pay, ctx->chk_sizes, arity, width, ctx->chk_n, ctx->chk_dst, d_tables, table_stride, d_status))
+      // (this rung is checked like the others: whatever it decoded must code back to the payload)
+      if (!launch_fpc_decode_serial(ctx->chk_pay, ctx->chk_sizes, arity, width, ctx->chk_n, ctx->chk_dst, d_tables, table_stride, d_status) ||
+          !fpc_check_launch(ctx, d_status))
         return 0;
       }
     TRICO_HIP_TRY(hipMemcpyAsync(ctx->h_pinned, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, current_stream()));
@@ -675,7 +792,8 @@ static int decode_complete(trico_hip_ctx* ctx, const char* what)
   ctx->chk_active = false;
   if (st != 0)
     {
-    set_error((st & CHECK_BITS) && (st & ~CHECK_BITS) == 0 ? "trico decode: the decoded values do not code back to the payload" : what);
+    set_error((st & (CHECK_BITS | FPC_STATUS_TIMEOUT)) && (st & ~(CHECK_BITS | FPC_STATUS_TIMEOUT)) == 0
+                ? "trico decode: the decoded values do not code back to the payload" : what);
     return 0;
     }
   return 1;
@@ -778,6 +896,13 @@ static int int_decode_launch(trico_hip_ctx* ctx, const uint8_t* const payloads[8
                              int width, uint32_t count, void* d_dst)
   {
   ctx->chk_active = false;
+  if (count > 0x7E000000u)
+    {
+    // LZ4_MAX_INPUT_SIZE (lz4.h:170): the reference cannot have written a larger block, and the data-parallel decoder tags its
+    // source words in bit 31
+    set_error("trico_hip_int_decode: plane larger than LZ4_MAX_INPUT_SIZE");
+    return 0;
+    }
   size_t total = 0, offs[8];
   bool any_host = false;
   for (int c = 0; c < width; ++c)

@@ -44,16 +44,24 @@ struct trico_archive
   uint8_t next_stream_type;
   int writable;
   trico_hip_ctx* ctx;   /* created on first use */
-  /* read-ahead: streams whose decode is already running, keyed by the cursor position of their count field */
+  /* read-ahead: streams that were decoded ahead as one batch, keyed by the cursor position of their count field */
   struct ra_entry* ra;
   int ra_n;
   int ra_started;
+  /* device-resident archive: the framing bytes (type, count, component sizes) of the next streams, fetched with one
+   * device-side walk and one copy instead of one copy per field (trico.c:100-124 reads them from host memory) */
+  struct trico_hip_frame_bytes* fr;
+  int fr_n;
+  uint8_t head8[8];
+  int head8_valid;
   };
 
 struct ra_entry
   {
   uint64_t pos;
-  trico_hip_ctx* ctx;
+  void* parked;         /* device buffer holding the decoded stream; NULL: it was decoded straight into the caller's array */
+  uint64_t bytes;
+  int ok, live;
   };
 
 #define TRICO_MAGIC 0x6f637254u   /* "Trco", trico.c:94 */
@@ -127,6 +135,53 @@ static uint32_t load_le32(const uint8_t* p)
 
 /* ---- read primitives (trico.c:65-124) ---------------------------------------------------- */
 
+/* components per stream type (trico.c:215-858), 0 = unknown; what the device-side frame walk needs to know */
+static const uint8_t NCOMP_OF_TYPE[21] = { 0, 3, 3, 4, 8, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 1, 1, 1, 2, 4, 8 };
+#define FRAME_CACHE 32
+
+/* serves [pos, pos + n) from the cached framing bytes of a device-resident archive; 0 = not cached */
+static int framing_lookup(const struct trico_archive* a, uint64_t pos, void* dst, uint64_t n)
+  {
+  if (a->head8_valid && pos + n <= 8)
+    {
+    memcpy(dst, a->head8 + pos, n);
+    return 1;
+    }
+  for (int i = 0; i < a->fr_n; ++i)
+    {
+    const struct trico_hip_frame_bytes* f = &a->fr[i];
+    if (pos >= f->tpos && pos + n <= f->tpos + f->nbytes_head)
+      {
+      memcpy(dst, f->bytes + (pos - f->tpos), n);
+      return 1;
+      }
+    for (uint32_t c = 0; c < f->ncomp; ++c)
+      if (pos >= f->size_pos[c] && f->size_valid[c] && pos + n <= f->size_pos[c] + 4)
+        {
+        memcpy(dst, f->bytes + 5 + 4 * c + (pos - f->size_pos[c]), n);
+        return 1;
+        }
+    }
+  return 0;
+  }
+
+/* one device-side walk over the next FRAME_CACHE streams starting at the type byte at tpos (or at the file header) */
+static void framing_fill(struct trico_archive* a, uint64_t tpos)
+  {
+  if (!a->fr)
+    a->fr = (struct trico_hip_frame_bytes*)malloc(sizeof(struct trico_hip_frame_bytes) * FRAME_CACHE);
+  if (!a->fr)
+    return;
+  uint8_t head[8];
+  const int n = trico_hip_walk_frames(a->data, a->data_size, tpos, NCOMP_OF_TYPE, a->fr, FRAME_CACHE, head);
+  a->fr_n = n > 0 ? n : 0;
+  if (n >= 0 && a->data_size >= 8)
+    {
+    memcpy(a->head8, head, 8);
+    a->head8_valid = 1;
+    }
+  }
+
 static int peek_bytes(struct trico_archive* a, void* dst, uint64_t n)
   {
   if (a->writable)
@@ -134,7 +189,18 @@ static int peek_bytes(struct trico_archive* a, void* dst, uint64_t n)
   if (a->pos + n > a->data_size)
     return 0;
   if (a->data_on_device)
-    return trico_hip_copy(dst, a->data + a->pos, n);
+    {
+    if (framing_lookup(a, a->pos, dst, n))
+      return 1;
+    if (n == 1)
+      {
+      /* a type byte the cache does not hold: the walk continues from here */
+      framing_fill(a, a->pos);
+      if (framing_lookup(a, a->pos, dst, n))
+        return 1;
+      }
+    return trico_hip_copy(dst, a->data + a->pos, n);      /* always right, one copy per field */
+    }
   memcpy(dst, a->data + a->pos, n);
   return 1;
   }
@@ -216,9 +282,12 @@ void* trico_open_archive_for_reading(const uint8_t* data, uint64_t data_size)
   a->data = data;
   a->data_size = data_size;
   a->data_on_device = (data != NULL && data_size != 0) ? trico_hip_pointer_is_device(data) : 0;
+  if (a->data_on_device && data_size >= 8)
+    framing_fill(a, 8);                       /* file header + framing of the first streams: one kernel, one copy */
   uint8_t hdr[8];
   if (data == NULL || !peek_bytes(a, hdr, 8) || load_le32(hdr) != TRICO_MAGIC)
     {
+    free(a->fr);
     free(a);
     return NULL;
     }
@@ -241,12 +310,10 @@ void trico_close_archive(void* archive)
       free(a->buffer);
     }
   for (int i = 0; i < a->ra_n; ++i)
-    if (a->ra[i].ctx)
-      {
-      (void)trico_hip_decode_finish(a->ra[i].ctx, NULL);      /* a stream that was never collected */
-      trico_hip_ctx_destroy(a->ra[i].ctx);
-      }
+    if (a->ra[i].live && a->ra[i].parked)
+      trico_hip_device_free(a->ra[i].parked);               /* a stream that was never collected */
   free(a->ra);
+  free(a->fr);
   if (a->ctx)
     trico_hip_ctx_destroy(a->ctx);
   free(a);
@@ -489,9 +556,11 @@ static int parse_frames(struct trico_archive* a, int ncomp, uint32_t* count, con
 /* ---- read-ahead ------------------------------------------------------------------------------
  * The reference decodes stream after stream (trico.c:943-1668), and the format leaves one serial chain
  * per component stream.  On the GPU a chain occupies one wave, so the first read that actually wants
- * data walks the remaining frames and starts the decode of every stream (one context and HIP stream
- * each, trico_hip_decode_begin); the trico_read_* calls then collect.  Results and error behaviour are
- * those of the one-by-one path: a malformed stream fails in its own read call.
+ * data walks the remaining frames and decodes every stream of the archive as ONE batch
+ * (trico_hip_decode_jobs: all chains in one kernel launch, the integer streams beside them).  The stream
+ * that is being read goes straight into the caller's array, the others are parked on the device and the
+ * later trico_read_* calls copy them out.  Results and error behaviour are those of the one-by-one path:
+ * a malformed stream fails in its own read call.
  * TRICO_HIP_READAHEAD_MB bounds the decoded bytes held at once (default 65536, 0 switches it off). */
 
 struct stream_layout { int known, is_int, ncomp, arity, width; uint32_t per_count; };
@@ -523,9 +592,33 @@ static struct stream_layout layout_of(uint8_t type)
 static int parse_frames(struct trico_archive* a, int ncomp, uint32_t* count, const uint8_t** payloads,
                         uint32_t* sizes, uint64_t* end_pos);
 
+/* the stream at the cursor as a decode job (dst not set); 0 if the type is unknown or the framing broken.  *end = cursor
+ * position behind the stream. */
+static int job_at_cursor(struct trico_archive* a, trico_hip_decode_job* job, uint32_t* count_field, uint64_t* end)
+  {
+  const struct stream_layout L = layout_of(a->next_stream_type);
+  uint32_t count = 0;
+  memset(job, 0, sizeof(*job));
+  if (!L.known || !parse_frames(a, L.ncomp, &count, job->payloads, job->sizes, end))
+    return 0;
+  const uint64_t n = (uint64_t)count * L.per_count;
+  if (n > 0xffffffffull)
+    return 0;
+  job->is_int = L.is_int;
+  job->arity = L.arity;
+  job->width = L.width;
+  job->n = (uint32_t)n;
+  *count_field = count;
+  return 1;
+  }
+
+static uint64_t job_bytes(const trico_hip_decode_job* job)
+  {
+  return (uint64_t)job->n * (uint64_t)job->width * (uint64_t)(job->is_int ? 1 : job->arity);
+  }
+
 /* device bytes the streams decoded ahead may occupy: TRICO_HIP_READAHEAD_MB (default 64 GiB), but never more than half
- * of what the device has free right now.  A stream is charged its decoded size plus its working set (staged payload,
- * byte planes, the 4 bytes per plane byte of the LZ4 decoder, the double tables): three times the output + 64 MiB. */
+ * of what the device has free right now. */
 static uint64_t readahead_budget(void)
   {
   const char* e = getenv("TRICO_HIP_READAHEAD_MB");
@@ -537,23 +630,28 @@ static uint64_t readahead_budget(void)
   return budget;
   }
 
-/* device memory a stream decoded ahead holds: its values, the staged payload, kernel workspaces, and for float / double
- * streams the workspace of the self-check (the encoder's: ~1.3 x the values for floats, ~3 x for doubles) */
+/* device memory a stream decoded ahead is charged: its parked values plus its share of the engine's working set (staged payload,
+ * byte planes, the 4 bytes per plane byte of the LZ4 decoder, the self-check's encoder workspace; these are shared by the
+ * streams of a batch, so the charge is generous) */
 static uint64_t readahead_cost(uint64_t decoded_bytes)
   {
-  return 5 * decoded_bytes + (64ull << 20);
+  return 3 * decoded_bytes + (64ull << 20);
   }
 
-/* drops the decode that was started ahead for the stream at the cursor (the caller skips it) */
+static void release_entry(struct ra_entry* e)
+  {
+  if (e->live && e->parked)
+    trico_hip_device_free(e->parked);
+  e->parked = NULL;
+  e->live = 0;
+  }
+
+/* drops the decode that was made ahead for the stream at the cursor (the caller skips it) */
 static void drop_readahead(struct trico_archive* a)
   {
   for (int i = 0; i < a->ra_n; ++i)
-    if (a->ra[i].ctx && a->ra[i].pos == a->pos)
-      {
-      (void)trico_hip_decode_finish(a->ra[i].ctx, NULL);
-      trico_hip_ctx_destroy(a->ra[i].ctx);
-      a->ra[i].ctx = NULL;
-      }
+    if (a->ra[i].live && a->ra[i].pos == a->pos)
+      release_entry(&a->ra[i]);
   }
 
 /* the one-by-one decode of a stream failed while other streams are still parked on the device: give their memory back
@@ -562,17 +660,16 @@ static int drop_all_readahead(struct trico_archive* a)
   {
   int dropped = 0;
   for (int i = 0; i < a->ra_n; ++i)
-    if (a->ra[i].ctx)
+    if (a->ra[i].live)
       {
-      (void)trico_hip_decode_finish(a->ra[i].ctx, NULL);
-      trico_hip_ctx_destroy(a->ra[i].ctx);
-      a->ra[i].ctx = NULL;
+      release_entry(&a->ra[i]);
       ++dropped;
       }
   return dropped;
   }
 
-static void start_readahead(struct trico_archive* a)
+/* `out` = destination of the stream at the cursor (the read call that triggered the read-ahead) */
+static void start_readahead(struct trico_archive* a, void* out)
   {
   a->ra_started = 1;
   const uint64_t budget = readahead_budget();
@@ -580,15 +677,14 @@ static void start_readahead(struct trico_archive* a)
     return;
   const uint64_t save_pos = a->pos;
   const uint8_t save_type = a->next_stream_type;
-  /* pass 1: is there more than one stream left?  (a lone stream gains nothing from the detour) */
+  /* pass 1: count the streams left (a lone stream gains nothing from the detour) */
   int streams = 0;
-  while (a->next_stream_type != (uint8_t)trico_empty && streams < 2)
+  while (a->next_stream_type != (uint8_t)trico_empty)
     {
-    const struct stream_layout L = layout_of(a->next_stream_type);
-    uint32_t count = 0, sizes[8];
-    const uint8_t* pay[8];
+    trico_hip_decode_job job;
+    uint32_t count = 0;
     uint64_t end = 0;
-    if (!L.known || !parse_frames(a, L.ncomp, &count, pay, sizes, &end))
+    if (!job_at_cursor(a, &job, &count, &end))
       break;
     ++streams;
     a->pos = end;
@@ -598,59 +694,80 @@ static void start_readahead(struct trico_archive* a)
   a->next_stream_type = save_type;
   if (streams < 2)
     return;
-  /* pass 2: start them */
-  uint64_t held = 0;
-  int cap = 0;
-  while (a->next_stream_type != (uint8_t)trico_empty)
+  trico_hip_decode_job* jobs = (trico_hip_decode_job*)calloc((size_t)streams, sizeof(trico_hip_decode_job));
+  struct ra_entry* ra = (struct ra_entry*)calloc((size_t)streams, sizeof(struct ra_entry));
+  if (!jobs || !ra)
     {
-    const struct stream_layout L = layout_of(a->next_stream_type);
-    uint32_t count = 0, sizes[8];
-    const uint8_t* pay[8];
+    free(jobs);
+    free(ra);
+    return;
+    }
+  /* pass 2: one job per stream, as long as the budget lasts */
+  uint64_t held = 0;
+  int n = 0;
+  while (a->next_stream_type != (uint8_t)trico_empty && n < streams)
+    {
+    uint32_t count = 0;
     uint64_t end = 0;
-    if (!L.known || !parse_frames(a, L.ncomp, &count, pay, sizes, &end))
+    if (!job_at_cursor(a, &jobs[n], &count, &end))
       break;
-    const uint64_t n = (uint64_t)count * L.per_count;
-    const uint64_t bytes = n * (uint64_t)L.width * (uint64_t)(L.is_int ? 1 : L.arity);
-    if (n != 0 && n <= 0xffffffffull && held + readahead_cost(bytes) <= budget)
+    const uint64_t bytes = job_bytes(&jobs[n]);
+    if (jobs[n].n != 0)
       {
-      if (a->ra_n == cap)
+      void* dst = NULL;
+      void* parked = NULL;
+      if (a->pos == save_pos)
+        dst = out;                                   /* the stream being read: straight into the caller's array */
+      else if (held + readahead_cost(bytes) <= budget)
         {
-        const int ncap = cap ? 2 * cap : 8;
-        struct ra_entry* nr = (struct ra_entry*)realloc(a->ra, (size_t)ncap * sizeof(struct ra_entry));
-        if (!nr)
-          break;
-        a->ra = nr;
-        cap = ncap;
+        parked = trico_hip_device_alloc(bytes + 16);
+        dst = parked;
+        held += parked ? readahead_cost(bytes) : 0;
         }
-      trico_hip_ctx* ctx = trico_hip_ctx_create();
-      if (ctx && trico_hip_decode_begin(ctx, L.is_int, pay, sizes, L.arity, L.width, (uint32_t)n))
+      if (dst)
         {
-        a->ra[a->ra_n].pos = a->pos;
-        a->ra[a->ra_n].ctx = ctx;
-        ++a->ra_n;
-        held += readahead_cost(bytes);
+        jobs[n].dst = dst;
+        ra[n].pos = a->pos;
+        ra[n].parked = parked;
+        ra[n].bytes = bytes;
+        ra[n].live = 1;
+        ++n;
         }
-      else if (ctx)
-        trico_hip_ctx_destroy(ctx);       /* the one-by-one path will report what is wrong with it */
       }
     a->pos = end;
     read_next_stream_type(a);
     }
   a->pos = save_pos;
   a->next_stream_type = save_type;
+  if (n >= 2)
+    {
+    (void)trico_hip_decode_jobs(jobs, n);            /* per-job results below: a stream that failed fails in its own read call */
+    for (int i = 0; i < n; ++i)
+      ra[i].ok = jobs[i].ok;
+    a->ra = ra;
+    a->ra_n = n;
+    }
+  else
+    {
+    for (int i = 0; i < n; ++i)
+      release_entry(&ra[i]);
+    free(ra);
+    }
+  free(jobs);
   }
 
-/* collects the stream at the cursor if its decode was started ahead: 1 done, 0 failed, -1 not started ahead */
+/* collects the stream at the cursor if it was decoded ahead: 1 done, 0 failed, -1 not decoded ahead */
 static int collect_readahead(struct trico_archive* a, void* out)
   {
   if (!a->ra_started)
-    start_readahead(a);
+    start_readahead(a, out);
   for (int i = 0; i < a->ra_n; ++i)
-    if (a->ra[i].ctx && a->ra[i].pos == a->pos)
+    if (a->ra[i].live && a->ra[i].pos == a->pos)
       {
-      const int ok = trico_hip_decode_finish(a->ra[i].ctx, out);
-      trico_hip_ctx_destroy(a->ra[i].ctx);
-      a->ra[i].ctx = NULL;
+      int ok = a->ra[i].ok;
+      if (ok && a->ra[i].parked)
+        ok = a->ra[i].bytes == 0 || trico_hip_copy(out, a->ra[i].parked, a->ra[i].bytes);
+      release_entry(&a->ra[i]);
       return ok;
       }
   return -1;
@@ -777,6 +894,123 @@ int trico_read_attributes_uint32(void* a, uint32_t** p)
   { return read_int_stream(a, trico_attribute_uint32_stream, (void**)p, 4, 1); }
 int trico_read_attributes_uint64(void* a, uint64_t** p)
   { return read_int_stream(a, trico_attribute_uint64_stream, (void**)p, 8, 1); }
+
+/* ---- whole archives at once (include/trico/trico_hip.h) ------------------------------------------- */
+
+int trico_hip_list_streams(void* archive, trico_hip_stream_info* out, int cap)
+  {
+  struct trico_archive* a = (struct trico_archive*)archive;
+  if (!a || a->writable || (cap > 0 && !out))
+    return -1;
+  const uint64_t save_pos = a->pos;
+  const uint8_t save_type = a->next_stream_type;
+  int n = 0, broken = 0;
+  while (a->next_stream_type != (uint8_t)trico_empty)
+    {
+    trico_hip_decode_job job;
+    uint32_t count = 0;
+    uint64_t end = 0;
+    if (!job_at_cursor(a, &job, &count, &end))
+      {
+      broken = 1;
+      break;
+      }
+    if (n < cap)
+      {
+      trico_hip_stream_info* o = &out[n];
+      o->type = a->next_stream_type;
+      o->is_int = job.is_int;
+      o->arity = job.arity;
+      o->width = job.width;
+      o->count = count;
+      o->n = job.n;
+      o->decoded_bytes = job_bytes(&job);
+      o->payload_bytes = 0;
+      for (int c = 0; c < (job.is_int ? job.width : job.arity); ++c)
+        o->payload_bytes += job.sizes[c];
+      }
+    ++n;
+    a->pos = end;
+    read_next_stream_type(a);
+    }
+  a->pos = save_pos;
+  a->next_stream_type = save_type;
+  return broken ? -1 : n;
+  }
+
+int trico_hip_read_archives(void* const* archives, int count, void* const* const* dsts, const int* nstreams)
+  {
+  if (!archives || count < 0 || (count > 0 && (!dsts || !nstreams)))
+    return 0;
+  int total = 0;
+  for (int k = 0; k < count; ++k)
+    {
+    const struct trico_archive* a = (const struct trico_archive*)archives[k];
+    if (!a || a->writable || nstreams[k] < 0 || (nstreams[k] > 0 && !dsts[k]))
+      return 0;
+    total += nstreams[k];
+    }
+  if (total == 0)
+    return 1;
+  trico_hip_decode_job* jobs = (trico_hip_decode_job*)calloc((size_t)total, sizeof(trico_hip_decode_job));
+  uint64_t* ends = (uint64_t*)calloc((size_t)total, sizeof(uint64_t));
+  int* parsed = (int*)calloc((size_t)count, sizeof(int));
+  if (!jobs || !ends || !parsed)
+    {
+    free(jobs); free(ends); free(parsed);
+    return 0;
+    }
+  /* the frames of every archive, from its cursor */
+  int all = 1, at = 0;
+  for (int k = 0; k < count; ++k)
+    {
+    struct trico_archive* a = (struct trico_archive*)archives[k];
+    const uint64_t save_pos = a->pos;
+    const uint8_t save_type = a->next_stream_type;
+    for (int s_ = 0; s_ < nstreams[k]; ++s_)
+      {
+      uint32_t cf = 0;
+      if (a->next_stream_type == (uint8_t)trico_empty || !job_at_cursor(a, &jobs[at + s_], &cf, &ends[at + s_]))
+        {
+        all = 0;
+        break;
+        }
+      jobs[at + s_].dst = dsts[k][s_];              /* NULL: skipped */
+      ++parsed[k];
+      a->pos = ends[at + s_];
+      read_next_stream_type(a);
+      }
+    a->pos = save_pos;
+    a->next_stream_type = save_type;
+    at += nstreams[k];
+    }
+  /* one batch over everything that parsed (jobs of unparsed streams have dst == NULL and are skipped) */
+  if (!trico_hip_decode_jobs(jobs, total))
+    all = 0;
+  /* cursors: behind the last stream of the successful prefix, as the one-by-one reads would leave them */
+  at = 0;
+  for (int k = 0; k < count; ++k)
+    {
+    struct trico_archive* a = (struct trico_archive*)archives[k];
+    for (int s_ = 0; s_ < parsed[k]; ++s_)
+      {
+      if (!jobs[at + s_].ok)
+        {
+        all = 0;
+        break;
+        }
+      if (a->ra_started)
+        drop_readahead(a);
+      a->pos = ends[at + s_];
+      read_next_stream_type(a);
+      }
+    at += nstreams[k];
+    }
+  free(jobs);
+  free(ends);
+  free(parsed);
+  return all;
+  }
 
 /* trico.c:1670-1698 */
 int trico_skip_next_stream(void* archive)
