@@ -102,10 +102,16 @@ bool engine_init()
   return true;
   }
 
-int chains_per_group()
+// Float chains per workgroup (= per compute unit, the workgroups claim most of a unit's LDS).  Measured on the MI355X with 24 /
+// 96 / 192 chains of 50 M values (profiles/r03_batch_decode_experiments.txt): two chains on one unit, on different SIMDs with
+// their parsers on the other two, cost each other 1.5 % (1.797 -> 1.825 s) - what round 2 saw as "two chains on one unit
+// halve each other" was two chain waves on ONE SIMD, not the shared scalar cache.  Four chains per unit do not fit the 16 KiB
+// scalar cache any more (4 x (4 KiB table + 2 KiB ring)): 1.4-2.7 x slower.  So: one chain per unit while the batch leaves
+// half of the GPU to the integer streams decoding beside it, two beyond that; TRICO_FPC32_CHAINS_PER_CU overrides.
+int chains_per_group(uint32_t nchains)
   {
-  static const int v = [] { const char* e = getenv("TRICO_FPC32_CHAINS_PER_CU"); const int x = e ? atoi(e) : 1; return x >= 4 ? 4 : (x >= 2 ? 2 : 1); }();
-  return v;
+  static const int v = [] { const char* e = getenv("TRICO_FPC32_CHAINS_PER_CU"); const int x = e ? atoi(e) : 0; return x >= 4 ? 4 : (x >= 2 ? 2 : (x == 1 ? 1 : 0)); }();
+  return v ? v : (nchains > 128u ? 2 : 1);
   }
 
 enum Kind { K_SKIP = 0, K_FP32, K_FP64, K_INT, K_SINGLE, K_BAD };   // K_SINGLE: straight to the single-stream path
@@ -327,7 +333,7 @@ int trico_hip_decode_jobs(trico_hip_decode_job* jobs, int count)
     if (launched)
       {
       ProfSpan span(TRICO_HIP_K_FPC32_DECODE);
-      launched = launch_fpc32_decode_batch((const Fpc32ChainJob*)E.jobs32.p, k, (uint32_t*)E.scratch32, chains_per_group()) != 0;
+      launched = launch_fpc32_decode_batch((const Fpc32ChainJob*)E.jobs32.p, k, (uint32_t*)E.scratch32, chains_per_group(k)) != 0;
       for (int i = 0; launched && i < count; ++i)
         if (kind[i] == K_FP32)
           launched = decode_sabotage(0, d_dst[i], jobs[i].n, jobs[i].arity, 4) &&

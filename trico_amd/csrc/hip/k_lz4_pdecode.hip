@@ -253,6 +253,35 @@ __global__ void __launch_bounds__(64) k_pd_tiles(PdPlanes P, int second)
     }
   Bytes b;
   stage_tile(lds, in, clen, start, lane, b);
+  if (!second && start != 0u)
+    {
+    // An arbitrary byte inside a run of 0xFF length-extension bytes never falls into step: read as a token it announces a
+    // literal run as long as the whole run of 0xFF says (a plane of 30 KiB matches is 118 such bytes per sequence, and every
+    // tile of it would be left to the serial chain walk).  The run ends with its remainder byte, and behind the remainder of
+    // a MATCH length the next token starts (lz4.c:1702-1710, 1830-1845): start there.  A wrong guess costs nothing but the
+    // speculation: records are only used where the chain really arrives (k_pd_chain).
+    uint32_t q = start;
+    if (b.at(q) == 255u)
+      {
+      uint32_t skipped = 0;
+      for (;;)
+        {
+        const uint32_t pos = q + (uint32_t)lane;
+        const uint64_t stop = __ballot(pos >= clen || b.at(pos) != 255u);
+        if (stop)
+          {
+          q += (uint32_t)__builtin_ctzll(stop);
+          break;
+          }
+        q += 64u;
+        skipped += 64u;
+        if (skipped >= PD_LEAD)
+          break;
+        }
+      if (q + 1u < clen && q + 1u < hi)
+        start = q + 1u;                               // behind the remainder byte
+      }
+    }
   Tile r;
   walk_tile(b, start, lo, hi, r, lane);           // every lane walks the same chain (uniform control flow, LDS broadcast reads)
   if (lane == 0)
@@ -262,7 +291,11 @@ __global__ void __launch_bounds__(64) k_pd_tiles(PdPlanes P, int second)
     }
   }
 
-// One wave follows the chain of tiles from position 0.  seq_base / out_base: sequences and output bytes before the tile.
+// One wave per plane follows the chain of tiles from position 0, 64 tiles per step: lane l looks at tile t + l, a tile is on the
+// chain if its record starts exactly where the tile before it left off (and that is inside the tile), so the longest run of
+// such lanes from lane 0 is accepted at once, with a wave scan for the output positions.  Where the run breaks - the tile's own
+// walk had not fallen into step when it entered the tile, or the chain jumps over tiles (a literal run of megabytes) - the
+// tile the chain really enters is walked from the true token, on the spot.  out_base: output bytes before the tile.
 __global__ void __launch_bounds__(64) k_pd_chain(PdPlanes P, uint32_t n, uint32_t* __restrict__ status)
   {
   const PdPlane& pl = P.p[blockIdx.x];
@@ -272,51 +305,74 @@ __global__ void __launch_bounds__(64) k_pd_chain(PdPlanes P, uint32_t n, uint32_
   uint32_t* onpath = pl.onpath;
   uint32_t* out_base = pl.out_base;
   Ctl* ctl = pl.ctl;
-  constexpr uint32_t WIN = 512;                   // tiles whose records are staged in LDS at a time
-  __shared__ Tile win[WIN];
   __shared__ uint32_t lds[PD_STAGE / 4 + 2];
   const int lane = threadIdx.x;
-  uint32_t w0 = 0xffffffffu;
   uint32_t entry = 0;
   unsigned long long outp = 0;
   uint32_t seqs = 0;
   bool bad = clen == 0u;
-  for (uint32_t guard = 0; !bad && guard <= ntiles; ++guard)
+  bool walked = false;                            // the tile at `entry` has just been walked from `entry`
+  for (uint32_t guard = 0; !bad && guard <= 2u * ntiles + 2u; ++guard)
     {
     const uint32_t t = entry / PD_TILE;
     if (t >= ntiles) { bad = true; break; }
-    if (t < w0 || t >= w0 + WIN)
+    const bool have = t + (uint32_t)lane < ntiles;
+    Tile r;
+    r.first = PD_NONE; r.exit = PD_NONE; r.nseq = 0; r.pad = 0; r.obytes = 0;
+    if (have)
+      r = tiles[t + (uint32_t)lane];
+    // where the chain would enter my tile: where the lane below me left its tile
+    const uint32_t from = (uint32_t)__builtin_amdgcn_update_dpp((int)entry, (int)r.exit, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 <- entry
+    const bool good = have && r.first == from && r.exit != PD_NONE && from / PD_TILE == t + (uint32_t)lane &&
+                      (r.exit == PD_END || r.exit > from);
+    const uint64_t gm = __ballot(good);
+    uint32_t run = gm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~gm);
+    const uint64_t em = __ballot(good && r.exit == PD_END);
+    if (em && (uint32_t)__builtin_ctzll(em) < run)
+      run = (uint32_t)__builtin_ctzll(em) + 1u;
+    if (run == 0u)
       {
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      w0 = t;
-      for (uint32_t i = (uint32_t)lane; i < WIN && w0 + i < ntiles; i += 64u)
-        win[i] = tiles[w0 + i];
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      }
-    Tile r = win[t - w0];
-    if (uni(r.first) != entry)
-      {
-      // the tile's own walk had not fallen into step when it entered the tile (or the chain enters it from far away): walk it
-      // from the true token
+      if (walked) { bad = true; break; }          // walked from the true token and still unusable: malformed
+      // the tile's own walk had not fallen into step when it entered the tile (or the chain enters it from far away)
       Bytes b;
       stage_tile(lds, in, clen, entry, lane, b);
-      walk_tile(b, entry, entry, (t + 1u) * PD_TILE, r, lane);
+      Tile w;
+      walk_tile(b, entry, entry, (t + 1u) * PD_TILE, w, lane);
+      if (uni(w.exit) == PD_NONE) { bad = true; break; }
       if (lane == 0)
-        tiles[t] = r;
+        tiles[t] = w;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+      walked = true;
+      continue;
       }
-    if (uni(r.exit) == PD_NONE) { bad = true; break; }
-    if (lane == 0)
+    walked = false;
+    // inclusive scan of the output bytes and sequences of the accepted lanes
+    unsigned long long ob = (uint32_t)lane < run ? r.obytes : 0ull;
+    uint32_t ns = (uint32_t)lane < run ? r.nseq : 0u;
+    for (int d = 1; d < 64; d <<= 1)
       {
-      onpath[t] = 1u;
-      out_base[t] = (uint32_t)outp;
+      const unsigned long long o2 = __shfl_up(ob, d, 64);
+      const uint32_t n2 = __shfl_up(ns, d, 64);
+      if (lane >= d)
+        {
+        ob += o2;
+        ns += n2;
+        }
       }
-    outp += r.obytes;
-    seqs += r.nseq;
+    const unsigned long long total = __shfl(ob, (int)run - 1, 64);
+    if ((uint32_t)lane < run)
+      {
+      onpath[t + (uint32_t)lane] = 1u;
+      out_base[t + (uint32_t)lane] = (uint32_t)(outp + ob - r.obytes);
+      }
+    outp += total;
+    seqs += (uint32_t)__shfl((int)ns, (int)run - 1, 64);
     if (outp > n) { bad = true; break; }
-    if (uni(r.exit) == PD_END)
+    const uint32_t ex = (uint32_t)__shfl((int)r.exit, (int)run - 1, 64);
+    if (ex == PD_END)
       break;
-    if (uni(r.exit) <= entry) { bad = true; break; }
-    entry = uni(r.exit);
+    if (ex <= entry) { bad = true; break; }
+    entry = ex;
     }
   if (bad || outp != n)
     {
