@@ -16,8 +16,12 @@ roofline  = the float-vertex encoder (north_star's target kernel): algorithmic b
 cpu_baseline = the reference itself (oracle/_ref, built from /root/reference) when that library is
             present, else the oracle port, on the SAME mesh, on this box's host cores: 1 thread (the reference's
             execution model) and one thread per independent stream; `nproc` states the cores of the box.
-other_mesh / pcie_inclusive / decode_concurrent: the same step on the walk mesh, through host pointers, and
-            BASELINE configs[4]'s shape on one GPU (N = 1 only, outside the timed region).
+roofline_all / decode_model: every other stage of the step against the same HBM peak (algorithmic bytes of SURVEY 8(d) /
+            live hipEvent spans), and what bounds the chain decoders: nanoseconds and cycles per value of each component chain.
+other_mesh / pcie_inclusive / decode_concurrent / config3: the same step on the walk mesh, through host pointers, BASELINE
+            configs[4]'s shape on one GPU (8 / 32 / 64 archives decoded as ONE batch, trico_hip_read_archives, with the hardware
+            queue count unset, 4 and 32), and BASELINE configs[2] (double vertices + normals + float uv, + u64 triangles so that the
+            archive is the reference's golden) - N = 1 only, outside the timed region.  --quick skips them.
 `python bench.py --gpus N` starts its N ranks itself (torch.distributed.run, RCCL) when no launcher did.
 """
 import argparse
@@ -32,13 +36,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-# ROCm maps HIP streams onto 4 hardware queues by default and kernels sharing a queue run one after the other; every stream of
-# an archive decodes on its own HIP stream, so the process asks for more BEFORE anything initialises HIP (torch gets there
-# before libtrico does, which only sets this when it makes the first HIP call itself).  16, not more: with every one of 24 or
-# 32 queues busy the hardware scheduler time-slices them, and a decoder chain that is saved and restored on another compute
-# unit loses the table it keeps in that unit's scalar cache (trico_amd/csrc/hip/shim.hip, "the chain decoders and their self-check").
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# (No GPU_MAX_HW_QUEUES here any more: round 2 needed 16 hardware queues because every stream decoded on a HIP stream of its own;
+# the decode engine launches all chains of a batch as one grid on three HIP streams, whatever the process allows.)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
@@ -73,18 +74,12 @@ import torch
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def pmc_traffic(mesh):
-    """HBM bytes per launch sequence of the float-vertex encoder from the newest committed PMC summary
-    (profiles/*_fpc32_encode_hbm_traffic_pmc.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over
-    tools/perf_fpc32.py, the same kernels on the same grid vertices; KB per dispatch).  Corrections per
-    MI355X_MICROARCH.md: KB units, FETCH_SIZE doubled on gfx950.  None when no summary applies to this mesh."""
-    import glob
+def _pmc_file_traffic(path):
+    """(bytes per launch sequence, launches) from a tools/pmc_summary.py text (KB per dispatch; FETCH_SIZE doubled per the
+    gfx950 rule of MI355X_MICROARCH.md, validated for this kernel's reads in profiles/r02_ubench_fetch_size.txt)."""
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_fpc32_encode_hbm_traffic_pmc.txt")))
-    if not files or mesh != "grid":
-        return None, None
     kernel, disp, fetch, write = None, {}, {}, {}
-    for line in open(files[-1]):
+    for line in open(path):
         m = re.match(r"^(\S+) dispatches (\d+)", line)
         if m:
             kernel = m.group(1)
@@ -93,13 +88,47 @@ def pmc_traffic(mesh):
         m = re.match(r"^\s+(FETCH_SIZE|WRITE_SIZE)\s+(\d+) per dispatch", line)
         if m and kernel and kernel.startswith("k_fpc32"):
             (fetch if m.group(1) == "FETCH_SIZE" else write)[kernel] = float(m.group(2)) * disp[kernel]
-    if not fetch or not write:
-        return None, None
     launches = disp.get("k_fpc32_code", 0)
-    if not launches:
+    if not fetch or not write or not launches:
+        return None
+    return int((2.0 * sum(fetch.values()) + sum(write.values())) * 1024.0 / launches)
+
+
+def pmc_traffic(mesh, live=True):
+    """HBM bytes per launch sequence of the float-vertex encoder.  Measured in THIS run when rocprofv3 is there: two child
+    processes, `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, --kernel-trace only beside them) over
+    tools/perf_fpc32.py, the same kernels on the same grid vertices; else the newest committed summary under profiles/.
+    Returns (bytes, source)."""
+    import glob
+    import shutil
+    import tempfile
+    if mesh != "grid":
         return None, None
-    total = (2.0 * sum(fetch.values()) + sum(write.values())) * 1024.0 / launches
-    return int(total), os.path.relpath(files[-1], ROOT)
+    if live and shutil.which("rocprofv3"):
+        tmp = tempfile.mkdtemp(prefix="trico_pmc_", dir="/tmp")
+        try:
+            text = ""
+            for c in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(tmp, c)
+                env = dict(os.environ, TMPDIR="/tmp")
+                subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", d, "--", sys.executable,
+                                os.path.join(ROOT, "tools", "perf_fpc32.py"), "grid"], cwd="/tmp", env=env, timeout=240,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+                text += subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), d], capture_output=True, text=True,
+                                       check=True).stdout
+            f = os.path.join(tmp, "summary.txt")
+            open(f, "w").write(text)
+            t = _pmc_file_traffic(f)
+            if t:
+                return t, "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/perf_fpc32.py grid"
+        except Exception as e:       # no profiler rights, timeout ...: say so and fall back
+            sys.stderr.write("bench.py: live PMC pass failed (%s), using the committed summary\n" % e)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_fpc32_encode_hbm_traffic_pmc.txt")))
+    if not files:
+        return None, None
+    return _pmc_file_traffic(files[-1]), os.path.relpath(files[-1], ROOT) + " (committed summary, not this run)"
 
 
 def parse():
@@ -112,8 +141,9 @@ def parse():
     ap.add_argument("--H", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="full", help="WxH of the CPU baseline's mesh; 'full' = the GPU's own mesh")
-    ap.add_argument("--concurrent", type=int, default=8, help="archives decoded at once in the decode_concurrent block (0: skip)")
+    ap.add_argument("--concurrent", default="8,32,64", help="archives decoded as one batch in the decode_concurrent block ('' : skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the walk mesh, PCIe-inclusive and concurrent-decode blocks")
+    ap.add_argument("--quick", action="store_true", help="headline, roofline and the 1-thread CPU baseline only")
     ap.add_argument("--shard", default="meshes", choices=["meshes", "streams"],
                     help="N > 1: 'meshes' = one mesh per GPU (BASELINE configs[3], weak scaling); 'streams' = ONE mesh, its component "
                          "streams and byte planes spread over the GPUs and assembled into one archive on rank 0 (strong scaling)")
@@ -122,62 +152,87 @@ def parse():
     return ap.parse_args()
 
 
-def _reference_streams_parallel(L, v, t, raw):
-    """SURVEY 8(d) mode (ii): the only parallelism the format offers a CPU — one thread per independent stream (three
-    coordinate streams, four index byte planes), each running the reference's coder on its stream (ctypes releases
-    the GIL).  The de-interleaving into those streams is done before the clock starts."""
+def _reference_streams_parallel(L, v, t, raw, K=1, reps=3):
+    """SURVEY 8(d) mode (ii): the only parallelism the format offers a CPU - one thread per independent stream (three
+    coordinate streams, four index byte planes) of K archives, 7 K threads, each running the reference's coder on its stream
+    (ctypes releases the GIL).  The de-interleaving into those streams is done before the clock starts; every thread touches
+    its output buffers before a common start barrier (pre-faulted); best of `reps` repetitions."""
     import threading
     n, p = v.size // 3, t.size
     comps = [np.ascontiguousarray(v.reshape(-1, 3)[:, c]) for c in range(3)]
     planes = [np.ascontiguousarray(t.view(np.uint8).reshape(-1, 4)[:, k]) for k in range(4)]
     cap = L.LZ4_compressBound(p)
-    lz = [np.empty(cap, np.uint8) for _ in range(4)]
-    fp_out, fp_len, lz_len = [ctypes.c_void_p() for _ in range(3)], [ctypes.c_uint32() for _ in range(3)], [0] * 4
-    back_fp, back_n = [ctypes.c_void_p() for _ in range(3)], [ctypes.c_uint32() for _ in range(3)]
-    back_lz = [np.empty(p, np.uint8) for _ in range(4)]
+    nthreads = 7 * K
+    lz = [[np.empty(cap, np.uint8) for _ in range(4)] for _ in range(K)]
+    back_lz = [[np.empty(p, np.uint8) for _ in range(4)] for _ in range(K)]
+    lz_len = [[0] * 4 for _ in range(K)]
+    fp_out = [[ctypes.c_void_p() for _ in range(3)] for _ in range(K)]
+    fp_len = [[ctypes.c_uint32() for _ in range(3)] for _ in range(K)]
+    back_fp = [[ctypes.c_void_p() for _ in range(3)] for _ in range(K)]
+    back_n = [[ctypes.c_uint32() for _ in range(3)] for _ in range(K)]
+    libc = ctypes.CDLL(None)
+    libc.free.argtypes = [ctypes.c_void_p]
 
     def run(jobs):
-        th = [threading.Thread(target=j) for j in jobs]
-        t0 = time.perf_counter()
+        gate = threading.Barrier(len(jobs) + 1)
+
+        def wrap(prep, work):
+            def f():
+                prep()
+                gate.wait()
+                work()
+            return f
+        th = [threading.Thread(target=wrap(pr, wk)) for pr, wk in jobs]
         for x in th:
             x.start()
+        gate.wait()
+        t0 = time.perf_counter()
         for x in th:
             x.join()
         return time.perf_counter() - t0
 
-    def enc_fp(c):
-        return lambda: L.trico_compress(ctypes.byref(fp_len[c]), ctypes.byref(fp_out[c]), ctypes.c_void_p(comps[c].ctypes.data),
-                                        ctypes.c_uint32(n), ctypes.c_uint32(4), ctypes.c_uint32(10))
+    def enc_fp(k, c):
+        return (lambda: None), (lambda: L.trico_compress(ctypes.byref(fp_len[k][c]), ctypes.byref(fp_out[k][c]), ctypes.c_void_p(comps[c].ctypes.data),
+                                                          ctypes.c_uint32(n), ctypes.c_uint32(4), ctypes.c_uint32(10)))
 
-    def enc_lz(k):
-        def f():
-            lz_len[k] = L.LZ4_compress_default(ctypes.c_void_p(planes[k].ctypes.data), ctypes.c_void_p(lz[k].ctypes.data), p, cap)
-        return f
+    def enc_lz(k, q):
+        def work():
+            lz_len[k][q] = L.LZ4_compress_default(ctypes.c_void_p(planes[q].ctypes.data), ctypes.c_void_p(lz[k][q].ctypes.data), p, cap)
+        return (lambda: lz[k][q].fill(0)), work
 
-    def dec_fp(c):
-        return lambda: L.trico_decompress(ctypes.byref(back_n[c]), ctypes.byref(back_fp[c]), fp_out[c])
+    def dec_fp(k, c):
+        return (lambda: None), (lambda: L.trico_decompress(ctypes.byref(back_n[k][c]), ctypes.byref(back_fp[k][c]), fp_out[k][c]))
 
-    def dec_lz(k):
-        return lambda: L.LZ4_decompress_safe(ctypes.c_void_p(lz[k].ctypes.data), ctypes.c_void_p(back_lz[k].ctypes.data), lz_len[k], p)
+    def dec_lz(k, q):
+        return (lambda: back_lz[k][q].fill(0)), (lambda: L.LZ4_decompress_safe(ctypes.c_void_p(lz[k][q].ctypes.data),
+                                                                                  ctypes.c_void_p(back_lz[k][q].ctypes.data), lz_len[k][q], p))
 
-    enc = run([enc_fp(c) for c in range(3)] + [enc_lz(k) for k in range(4)])
-    dec = run([dec_fp(c) for c in range(3)] + [dec_lz(k) for k in range(4)])
-    ok = all(back_lz[k].tobytes() == planes[k].tobytes() for k in range(4))
-    libc = ctypes.CDLL(None)
-    for c in range(3):
-        ok = ok and ctypes.string_at(back_fp[c].value, 4 * n) == comps[c].tobytes()
-        libc.free(fp_out[c])
-        libc.free(back_fp[c])
-    assert ok
-    return {"value": round(raw / (enc + dec) / 1e9, 4), "unit": "GB/s", "cores": min(7, os.cpu_count() or 1), "threads": 7,
-            "encode_GBps": round(raw / enc / 1e9, 4),
-            "decode_GBps": round(raw / dec / 1e9, 4),
-            "what": "same sample, one thread per independent stream (x, y, z, b1..b4) calling the reference's coder"}
+    enc = dec = None
+    for rep in range(reps):
+        e = run([enc_fp(k, c) for k in range(K) for c in range(3)] + [enc_lz(k, q) for k in range(K) for q in range(4)])
+        d = run([dec_fp(k, c) for k in range(K) for c in range(3)] + [dec_lz(k, q) for k in range(K) for q in range(4)])
+        if rep == reps - 1:
+            ok = all(back_lz[k][q].tobytes() == planes[q].tobytes() for k in (0, K - 1) for q in range(4))
+            for c in range(3):
+                ok = ok and ctypes.string_at(back_fp[K - 1][c].value, 4 * n) == comps[c].tobytes()
+            assert ok
+        for k in range(K):
+            for c in range(3):
+                libc.free(fp_out[k][c])
+                libc.free(back_fp[k][c])
+        enc = e if enc is None or e < enc else enc
+        dec = d if dec is None or d < dec else dec
+    tot = K * raw
+    return {"value": round(tot / (enc + dec) / 1e9, 4), "unit": "GB/s", "archives": K, "threads": nthreads, "cores": min(nthreads, os.cpu_count() or 1),
+            "encode_GBps": round(tot / enc / 1e9, 4), "decode_GBps": round(tot / dec / 1e9, 4), "best_of": reps,
+            "what": "%d archive(s) x 7 independent streams (x, y, z, b1..b4), one thread each calling the reference's coder; buffers "
+                    "pre-faulted, threads released together" % K}
 
 
-def cpu_baseline(mesh, W, H, v, t):
+def cpu_baseline(mesh, W, H, v, t, all_cores_K=()):
     """Times the CPU path on the host cores of this box: encode + decode through the reference's API, 1 thread (the
-    reference's own execution model), and one thread per independent stream (the only parallelism the format offers)."""
+    reference's own execution model), one thread per independent stream (the only parallelism the format offers), and - the
+    shape decode_concurrent gives the GPU - K archives at once on min(nproc, 7 K) cores (`all_cores`)."""
     from oracle import oracle as O
     nv, nt = W * H, 2 * W * H
     raw = v.nbytes + t.nbytes
@@ -204,6 +259,19 @@ def cpu_baseline(mesh, W, H, v, t):
         assert v2.tobytes() == v.tobytes() and t2.tobytes() == t.tobytes()
         enc, dec = t1 - t0, t3 - t2s
         par = _reference_streams_parallel(L, v, t, raw)
+        allc = []
+        for K in all_cores_K:
+            need = K * (4 * (t.size + t.size // 200) + 4 * t.size + 2 * v.nbytes) * 1.3      # LZ4 out + planes back + fp out/back
+            try:
+                import psutil
+                avail = psutil.virtual_memory().available
+            except Exception:
+                avail = 0
+            if (os.cpu_count() or 1) < 7 * K or avail < need:
+                allc.append({"archives": K, "skipped": "needs %d cores and %.0f GB of host memory (box: %d cores, %.0f GB available)"
+                                                       % (7 * K, need / 1e9, os.cpu_count() or 1, avail / 1e9)})
+                continue
+            allc.append(_reference_streams_parallel(L, v, t, raw, K=K))
     else:
         kind = "port"
         t0 = time.perf_counter()
@@ -229,7 +297,8 @@ def cpu_baseline(mesh, W, H, v, t):
         t3 = time.perf_counter()
         enc, dec = t1 - t0, t3 - t2s
         par = None
-    return {"streams_parallel": par, "nproc": os.cpu_count(),
+        allc = []
+    return {"streams_parallel": par, "all_cores": allc, "nproc": os.cpu_count(),
             "value": round(raw / (enc + dec) / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
             "sample": "%s(%d,%d): %d float vertices + %d u32 triangles, %.0f MB raw; encode %.2f s, decode %.2f s"
                       % (mesh, W, H, nv, nt, raw / 1e6, enc, dec),
@@ -297,42 +366,118 @@ def extras(args, api, meshgen, dev, d_v, d_t, nv, nt, raw_bytes):
                              "value": round(raw_bytes / (best[0] + best[1]) / 1e9, 4), "encode_GBps": round(raw_bytes / best[0] / 1e9, 4),
                              "decode_GBps": round(raw_bytes / best[1] / 1e9, 4)}
     del blob, v2, t2
-    # ---- several archives decoded at once (BASELINE configs[4] on one GPU) ----------------------------------------------
-    K = args.concurrent
-    if K > 0:
-        a = api.Archive.open_for_writing(raw_bytes // 4, device=True)
-        assert a.write("vertices", d_v, nv) == 1 and a.write("triangles", d_t, nt) == 1, api.last_error()
-        outs = [(torch.empty_like(d_v), torch.empty_like(d_t)) for _ in range(K)]
-        errs = []
-
-        def decode(k):
-            r = api.Archive.open_for_reading(a.get_buffer_pointer(), a.get_size())
-            if not (r.read("vertices", outs[k][0]) == 1 and r.read("triangles", outs[k][1]) == 1):
-                errs.append(k)
-            r.close()
-
-        res = []
-        for kk in [1, K, K]:                # the second K-way pass finds the device workspaces of the first in the library's pool
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            th = [threading.Thread(target=decode, args=(k,)) for k in range(kk)]
-            for x in th:
-                x.start()
-            for x in th:
-                x.join()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            assert not errs, errs
-            for k in range(kk):
-                assert torch.equal(outs[k][0].view(torch.int32), d_v.view(torch.int32)) and torch.equal(outs[k][1], d_t)
-            res.append({"archives": kk, "seconds": round(dt, 3), "decode_GBps": round(kk * raw_bytes / dt / 1e9, 3),
-                        "workspaces": "pooled" if len(res) == 2 else "first use (hipMalloc inside)"})
-        a.close()
-        out["decode_concurrent"] = {"what": "%d readers of the %s(%d,%d) archive decoding at once on one GPU, one host thread each; "
-                                            "GB/s of decoded bytes, outputs compared bit for bit" % (K, args.mesh, W, H),
-                                    "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "results": res,
-                                    "decode_GBps": res[-1]["decode_GBps"]}
+    # ---- several archives decoded as ONE batch (BASELINE configs[4] on one GPU) -------------------------------------------
+    Ks = [int(k) for k in args.concurrent.split(",") if k.strip()]
+    if Ks:
+        from bench_batch_decode import batch_rows
+        rows = batch_rows(Ks, d_v, d_t, nv, nt, raw_bytes, passes=2)
+        # the same batch with the hardware queue count of the process set to 4 and to 32: child processes (the variable is read
+        # when HIP initialises); round 2's one-launch-per-stream decoder went from 7 GB/s to wrong results between these two
+        variants = []
+        kq = 32 if 32 in Ks else Ks[-1]
+        for q in ("4", "32"):
+            env = dict(os.environ, GPU_MAX_HW_QUEUES=q)
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_batch_decode.py"), "--mesh", args.mesh, "--W", str(W),
+                                    "--H", str(H), "--K", str(kq), "--passes", "1"], env=env, capture_output=True, text=True, timeout=300)
+                line = [x for x in r.stdout.splitlines() if x.startswith("{")]
+                variants.append({"GPU_MAX_HW_QUEUES": q, **json.loads(line[-1])["rows"][0]} if line else {"GPU_MAX_HW_QUEUES": q, "error": r.stderr[-300:]})
+            except Exception as e:
+                variants.append({"GPU_MAX_HW_QUEUES": q, "error": str(e)})
+        out["decode_concurrent"] = {"what": "K readers of the %s(%d,%d) archive decoded as ONE batch (trico_hip_read_archives: every float chain in one "
+                                            "kernel launch, the index streams beside them) on one GPU; GB/s of decoded bytes, outputs compared bit "
+                                            "for bit, `repeats` = chain decodes the self-check sent back" % (args.mesh, W, H),
+                                    "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "results": rows, "queue_count_variants": variants,
+                                    "decode_GBps": max(r["decode_GBps"] for r in rows)}
     return out
+
+
+def decode_model(api, d_v, d_t, nv, nt, raw_bytes):
+    """What bounds the chain decoders: every component chain of the mesh decoded alone (one job of arity 1 per chain through
+    trico_hip_decode_jobs, hipEvent span around kernel + self-check), nanoseconds and cycles per value."""
+    import struct
+    L = api.lib()
+    a = api.Archive.open_for_writing(raw_bytes // 4, device=True)
+    assert a.write("vertices", d_v, nv) == 1, api.last_error()
+    head = bytearray(8 + 5 + 3 * 4 + 64)
+    base = a.get_buffer_pointer()
+    out = torch.empty(nv, dtype=torch.float32, device=d_v.device)
+    ns, pos = {}, 8 + 5
+    spans = ctypes.c_uint64(0)
+    for name in ("x", "y", "z"):
+        sz = (ctypes.c_uint32 * 1)()
+        assert L.trico_hip_copy(ctypes.addressof(sz), base + pos, 4) == 1
+        jobs = api.make_jobs([{"is_int": 0, "arity": 1, "width": 4, "n": nv, "payloads": [(base + pos + 4, sz[0])], "dst": out}])
+        best = None
+        for _ in range(2):
+            L.trico_hip_profile_reset()
+            assert L.trico_hip_decode_jobs(jobs, 1) == 1, api.last_error()
+            ms = L.trico_hip_profile_ms(api.KERNEL_IDS["fpc32_decode"], ctypes.byref(spans))
+            best = ms if best is None or ms < best else best
+        assert torch.equal(out.view(torch.int32), d_v.view(torch.int32)[{"x": 0, "y": 1, "z": 2}[name]::3])
+        ns[name] = round(best * 1e6 / nv, 2)
+        pos += 4 + sz[0]
+    a.close()
+    del head
+    clock_ghz = 2.4
+    return {"ns_per_value": ns, "cycles_per_value": {k: round(v * clock_ghz, 1) for k, v in ns.items()}, "clock_GHz_assumed": clock_ghz,
+            "chains": "one per component stream (fpsc.c:308-326: value i needs value i-1 through both tables); the step time is the slowest "
+                      "chain's n x ns_per_value, whatever the GPU has left",
+            "bound": "issue + scalar-cache latency of ONE wave: 20 scalar instructions per value at 4 cycles each, 37-cycle table load on the "
+                     "dependent path (DESIGN.md 4.5); smooth streams skip batches of exact hits",
+            "algorithmic_GBps_per_chain": {k: round(4.0 / v, 3) for k, v in ns.items()}}
+
+
+def config3_block(api, meshgen, dev, W, H):
+    """BASELINE configs[2]: double vertices + double normals + float uv (+ u64 triangles: the archive is then the reference's
+    golden multi_WxH), device-resident encode and decode; sha256 against tests/golden/hashes.json."""
+    v, nrm, uv, t = meshgen.multi(W, H)
+    n = W * H
+    streams = [("vertices_double", v, n), ("vertex_normals_double", nrm, n), ("uv_per_vertex", uv, n), ("triangles_long", t, 2 * n)]
+    devs = [(name, torch.from_numpy(a.view(np.uint8)).to(dev), cnt) for name, a, cnt in streams]
+    raw = sum(a.nbytes for _, a, _ in streams)
+    fp_raw = v.nbytes + nrm.nbytes + uv.nbytes
+    del v, nrm, uv, t
+    res = None
+    for rep in range(2):
+        a = api.Archive.open_for_writing(raw // 3, device=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for name, d, cnt in devs:
+            assert a.write(name, d, cnt) == 1, api.last_error()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        outs = [torch.empty_like(d) for _, d, _ in devs]
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        r = api.Archive.open_for_reading(a.get_buffer_pointer(), a.get_size())
+        for (name, d, cnt), o in zip(devs, outs):
+            assert r.read(name, o) == 1, api.last_error()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        ok = all(bool(torch.equal(o, d)) for (_, d, _), o in zip(devs, outs))
+        size = a.get_size()
+        sha = hashlib.sha256(a.tobytes()).hexdigest() if rep == 0 else res["sha256"]
+        r.close()
+        a.close()
+        del outs
+        res = {"sha256": sha, "archive_bytes": size, "encode_s": round(t1 - t0, 4), "decode_s": round(t3 - t2, 4), "roundtrip_ok": ok}
+    g = None
+    hp = os.path.join(ROOT, "tests", "golden", "hashes.json")
+    if os.path.exists(hp):
+        g = json.load(open(hp)).get("multi_%dx%d" % (W, H))
+    assert res["roundtrip_ok"]
+    parity = "unchecked (no golden for this size)"
+    if g is not None:
+        if g["sha256"] != res["sha256"]:
+            raise SystemExit("bench.py: config-3 archive sha256 differs from the reference's golden")
+        parity = "sha256 == reference golden"
+    return {"workload": "multi(%d,%d): %d double vertices + double normals + float uv (BASELINE configs[2]) + u64 triangles (the reference's "
+                        "golden archive of this mesh), device-resident" % (W, H, n),
+            "raw_bytes": raw, "floating_point_raw_bytes": fp_raw, "archive_bytes": res["archive_bytes"], "parity": parity,
+            "encode_GBps": round(raw / res["encode_s"] / 1e9, 3), "decode_GBps": round(raw / res["decode_s"] / 1e9, 3),
+            "encode_s": res["encode_s"], "decode_s": res["decode_s"],
+            "value": round(raw / (res["encode_s"] + res["decode_s"]) / 1e9, 4)}
 
 
 def main():
@@ -507,7 +652,23 @@ def main():
         fe = kms.get("fpc32_encode", {"avg_ms": float("nan")})
         alg_bytes = v.nbytes + state["vertex_payload_bytes"]
         achieved = alg_bytes / (fe["avg_ms"] * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(args.mesh)
+        traffic, traffic_src = pmc_traffic(args.mesh, live=(world == 1 and not args.quick))
+        # every other stage of the step against the same peak: algorithmic bytes / live hipEvent span
+        tri_raw = t.nbytes
+        tri_pay = state["archive_bytes"] - 8 - 2 * 5 - 7 * 4 - state["vertex_payload_bytes"]
+        stage_bytes = {"planes_split": 2 * tri_raw, "lz4_encode": tri_raw + tri_pay, "lz4_decode": tri_raw + tri_pay, "planes_merge": 2 * tri_raw,
+                       "fpc32_decode": v.nbytes + state["vertex_payload_bytes"]}
+        stage_bound = {"planes_split": "hbm", "planes_merge": "hbm",
+                       "lz4_encode": "latency of the greedy parse chain per plane, made parallel by chunk speculation (DESIGN.md 4.3)",
+                       "lz4_decode": "hbm traffic of the pointer-jumping rounds, 12 B per output byte and round (DESIGN.md 4.4)",
+                       "fpc32_decode": "one dependent chain per component: see decode_model"}
+        roofline_all = []
+        for name in ("planes_split", "lz4_encode", "fpc32_decode", "lz4_decode", "planes_merge"):
+            if name in kms and sharded is False:
+                ms = kms[name]["avg_ms"]
+                gb = stage_bytes[name] / (ms * 1e-3) / 1e9
+                roofline_all.append({"stage": name, "algorithmic_bytes": stage_bytes[name], "avg_ms": ms, "achieved": round(gb, 2), "unit": "GB/s",
+                                     "peak": HBM_PEAK_GBPS, "frac": round(gb / HBM_PEAK_GBPS, 5), "bound": stage_bound[name]})
         out = {
             "metric": "encode+decode GB/s (input bytes)",
             "value": round(total_raw / step_s / 1e9, 4),
@@ -527,21 +688,29 @@ def main():
             "encode_GBps": round(total_raw / (elapsed[1] / args.steps) / 1e9, 4),
             "decode_GBps": round(total_raw / (elapsed[3] / args.steps) / 1e9, 4),
             "gather_ms": round(elapsed[2] / args.steps * 1e3, 3),
-            "roofline": {"kernel": "float-vertex encoder (k_fpc32_index + scan + k_fpc32_code + offsets + gather)",
+            "roofline": {"kernel": "float-vertex encoder (every kernel of its launch sequence, AoS vertices -> payload bytes in the archive)",
                          "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fe["avg_ms"]},
+            "roofline_all": roofline_all,
             "kernels": kms,
         }
-        if world == 1 and not args.no_extras:
+        Ks = [int(k) for k in args.concurrent.split(",") if k.strip()]
+        if world == 1 and not args.no_extras and not args.quick:
+            out["decode_model"] = decode_model(api, d_v, d_t, nv, nt, raw_bytes)
             out.update(extras(args, api, meshgen, dev, d_v, d_t, nv, nt, raw_bytes))
+            if args.mesh == "grid":
+                del d_v2, d_t2
+                torch.cuda.empty_cache()
+                out["config3"] = config3_block(api, meshgen, dev, W, H)
         if world == 1 and not args.no_cpu_baseline:
+            allK = tuple(k for k in Ks if k in (8, 32)) if not (args.no_extras or args.quick) else ()
             if args.cpu_sample == "full":
-                out["cpu_baseline"] = cpu_baseline(args.mesh, W, H, v, t)
+                out["cpu_baseline"] = cpu_baseline(args.mesh, W, H, v, t, allK)
             else:
                 cw, ch = (int(x) for x in args.cpu_sample.split("x"))
                 cv, ct = gen(cw, ch)
-                out["cpu_baseline"] = cpu_baseline(args.mesh, cw, ch, cv, ct)
+                out["cpu_baseline"] = cpu_baseline(args.mesh, cw, ch, cv, ct, allK)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if unit_encoder is not None:

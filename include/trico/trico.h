@@ -28,9 +28,7 @@
 extern "C" {
 #endif
 
-#ifndef TRICO_API
-#define TRICO_API __attribute__((visibility("default")))
-#endif
+#include "trico_api.h"
 
 /* reference: trico/trico.h:11-34 */
 enum trico_stream_type

@@ -19,9 +19,7 @@
 extern "C" {
 #endif
 
-#ifndef TRICO_API
-#define TRICO_API __attribute__((visibility("default")))
-#endif
+#include "trico_api.h"
 
 typedef struct trico_hip_ctx trico_hip_ctx;   /* per-archive device workspace (not thread-shared) */
 

@@ -144,3 +144,31 @@ def test_container_walk_under_sanitizers_on_mutated_archives(tmp_path, gold_dir)
         assert r.returncode == 0 and "ERROR" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
         opened += r.stdout.count("opened=1")
     assert opened >= len(src)
+
+
+def test_cmake_package_builds_a_consumer(native_libs, tmp_path):
+    """cmake/trico-config.cmake: a consumer written for the reference's CMake target names (`trico`, `trico_io`, headers
+    <trico/alloc.h>, <trico/trico.h>, <trico_io/iostl.h>) configures and links against this repo's libraries."""
+    import shutil
+    import subprocess
+    cmake = shutil.which("cmake")
+    if not cmake:
+        pytest.skip("no cmake")
+    src = tmp_path / "src"
+    src.mkdir()
+    (src / "main.c").write_text(
+        "#include <trico/alloc.h>\n#include <trico/trico.h>\n#include <trico_io/iostl.h>\n#include <stdio.h>\n"
+        "int main(void)\n{\n  void* a = trico_open_archive_for_writing(64);\n  if (!a) return 1;\n"
+        "  printf(\"%llu\\n\", (unsigned long long)trico_get_size(a));\n  trico_close_archive(a);\n"
+        "  float* p = (float*)trico_malloc(16);\n  trico_free(p);\n  return 0;\n}\n")
+    (src / "CMakeLists.txt").write_text(
+        "cmake_minimum_required(VERSION 3.10)\nproject(consumer C)\n"
+        "find_package(trico CONFIG REQUIRED PATHS \"%s\" NO_DEFAULT_PATH)\n"
+        "add_executable(consumer main.c)\ntarget_link_libraries(consumer PRIVATE trico_io trico)\n" % os.path.join(ROOT, "cmake"))
+    bld = tmp_path / "bld"
+    r = subprocess.run([cmake, "-S", str(src), "-B", str(bld)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([cmake, "--build", str(bld)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([str(bld / "consumer")], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "8", r.stdout + r.stderr        # the empty archive: magic + version

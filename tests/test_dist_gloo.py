@@ -1,6 +1,7 @@
 """CPU tier: the N>1 path (one process per rank, shard independent units, size exchange + point-to-point
-gather of variable-length archives onto rank 0) on the gloo backend with world_size 2 and 3.  The bytes
-gathered are oracle archives, so the test also shows that per-rank archives are position independent."""
+gather of variable-length archives onto rank 0) on the gloo backend with world_size 2, 3 and 8 (the shape of
+BASELINE configs[3]: one mesh per rank, seeds GRID_SEED + rank; and 7 stream units over 8 ranks, one rank idle).
+The bytes gathered are oracle archives, so the test also shows that per-rank archives are position independent."""
 import os
 import sys
 
@@ -13,7 +14,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n_units=5):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -22,7 +23,6 @@ def _worker(rank, world, port, q):
     from oracle import oracle as O
     from trico_amd import meshgen
     from trico_amd.parallel import gather_archives, shard_units, split_archives
-    n_units = 5
     mine = shard_units(n_units, world, rank)
     blobs = []
     for u in mine:
@@ -44,16 +44,18 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_gather_archives_gloo(world, native_libs):
+@pytest.mark.parametrize("world,n_units", [(2, 5), (3, 5), (8, 8), (8, 5)])
+def test_gather_archives_gloo(world, n_units, native_libs):
+    """(8, 8): BASELINE configs[3]'s shape - eight ranks, one mesh each (seeds GRID_SEED + rank), archives gathered on rank 0;
+    (8, 5): three ranks own nothing and still take part in the exchange."""
     sys.path.insert(0, ROOT)
     from oracle import oracle as O
     from trico_amd import meshgen
     from trico_amd.parallel import shard_units
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + world * 7 + (os.getpid() % 500)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 29500 + world * 7 + n_units * 3 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, n_units)) for r in range(world)]
     for p in procs:
         p.start()
     sizes, parts = q.get(timeout=120)
@@ -63,7 +65,7 @@ def test_gather_archives_gloo(world, native_libs):
     # expected: per rank, its units' archives concatenated in unit order
     for r in range(world):
         want = b""
-        for u in shard_units(5, world, r):
+        for u in shard_units(n_units, world, r):
             v, t = meshgen.grid(24 + u, 10, meshgen.GRID_SEED + u)
             a = O.OracleArchive()
             a.write("vertices", v, (24 + u) * 10)
@@ -115,7 +117,7 @@ def _shard_worker(rank, world, port, kind, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,kind", [(2, "grid"), (3, "grid"), (3, "multi")])
+@pytest.mark.parametrize("world,kind", [(2, "grid"), (3, "grid"), (3, "multi"), (8, "grid")])
 def test_stream_sharded_archive_is_the_single_rank_archive(world, kind, native_libs):
     """Rank r encodes units r, r + world, ... of ONE mesh (x, y, z, b1..b4; for `multi` 3 + 3 + 2 components and 8 planes);
     the root frames the gathered payloads with trico_hip_append_encoded_stream.  The result must be the archive the

@@ -240,7 +240,8 @@ __global__ void __launch_bounds__(64) k_pd_tiles(PdPlanes P, int second)
     // second round: where the predecessor's walk of the first round left its tile.  Even if that walk started at a wrong
     // byte, it has normally fallen into step with the real chain within its 8 KiB, so this is a real token.
     const uint32_t e = t ? pl.tiles0[t - 1].exit : PD_NONE;
-    if (t == 0 || e < lo || e >= hi)
+    // (a tile whose first-round walk already began exactly where its predecessor arrived has nothing to gain either)
+    if (t == 0 || e < lo || e >= hi || e == pl.tiles0[t].first)
       {
       if (lane == 0)
         {
@@ -519,7 +520,28 @@ __global__ void __launch_bounds__(256) k_pd_jump(PdPlanes P, uint32_t n)
   if (pl.clen == 0u || ctl->done || ctl->error)
     return;
   bool changed = false;
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
+  // four words per thread (the workspace is 256-byte aligned): 16-byte loads of the words, dword gathers only where a word
+  // is not final yet.  Words are read and written while other threads jump them: any value seen is final or an earlier byte.
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const uint32_t n4 = n >> 2;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u)
+    {
+    u32x4 w = __builtin_nontemporal_load((const u32x4*)src + i);
+    bool mine = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (!(w[k] & PD_FINAL))
+        {
+        w[k] = __hip_atomic_load(&src[w[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mine = true;
+        }
+    if (mine)
+      {
+      *((u32x4*)src + i) = w;
+      changed = true;
+      }
+    }
+  for (uint32_t i = 4u * n4 + blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
     {
     const uint32_t s = src[i];
     if (!(s & PD_FINAL))

@@ -111,6 +111,16 @@ def hip_unit_encoder(api):
     return encode
 
 
+def collective_device(dist):
+    """Device the tensors of a collective must live on: the current GPU under nccl (= RCCL), the CPU under gloo.  A rank
+    that owns no unit (world > units: the 7 units of a vertices + triangles mesh on 8 GPUs) still takes part in every
+    collective, and must do so with tensors of the backend's device."""
+    backend = str(dist.get_backend()).lower()
+    if "nccl" in backend and torch.cuda.is_available():
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
 def sharded_write(dist, api, streams, encode_unit, root=0, device_archive=False, gather=None):
     """All ranks call this with the same `streams` = [(name, data, count)] (every rank holds, or can read, the whole
     mesh).  Each rank encodes its units with `encode_unit(name, data, count, unit) -> uint8 tensor`, the payloads are
@@ -120,7 +130,7 @@ def sharded_write(dist, api, streams, encode_unit, root=0, device_archive=False,
     units = stream_units(streams)
     mine = shard_units(len(units), world, rank)
     payloads = [encode_unit(streams[units[u][0]][0], streams[units[u][0]][1], streams[units[u][0]][2], units[u][1]) for u in mine]
-    dev = payloads[0].device if payloads else torch.device("cpu")
+    dev = payloads[0].device if payloads else collective_device(dist)
     # every rank's unit sizes, padded to the same length: one small all-gather
     per = (len(units) + world - 1) // world
     mysz = torch.zeros(per, dtype=torch.int64, device=dev)
