@@ -183,3 +183,31 @@ def test_product_library_has_no_sabotage_switch():
     env["TRICO_HIP_DECODE_SABOTAGE"] = "3"
     out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "BATCH OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_payload_of_another_writer_is_decoded_and_counted(api):
+    """A float stream whose codes are decodable but not the ones the reference's encoder picks (value 2 of eight 1.0f: an exact
+    FCM hit written as code 1 with a zero byte instead of code 0).  The self-check cannot code the values back to these bytes;
+    after the repeat ladder the reference-order kernel's values stand, and word 3 of trico_hip_last_stats counts the stream."""
+    import struct
+    pay = bytes.fromhex("25" "00000008" "00006c" "3f800000" "00" "00")
+    blob = struct.pack("<II", 0x6f637254, 0) + bytes([15]) + struct.pack("<I", 8) + struct.pack("<I", len(pay)) + pay
+    stats = (ctypes.c_uint32 * 4)()
+    api.lib().trico_hip_last_stats(stats)
+    before = stats[3]
+    r = api.Archive.open_for_reading(blob)
+    got = r.read_alloc("attributes_float", 8, np.float32)
+    assert got is not None, api.last_error()
+    assert got.tolist() == [1.0] * 8
+    r.close()
+    api.lib().trico_hip_last_stats(stats)
+    assert stats[3] == before + 1
+    # the canonical payload of the same values raises no flag
+    pay = bytes.fromhex("25" "00000008" "00002c" "3f800000" "00")
+    blob = struct.pack("<II", 0x6f637254, 0) + bytes([15]) + struct.pack("<I", 8) + struct.pack("<I", len(pay)) + pay
+    r = api.Archive.open_for_reading(blob)
+    got = r.read_alloc("attributes_float", 8, np.float32)
+    assert got is not None and got.tolist() == [1.0] * 8
+    r.close()
+    api.lib().trico_hip_last_stats(stats)
+    assert stats[3] == before + 1

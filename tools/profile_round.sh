@@ -1,15 +1,28 @@
-# Collects the profiles committed under profiles/: kernel trace of bench.py and PMC passes over the float encoder.
-# usage (GPU box): bash tools/profile_round.sh <tag>
+# Collects the profiles committed under profiles/ (round 3 layout).  usage (GPU box): bash tools/profile_round.sh <tag>
+#   <tag>_bench_config2.json / _kernel_stats.txt      bench.py --quick under rocprofv3 --kernel-trace --stats
+#   <tag>_bench_config2_unprofiled.json               the full bench.py line, no profiler attached
+#   <tag>_fpc32_encode_kernel_stats.txt               the float-vertex encoder ALONE (tools/perf_fpc32.py grid): per-kernel durations
+#   <tag>_fpc32_encode_hbm_traffic_pmc.txt            --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, same program
+#   <tag>_fpc32_encode_sq_counters.txt                SQ instruction / cycle counters, same program
+#   <tag>_lz4_kernel_stats.txt                        tools/perf_lz4.py grid and walk: per-kernel durations of the LZ4 codec
+#   <tag>_device_archive_open_hip_api.txt             hipMemcpy* calls to walk the framing of a device-resident archive
 set -e
-TAG=${1:-r01}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-echo "== kernel trace of bench.py"
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python $R/bench.py --steps 3 --warmup 1 > $O/bench.json 2> $O/bench.err
+echo "== full bench, no profiler"
+timeout -k 10 600 python $R/bench.py --steps 3 --warmup 1 > $O/${TAG}_bench_config2_unprofiled.json 2> $O/bench_unprofiled.err
+echo "== kernel trace of bench.py --quick"
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python $R/bench.py --quick --steps 3 --warmup 1 > $O/${TAG}_bench_config2.json 2> $O/bench.err
 python $R/tools/prof_summary.py $O/bench > $O/${TAG}_bench_config2_kernel_stats.txt
-cp $O/bench.json $O/${TAG}_bench_config2.json
+echo "== encoder alone: kernel trace"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/enc -- python $R/tools/perf_fpc32.py grid > $O/enc.log 2>&1
+{ echo "# rocprofv3 --kernel-trace --stats -- python tools/perf_fpc32.py grid: the float-vertex encoder alone on the 50 M config-2 vertices (6 encodes,"
+  echo "# payloads gathered to a device buffer with one launch per component; no decoder, no self-check traffic beside it)"
+  grep "kernel span" $O/enc.log
+  python $R/tools/prof_summary.py $O/enc; } > $O/${TAG}_fpc32_encode_kernel_stats.txt
 echo "== PMC: HBM traffic of the float encoder (separate passes)"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $R/tools/perf_fpc32.py grid > $O/pmc_$c.log 2>&1
@@ -22,6 +35,31 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_sq2 -- python $R/tools/perf_fpc32.py grid > $O/pmc_sq2.log 2>&1
 { echo "# rocprofv3 SQ counters of the float encoder sweeps (tools/perf_fpc32.py grid), per dispatch"
   python $R/tools/pmc_summary.py $O/pmc_sq1; python $R/tools/pmc_summary.py $O/pmc_sq2; } > $O/${TAG}_fpc32_encode_sq_counters.txt
-grep "kernel span" $O/pmc_sq1.log || true
-rm -rf $O/bench $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_sq1 $O/pmc_sq2
+echo "== LZ4 codec: kernel traces"
+for m in grid walk; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lz4_$m -- python $R/tools/perf_lz4.py $m > $O/lz4_$m.log 2>&1
+done
+{ for m in grid walk; do
+    echo "# rocprofv3 --kernel-trace --stats -- python tools/perf_lz4.py $m: byte planes + LZ4 of the 100 M config-2 triangles, 3 encodes + 2 decodes"
+    grep -E "encode iter 2|decode iter 1" $O/lz4_$m.log
+    python $R/tools/prof_summary.py $O/lz4_$m
+  done; } > $O/${TAG}_lz4_kernel_stats.txt
+echo "== device-resident archive: HIP API calls to read the framing"
+for m in upload open; do
+  timeout -k 10 200 rocprofv3 --hip-trace --stats --output-format csv -d $O/hip_$m -- python $R/tools/trace_device_open.py $m > $O/hip_$m.log 2>&1
+done
+{ echo "# rocprofv3 --hip-trace --stats -- python tools/trace_device_open.py {upload|open}: tests/golden/allstreams.trc (18 streams, 44 frames) in device memory."
+  echo "# 'upload' = torch moves the archive to the GPU and nothing else; 'open' = the same + trico_open_archive_for_reading on the device pointer,"
+  echo "# trico_hip_list_streams and a skip of every stream (all type / count / size fields are read).  Calls per HIP memcpy entry point:"
+  for m in upload open; do
+    echo "## $m"; cat $O/hip_$m.log | grep -v "^[WE]2" | tail -2
+    python - $O/hip_$m <<'PY'
+import csv, glob, sys
+for f in glob.glob(sys.argv[1] + "/**/*hip_api_stats.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "emcpy" in r["Name"] or "LaunchKernel" in r["Name"] or "StreamSynchronize" in r["Name"]:
+            print("   %-40s calls %s" % (r["Name"], r["Calls"]))
+PY
+  done; } > $O/${TAG}_device_archive_open_hip_api.txt
+rm -rf $O/bench $O/enc $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_sq1 $O/pmc_sq2 $O/lz4_grid $O/lz4_walk $O/hip_upload $O/hip_open
 ls -la $O
