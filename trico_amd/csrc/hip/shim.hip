@@ -528,13 +528,17 @@ int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int
 // from some value on — silently: the payload is well-formed.  (Twelve and more archives decoded at once with 32 queues: 20-40 %
 // of the noisy streams; eight archives, or sixteen queues: none in hundreds of runs; write-through stores (glc) cure it at eight
 // times the time per value.)  Therefore:
-//   * libtrico asks for 16 hardware queues when it initialises HIP itself (device_ready), and INTEGRATION.md tells a host
-//     application to stay at or below that;
+//   * the library itself no longer creates that situation: all chains of a batch are ONE kernel launch on one of three HIP
+//     streams (engine.hip), whatever the number of archives, so it needs no queue setting and makes none (round 2 set
+//     GPU_MAX_HW_QUEUES=16 here);
+//   * the two waves of a chain wait for each other with a bound (k_fpc32_decode.hip: SPIN_LIMIT_*): counters that went stale
+//     end the kernel with FPC_STATUS_TIMEOUT instead of hanging it, and the host repeats the stream;
 //   * every decode of these kernels is CHECKED: the decoded values are coded again with the throughput encoder (1 ms for 50 M
 //     float vertices, 25 ms for doubles) and the bytes compared with the payload on the device.  The coder is a deterministic
 //     function of the values and the decoder of the payload, so equal payloads mean the values are the payload's values.  A
 //     stream that fails is decoded again: twice more by the same kernel, then by the reference-order kernel of k_serial.hip,
-//     which does not use the scalar cache (20x slower; trico_hip_last_stats word 2 counts the repeats).
+//     which does not use the scalar cache (20x slower; trico_hip_last_stats word 2 counts the repeats).  That last rung is
+//     checked as well; values of it that do not code back mean a payload the reference's encoder did not write (word 3).
 //     TRICO_HIP_DECODE_CHECK=0 switches the check off (measurements only).
 
 } // extern "C"
