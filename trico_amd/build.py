@@ -28,7 +28,7 @@ HIP_HDR = sorted(f for f in os.listdir(os.path.join(CSRC, "hip")) if f.endswith(
 
 LIBTRICO = os.path.join(LIBDIR, "libtrico.so")
 LIBTRICO_HOOKS = os.path.join(LIBDIR, "libtrico_testhooks.so")    # same library + the decode sabotage switch (tests only)
-HOOKED = ("shim.hip",)                                             # sources that look at TRICO_HIP_TEST_HOOKS
+HOOKED = ("shim.hip", "dist.hip")                                             # sources that look at TRICO_HIP_TEST_HOOKS
 LIBMESHGEN = os.path.join(LIBDIR, "libtrico_meshgen.so")
 LIBIO = os.path.join(LIBDIR, "libtrico_io.so")
 BINDIR = os.path.join(HERE, "bin")

@@ -131,10 +131,15 @@ bool rccl_ready()
     g_rccl.GroupStart = (int (*)())sym("ncclGroupStart");
     g_rccl.GroupEnd = (int (*)())sym("ncclGroupEnd");
     g_rccl.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    // the declarations above are the ABI of RCCL / NCCL 2.x (128-byte unique id by value, these enum values): refuse anything else
+    int (*get_version)(int*) = (int (*)(int*))sym("ncclGetVersion");
+    int version = 0;
+    if (ok && (get_version(&version) != 0 || version < 20000 || version >= 30000))
+      ok = false;
     g_rccl_state = ok ? 1 : -1;
     }
   if (g_rccl_state < 0)
-    set_error("RCCL (librccl.so) could not be loaded");
+    set_error("RCCL (librccl.so, version 2.x) could not be loaded");
   return g_rccl_state > 0;
   }
 
@@ -150,12 +155,110 @@ bool rccl_ok(int r, const char* what)
 
 } // namespace
 
+#ifdef TRICO_HIP_TEST_HOOKS
+// Test transport (libtrico_testhooks.so only): the ranks of a "job" are THREADS of one process on one GPU, and the four RCCL
+// calls trico_hip_comm_gather makes are played by a rendezvous in host memory plus hipMemcpy between the ranks' device buffers.
+// It exists so that the offset arithmetic and the call pattern of the gather (sizes, verdict of the root, one transfer per
+// non-empty rank, empty ranks, a root that is not rank 0) can be tested with more than one rank on a box with one GPU.
+#include <condition_variable>
+namespace {
+struct FakeGroup
+  {
+  std::mutex mu;
+  std::condition_variable cv;
+  int world = 0, arrived = 0, generation = 0;
+  const void* gather_src[64];
+  struct Msg { const void* src; size_t bytes; bool posted; } send[64];      // one outstanding send per source rank
+  };
+FakeGroup g_fake;
+struct FakeComm { int rank; };
+
+void fake_barrier(std::unique_lock<std::mutex>& lk)
+  {
+  const int gen = g_fake.generation;
+  if (++g_fake.arrived == g_fake.world)
+    {
+    g_fake.arrived = 0;
+    ++g_fake.generation;
+    g_fake.cv.notify_all();
+    }
+  else
+    g_fake.cv.wait(lk, [&] { return g_fake.generation != gen; });
+  }
+
+int fake_all_gather(const void* send, void* recv, size_t count, int type, rcclComm_t comm, hipStream_t st)
+  {
+  const size_t esz = type == RCCL_UINT64 ? 8 : 1;
+  FakeComm* fc = (FakeComm*)comm;
+  (void)hipStreamSynchronize(st);
+  std::unique_lock<std::mutex> lk(g_fake.mu);
+  g_fake.gather_src[fc->rank] = send;
+  fake_barrier(lk);
+  for (int r = 0; r < g_fake.world; ++r)
+    if (hipMemcpy((uint8_t*)recv + (size_t)r * count * esz, g_fake.gather_src[r], count * esz, hipMemcpyDeviceToDevice) != hipSuccess)
+      return 1;
+  fake_barrier(lk);                                   // nobody changes its send buffer before everybody has read it
+  return 0;
+  }
+int fake_send(const void* src, size_t count, int, int, rcclComm_t comm, hipStream_t st)
+  {
+  FakeComm* fc = (FakeComm*)comm;
+  (void)hipStreamSynchronize(st);
+  std::unique_lock<std::mutex> lk(g_fake.mu);
+  g_fake.send[fc->rank] = FakeGroup::Msg{ src, count, true };
+  g_fake.cv.notify_all();
+  g_fake.cv.wait(lk, [&] { return !g_fake.send[fc->rank].posted; });       // until the root has taken it
+  return 0;
+  }
+int fake_recv(void* dst, size_t count, int, int peer, rcclComm_t, hipStream_t st)
+  {
+  (void)hipStreamSynchronize(st);
+  std::unique_lock<std::mutex> lk(g_fake.mu);
+  g_fake.cv.wait(lk, [&] { return g_fake.send[peer].posted; });
+  const FakeGroup::Msg m = g_fake.send[peer];
+  const int rc = (m.bytes == count && hipMemcpy(dst, m.src, count, hipMemcpyDeviceToDevice) == hipSuccess) ? 0 : 1;
+  g_fake.send[peer].posted = false;
+  g_fake.cv.notify_all();
+  return rc;
+  }
+int fake_ok() { return 0; }
+int fake_destroy(rcclComm_t comm) { delete (FakeComm*)comm; return 0; }
+const char* fake_error(int) { return "fake transport error"; }
+} // namespace
+#endif
+
 struct trico_hip_comm
   {
   rcclComm_t comm = nullptr;
   int rank = 0, world = 1;
   uint64_t* d_sizes = nullptr;     // world + 1 words: [0] mine, [1..] everybody's
+  Rccl tr;                         // the transport of this communicator: RCCL, or the test transport
   };
+
+#ifdef TRICO_HIP_TEST_HOOKS
+extern "C" TRICO_API trico_hip_comm* trico_hip_comm_create_fake(int rank, int world)
+  {
+  if (world < 1 || world > 64 || rank < 0 || rank >= world || !trico_hip_available())
+    return nullptr;
+  {
+  std::lock_guard<std::mutex> lk(g_fake.mu);
+  g_fake.world = world;
+  g_fake.send[rank].posted = false;
+  }
+  trico_hip_comm* c = new trico_hip_comm;
+  c->rank = rank;
+  c->world = world;
+  c->comm = new FakeComm{ rank };
+  c->tr = Rccl{ nullptr, nullptr, fake_destroy, fake_all_gather, fake_send, fake_recv, fake_ok, fake_ok, fake_error };
+  if (!hip_ok(hipMalloc((void**)&c->d_sizes, sizeof(uint64_t) * (size_t)(world + 1)), "hipMalloc(comm sizes)"))
+    {
+    delete (FakeComm*)c->comm;
+    delete c;
+    return nullptr;
+    }
+  return c;
+  }
+#endif
 
 int trico_hip_comm_unique_id(uint8_t id[128])
   {
@@ -175,6 +278,7 @@ trico_hip_comm* trico_hip_comm_create(const uint8_t id[128], int rank, int world
   trico_hip_comm* c = new trico_hip_comm;
   c->rank = rank;
   c->world = world;
+  c->tr = g_rccl;
   rcclUniqueId u;
   memcpy(u.internal, id, 128);
   if (!rccl_ok(g_rccl.CommInitRank(&c->comm, world, u, rank), "ncclCommInitRank") ||
@@ -194,7 +298,7 @@ void trico_hip_comm_destroy(trico_hip_comm* c)
     return;
   (void)hipStreamSynchronize(current_stream());
   if (c->comm)
-    (void)g_rccl.CommDestroy(c->comm);
+    (void)c->tr.CommDestroy(c->comm);
   if (c->d_sizes)
     (void)hipFree(c->d_sizes);
   delete c;
@@ -211,7 +315,7 @@ int trico_hip_comm_gather(trico_hip_comm* c, const void* d_local, uint64_t local
   hipStream_t st = current_stream();
   // 1. everybody learns everybody's size (one all-gather of the compressed sizes)
   TRICO_HIP_TRY(hipMemcpyAsync(c->d_sizes, &local_bytes, sizeof(uint64_t), hipMemcpyHostToDevice, st));
-  if (!rccl_ok(g_rccl.AllGather(c->d_sizes, c->d_sizes + 1, 1, RCCL_UINT64, c->comm, st), "ncclAllGather(sizes)"))
+  if (!rccl_ok(c->tr.AllGather(c->d_sizes, c->d_sizes + 1, 1, RCCL_UINT64, c->comm, st), "ncclAllGather(sizes)"))
     return 0;
   TRICO_HIP_TRY(hipMemcpyAsync(sizes, c->d_sizes + 1, sizeof(uint64_t) * (size_t)c->world, hipMemcpyDeviceToHost, st));
   TRICO_HIP_TRY(hipStreamSynchronize(st));
@@ -224,7 +328,7 @@ int trico_hip_comm_gather(trico_hip_comm* c, const void* d_local, uint64_t local
   // all-gather, so that nobody posts a transfer the root will not match
   uint64_t verdict = (c->rank == root && (total > root_capacity || (total && !d_root))) ? 1u : 0u;
   TRICO_HIP_TRY(hipMemcpyAsync(c->d_sizes, &verdict, sizeof(uint64_t), hipMemcpyHostToDevice, st));
-  if (!rccl_ok(g_rccl.AllGather(c->d_sizes, c->d_sizes + 1, 1, RCCL_UINT64, c->comm, st), "ncclAllGather(verdict)"))
+  if (!rccl_ok(c->tr.AllGather(c->d_sizes, c->d_sizes + 1, 1, RCCL_UINT64, c->comm, st), "ncclAllGather(verdict)"))
     return 0;
   uint64_t root_verdict = 0;
   TRICO_HIP_TRY(hipMemcpyAsync(&root_verdict, c->d_sizes + 1 + root, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
@@ -235,16 +339,16 @@ int trico_hip_comm_gather(trico_hip_comm* c, const void* d_local, uint64_t local
   if (c->rank == root)
     {
     uint64_t off = 0;
-    if (!rccl_ok(g_rccl.GroupStart(), "ncclGroupStart"))
+    if (!rccl_ok(c->tr.GroupStart(), "ncclGroupStart"))
       return 0;
     bool ok = true;
     for (int r = 0; r < c->world; ++r)
       {
       if (r != root && sizes[r])
-        ok = ok && rccl_ok(g_rccl.Recv((uint8_t*)d_root + off, (size_t)sizes[r], RCCL_UINT8, r, c->comm, st), "ncclRecv");
+        ok = ok && rccl_ok(c->tr.Recv((uint8_t*)d_root + off, (size_t)sizes[r], RCCL_UINT8, r, c->comm, st), "ncclRecv");
       off += sizes[r];
       }
-    if (!rccl_ok(g_rccl.GroupEnd(), "ncclGroupEnd") || !ok)
+    if (!rccl_ok(c->tr.GroupEnd(), "ncclGroupEnd") || !ok)
       return 0;
     uint64_t mine = 0;
     for (int r = 0; r < root; ++r)
@@ -254,7 +358,7 @@ int trico_hip_comm_gather(trico_hip_comm* c, const void* d_local, uint64_t local
     }
   else if (local_bytes)
     {
-    if (!rccl_ok(g_rccl.Send(d_local, (size_t)local_bytes, RCCL_UINT8, root, c->comm, st), "ncclSend"))
+    if (!rccl_ok(c->tr.Send(d_local, (size_t)local_bytes, RCCL_UINT8, root, c->comm, st), "ncclSend"))
       return 0;
     }
   TRICO_HIP_TRY(hipStreamSynchronize(st));
