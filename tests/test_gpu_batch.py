@@ -211,3 +211,12 @@ def test_payload_of_another_writer_is_decoded_and_counted(api):
     r.close()
     api.lib().trico_hip_last_stats(stats)
     assert stats[3] == before + 1
+
+
+def test_lds_only_decoder_as_first_choice():
+    """TRICO_HIP_DECODE_ROBUST=1: float chains decoded by k_fpc32_decode_robust (tables, ring and counters in LDS, nothing behind the
+    scalar cache) instead of the scalar chain - same values, through the batch engine and through the single-stream path."""
+    env = dict(os.environ)
+    env["TRICO_HIP_DECODE_ROBUST"] = "1"
+    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "BATCH OK" in out.stdout, out.stdout + out.stderr

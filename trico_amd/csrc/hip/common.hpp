@@ -145,6 +145,10 @@ int launch_fpc32_decode(const uint8_t* const d_payloads[3], const uint32_t sizes
                         uint32_t* d_status, uint32_t* d_tables);
 // every chain of a batch in one launch: d_jobs = device table, d_scratch = FPC32_DECODE_TABLE_BYTES per chain
 int launch_fpc32_decode_batch(const Fpc32ChainJob* d_jobs, uint32_t njobs, uint32_t* d_scratch, int chains_per_group);
+// the same chains with tables, ring and counters in LDS (nothing behind the scalar cache): ~2 x the time per value, survives a
+// save / restore of its workgroup; third rung of the repeat ladder, first choice under TRICO_HIP_DECODE_ROBUST=1
+int launch_fpc32_decode_robust(const Fpc32ChainJob* d_jobs, uint32_t njobs);
+bool decode_robust_first();       // TRICO_HIP_DECODE_ROBUST=1
 
 // double-precision coder (k_fpc64.hip): one wave per component stream, 2 x 2^20-entry tables per stream in d_tables (zeroed)
 int launch_fpc64_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes, uint64_t* d_tables);

@@ -333,7 +333,8 @@ int trico_hip_decode_jobs(trico_hip_decode_job* jobs, int count)
     if (launched)
       {
       ProfSpan span(TRICO_HIP_K_FPC32_DECODE);
-      launched = launch_fpc32_decode_batch((const Fpc32ChainJob*)E.jobs32.p, k, (uint32_t*)E.scratch32, chains_per_group(k)) != 0;
+      launched = (decode_robust_first() ? launch_fpc32_decode_robust((const Fpc32ChainJob*)E.jobs32.p, k)
+                                        : launch_fpc32_decode_batch((const Fpc32ChainJob*)E.jobs32.p, k, (uint32_t*)E.scratch32, chains_per_group(k))) != 0;
       for (int i = 0; launched && i < count; ++i)
         if (kind[i] == K_FP32)
           launched = decode_sabotage(0, d_dst[i], jobs[i].n, jobs[i].arity, 4) &&

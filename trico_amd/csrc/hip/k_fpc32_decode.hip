@@ -574,6 +574,205 @@ __global__ void __launch_bounds__(128 * CPW) k_fpc32_decode_batch(const Fpc32Cha
   decode_group<CPW>(jobs, njobs, blockIdx.x * (uint32_t)CPW, scratch);
   }
 
+// ---- the same decoder with NOTHING behind the scalar cache ---------------------------------------------------------------
+// k_fpc32_decode_robust: one workgroup of two waves per chain like the kernel above, but both predictor tables, the ring of
+// residuals and the two counters live in LDS, and the chain is ordinary vector code.  Everything the pair knows is then in
+// registers and LDS, which travel with the workgroup when the hardware scheduler saves and restores it: this kernel cannot lose
+// its tables the way the scalar-cache chain can (shim.hip, "the chain decoders and their self-check").  The price is four LDS
+// instructions per value on the dependent path (13-17 cycles of issue each, a read behind a write ~120): measured ~2 x the
+// scalar chain's time per value.  It is the third rung of the repeat ladder for float streams (before the reference-order
+// kernel), and TRICO_HIP_DECODE_ROBUST=1 makes it the first choice for processes that expect to be preempted.
+constexpr uint32_t RRING = 4;                                   // batches the parser may run ahead
+
+struct RobustLds
+  {
+  uint32_t win[WINW + 4];
+  uint32_t T2[1024], T1[16];
+  uint32_t x[RRING][64];                                        // residuals of a batch, lane K = value K
+  uint32_t mlo[RRING], mhi[RRING];                              // its mask of DFCM-coded values
+  uint32_t produced, consumed, bad, q;
+  };
+
+__global__ void __launch_bounds__(128) k_fpc32_decode_robust(const Fpc32ChainJob* __restrict__ jobs, uint32_t njobs)
+  {
+  __shared__ RobustLds L;
+  const int lane = threadIdx.x & 63;
+  const int role = (int)rfl(threadIdx.x >> 6);
+  const uint32_t id = blockIdx.x;
+  if (id >= njobs)
+    return;
+  const Fpc32ChainJob* jp = jobs + id;
+  const uint8_t* in = (const uint8_t*)rfl64((uint64_t)(uintptr_t)jp->pay);
+  uint32_t* dst = (uint32_t*)rfl64((uint64_t)(uintptr_t)jp->dst);
+  uint32_t* status = (uint32_t*)rfl64((uint64_t)(uintptr_t)jp->status);
+  const uint32_t len = rfl(jp->size), n = rfl(jp->n);
+  const int arity = (int)rfl(jp->stride);
+  for (uint32_t i = threadIdx.x; i < 1024u; i += 128u)
+    L.T2[i] = 0u;
+  if (threadIdx.x < 16u)
+    L.T1[threadIdx.x] = 0u;
+  if (threadIdx.x == 0u)
+    {
+    L.produced = 0u; L.consumed = 0u; L.bad = 0u; L.q = 5u;
+    }
+  uint32_t early = 0, e1 = 4u, e2 = 10u;
+  if (len < 5u)
+    early = FPC_STATUS_SHORT;
+  else
+    {
+    e1 = (uint32_t)(in[0] >> 4) << 1;
+    e2 = (uint32_t)(in[0] & 15) << 1;
+    const uint32_t cnt = ((uint32_t)in[1] << 24) | ((uint32_t)in[2] << 16) | ((uint32_t)in[3] << 8) | in[4];
+    if (cnt != n || e1 == 0u || e2 == 0u || e1 > 4u || e2 > 10u)
+      early = FPC_STATUS_HEADER;
+    }
+  early = rfl(early); e1 = rfl(e1); e2 = rfl(e2);
+  const bool work = early == 0u;
+  const uint32_t nb = (work && e1 == 4u && e2 == 10u) ? n / 64u : 0u;
+  __syncthreads();
+  volatile uint32_t* produced = &L.produced;
+  volatile uint32_t* consumed = &L.consumed;
+  uint32_t last = 0, h1 = 0, h2 = 0;
+  if (role == 1 && nb)
+    {
+    // ---- parser: the same walk as in decode_pair, residuals to the LDS ring ------------------------------------------------
+    const uint32_t al = (uint32_t)((uintptr_t)in & 3u);
+    const uint32_t* abase = (const uint32_t*)(in - al);
+    const uint32_t total_q = len + al;
+    const uint32_t ndw = (total_q + 3u) >> 2;
+    uint32_t wd = 0, q = 5u + al;
+    uint32_t* win = L.win;
+    auto refill = [&](uint32_t from_q)
+      {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      wd = from_q >> 2;
+      for (uint32_t i = (uint32_t)lane; i < (uint32_t)WINW + 4u; i += 64u)
+        win[i] = (wd + i < ndw) ? abase[wd + i] : 0u;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      };
+    refill(q);
+    uint32_t t = 0, failed = 0, spins = 0;
+    while (t < nb)
+      {
+      const uint32_t cons = *consumed;
+      if (cons == ABORT)
+        break;
+      if (t >= cons + RRING)
+        {
+        if (++spins > SPIN_LIMIT_PARSER) { failed = 2u; break; }
+        __builtin_amdgcn_s_sleep(4);
+        continue;
+        }
+      spins = 0;
+      if (q + BATCH_BYTES + 8u > 4u * (wd + (uint32_t)WINW))
+        refill(q);
+      uint32_t lq = q - 4u * wd, bcv = 0, myq = 0;
+#pragma unroll
+      for (uint32_t g = 0; g < 8u; ++g)
+        {
+        const uint32_t w = rfl(__builtin_amdgcn_alignbyte(win[(lq >> 2) + 1u], win[lq >> 2], lq & 3u));
+        const uint32_t bc = __builtin_bswap32(w) >> 8;
+        if (((uint32_t)lane >> 3) == g) { bcv = bc; myq = lq; }
+        lq += 3u + lens_sum(bc);
+        }
+      const uint32_t qend = 4u * wd + lq;
+      if (qend > total_q) { failed = 1u; break; }
+      q = qend;
+      const uint32_t j3 = 3u * ((uint32_t)lane & 7u);
+      const uint32_t code = (bcv >> j3) & 7u;
+      const uint32_t nbytes = code <= 4u ? code : code - 4u;
+      const uint32_t rp = myq + 3u + lens_sum(bcv & ((1u << j3) - 1u));
+      const uint32_t raw = __builtin_amdgcn_alignbyte(win[(rp >> 2) + 1u], win[rp >> 2], rp & 3u);
+      const uint32_t xr = nbytes ? __builtin_bswap32(raw) >> (8u * (4u - nbytes)) : 0u;
+      const uint64_t dfcm = __ballot(code > 4u);
+      const uint32_t sl = t % RRING;
+      L.x[sl][lane] = xr;
+      if (lane == 0) { L.mlo[sl] = (uint32_t)dfcm; L.mhi[sl] = (uint32_t)(dfcm >> 32); }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      ++t;
+      if (lane == 0) *produced = t;
+      }
+    if (failed && lane == 0)
+      {
+      *produced = ABORT;
+      atomicOr(&L.bad, failed);
+      }
+    if (lane == 0)
+      L.q = q - al;
+    }
+  else if (role == 0 && nb)
+    {
+    // ---- chain: every lane runs the recurrence on the same values (LDS broadcast reads; lane 0 writes the tables) ----------
+    // (volatile: lane 0 writes the tables, every lane reads them; the accesses must stay where they are written)
+    volatile uint32_t* T1v = L.T1;
+    volatile uint32_t* T2v = L.T2;
+    uint32_t spins = 0;
+    bool stop = false;
+    for (uint32_t b = 0; b < nb && !stop; ++b)
+      {
+      for (;;)
+        {
+        const uint32_t p = *produced;
+        if (p == ABORT) { stop = true; break; }
+        if (p > b) break;
+        if (++spins > SPIN_LIMIT_CHAIN)
+          {
+          if (lane == 0) { *consumed = ABORT; atomicOr(&L.bad, 2u); }
+          stop = true;
+          break;
+          }
+        __builtin_amdgcn_s_sleep(1);
+        }
+      if (stop)
+        break;
+      spins = 0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      const uint32_t sl = b % RRING;
+      const uint32_t xk = L.x[sl][lane];
+      const uint64_t mask = ((uint64_t)L.mhi[sl] << 32) | L.mlo[sl];
+      uint32_t outv = 0;
+#pragma unroll 8
+      for (int k = 0; k < 64; ++k)
+        {
+        const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)xk, k);
+        const uint32_t t2 = T2v[h2], t1 = T1v[h1];
+        const uint32_t pred = ((mask >> k) & 1ull) ? last + t2 : t1;          // fpsc.c:308-311
+        const uint32_t v = x ^ pred;
+        const uint32_t s = v - last;
+        if (lane == 0)
+          {
+          T1v[h1] = v;                                                         // fpsc.c:312-314, 323-326
+          T2v[h2] = s;
+          }
+        h1 = v >> 28;
+        h2 = ((h2 << 5) ^ (s >> 22)) & 1023u;
+        last = v;
+        outv = lane == k ? v : outv;
+        }
+      dst[((size_t)64u * b + (uint32_t)lane) * (uint32_t)arity] = outv;
+      if (lane == 0) *consumed = b + 1u;
+      }
+    }
+  __syncthreads();
+  // hand the chain's state to thread 0 for the tail (fewer than 64 values, or table shapes below the API's)
+  __shared__ uint32_t hand[3];
+  if (role == 0 && lane == 0) { hand[0] = last; hand[1] = h1; hand[2] = h2; }
+  __syncthreads();
+  const bool bad = L.bad != 0u;
+  uint32_t st = early | ((L.bad & 1u) ? FPC_STATUS_MALFORMED : 0u) | ((L.bad & 2u) ? FPC_STATUS_TIMEOUT : 0u);
+  const uint32_t i0 = 64u * nb;
+  if (work && !bad && i0 < n && threadIdx.x == 0)
+    {
+    uint32_t pos = L.q, t_h1 = hand[1], t_h2 = hand[2], t_last = hand[0];
+    bool tail_bad = false;
+    serial_values(in, len, pos, i0, n, e1, e2, t_h1, t_h2, t_last, L.T1, L.T2, dst, arity, 0, tail_bad);
+    if (tail_bad)
+      st |= FPC_STATUS_MALFORMED;
+    }
+  if (st != 0u && threadIdx.x == 0)
+    atomicOr(status, st);
+  }
+
 // One chain per CU: the chain wave needs its SIMD's issue slots and its CU's scalar cache; the workgroup asks for more than
 // half of the CU's LDS (it uses a fraction of it) so that no second workgroup of this kernel can be placed beside it.
 constexpr size_t CLAIM = 88u << 10;
@@ -595,6 +794,15 @@ int launch_fpc32_decode(const uint8_t* const d_payloads[3], const uint32_t sizes
   static const bool claimed = claim_lds(k_fpc32_decode);
   hipLaunchKernelGGL(k_fpc32_decode, dim3(arity), dim3(128), claimed ? CLAIM : 0, current_stream(), a, (uint32_t)arity, d_scratch);
   return hip_ok(hipGetLastError(), "k_fpc32_decode") ? 1 : 0;
+  }
+
+// the LDS-only decoder for every chain of the table (no scratch: nothing lives outside registers and LDS)
+int launch_fpc32_decode_robust(const Fpc32ChainJob* d_jobs, uint32_t njobs)
+  {
+  if (njobs == 0)
+    return 1;
+  hipLaunchKernelGGL(k_fpc32_decode_robust, dim3(njobs), dim3(128), 0, current_stream(), d_jobs, njobs);
+  return hip_ok(hipGetLastError(), "k_fpc32_decode_robust") ? 1 : 0;
   }
 
 // All chains of a batch in ONE launch (`d_jobs`: device table of njobs descriptors, `d_scratch`: FPC32_DECODE_TABLE_BYTES per chain):

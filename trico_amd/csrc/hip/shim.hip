@@ -629,6 +629,12 @@ int decode_sabotage(int, void*, uint32_t, int, int) { return 1; }
 static thread_local int g_first_attempt = 0;
 void set_first_attempt(int a) { g_first_attempt = a; }
 
+bool decode_robust_first()
+  {
+  static const bool on = [] { const char* e = getenv("TRICO_HIP_DECODE_ROBUST"); return e && e[0] == '1'; }();
+  return on;
+  }
+
 } // namespace trico
 
 extern "C" {
@@ -642,8 +648,21 @@ static int fpc_chain_decode(trico_hip_ctx* ctx, int attempt)
   const size_t tb = width == 8 ? (size_t)arity * 2 * ((size_t)1 << 20) * 8 + 3 * FPC64_DECODE_SCRATCH_BYTES : 3 * FPC32_DECODE_TABLE_BYTES;
   if (!ctx->tmp.reserve(tb))
     return 0;
-  const int ok = width == 4 ? launch_fpc32_decode(ctx->chk_pay, ctx->chk_sizes, arity, n, ctx->chk_dst, d_status, (uint32_t*)ctx->tmp.p)
-                            : launch_fpc64_decode(ctx->chk_pay, ctx->chk_sizes, arity, n, ctx->chk_dst, (uint64_t*)ctx->tmp.p, d_status);
+  int ok;
+  if (width == 4 && (attempt >= 2 || decode_robust_first()))
+    {
+    // float streams, third attempt (or TRICO_HIP_DECODE_ROBUST=1): the decoder that keeps everything in LDS and registers
+    Fpc32ChainJob h[3];
+    for (int c = 0; c < arity; ++c)
+      h[c] = Fpc32ChainJob{ ctx->chk_pay[c], (uint32_t*)ctx->chk_dst + c, d_status, ctx->chk_sizes[c], n, (uint32_t)arity, 0u };
+    Fpc32ChainJob* d_jobs = (Fpc32ChainJob*)((uint8_t*)ctx->aux.p + 1024);
+    TRICO_HIP_TRY(hipMemcpyAsync(d_jobs, h, sizeof(Fpc32ChainJob) * (size_t)arity, hipMemcpyHostToDevice, current_stream()));
+    TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));          // h lives on this stack
+    ok = launch_fpc32_decode_robust(d_jobs, (uint32_t)arity);
+    }
+  else
+    ok = width == 4 ? launch_fpc32_decode(ctx->chk_pay, ctx->chk_sizes, arity, n, ctx->chk_dst, d_status, (uint32_t*)ctx->tmp.p)
+                    : launch_fpc64_decode(ctx->chk_pay, ctx->chk_sizes, arity, n, ctx->chk_dst, (uint64_t*)ctx->tmp.p, d_status);
   return ok && decode_sabotage(attempt, ctx->chk_dst, n, arity, width) && fpc_check_launch(ctx, d_status);
   }
 
