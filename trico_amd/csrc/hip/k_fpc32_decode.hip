@@ -703,9 +703,9 @@ __global__ void __launch_bounds__(128) k_fpc32_decode_robust(const Fpc32ChainJob
   else if (role == 0 && nb)
     {
     // ---- chain: every lane runs the recurrence on the same values (LDS broadcast reads; lane 0 writes the tables) ----------
-    // (volatile: lane 0 writes the tables, every lane reads them; the accesses must stay where they are written)
-    volatile uint32_t* T1v = L.T1;
+    // (volatile: lane 0 writes the table, every lane reads it; the accesses must stay where they are written)
     volatile uint32_t* T2v = L.T2;
+    uint32_t t1reg = 0;                                  // the FCM table: lane j < 16 holds entry j (read with v_readlane)
     uint32_t spins = 0;
     bool stop = false;
     for (uint32_t b = 0; b < nb && !stop; ++b)
@@ -735,15 +735,14 @@ __global__ void __launch_bounds__(128) k_fpc32_decode_robust(const Fpc32ChainJob
       for (int k = 0; k < 64; ++k)
         {
         const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)xk, k);
-        const uint32_t t2 = T2v[h2], t1 = T1v[h1];
+        const uint32_t t2 = T2v[h2];
+        const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)t1reg, (int)rfl(h1));
         const uint32_t pred = ((mask >> k) & 1ull) ? last + t2 : t1;          // fpsc.c:308-311
         const uint32_t v = x ^ pred;
         const uint32_t s = v - last;
+        t1reg = (uint32_t)lane == h1 ? v : t1reg;                              // fpsc.c:312-314
         if (lane == 0)
-          {
-          T1v[h1] = v;                                                         // fpsc.c:312-314, 323-326
-          T2v[h2] = s;
-          }
+          T2v[h2] = s;                                                         // fpsc.c:323-326
         h1 = v >> 28;
         h2 = ((h2 << 5) ^ (s >> 22)) & 1023u;
         last = v;
@@ -752,6 +751,8 @@ __global__ void __launch_bounds__(128) k_fpc32_decode_robust(const Fpc32ChainJob
       dst[((size_t)64u * b + (uint32_t)lane) * (uint32_t)arity] = outv;
       if (lane == 0) *consumed = b + 1u;
       }
+    if (lane < 16)
+      L.T1[lane] = t1reg;                                // for the tail loop
     }
   __syncthreads();
   // hand the chain's state to thread 0 for the tail (fewer than 64 values, or table shapes below the API's)
