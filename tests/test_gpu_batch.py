@@ -51,6 +51,9 @@ def test_read_archives_equals_one_by_one(api, allstreams, where):
     import torch
     sets = some_archives(allstreams)
     keep, archives, outs = [], [], []
+    stats = (ctypes.c_uint32 * 4)()
+    api.lib().trico_hip_last_stats(stats)
+    repeats_before = stats[2]
     for blob, streams in sets:
         if where == "device":
             t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
@@ -76,9 +79,8 @@ def test_read_archives_equals_one_by_one(api, allstreams, where):
             g = got.cpu().numpy().tobytes() if where == "device" else got.tobytes()
             assert g == data.tobytes(), name
         r.close()
-    stats = (ctypes.c_uint32 * 4)()
     api.lib().trico_hip_last_stats(stats)
-    assert stats[2] == 0, "a chain decode had to be repeated"
+    assert stats[2] == repeats_before, "a chain decode had to be repeated"
 
 
 def test_read_archives_prefix_and_skips(api, allstreams):
@@ -220,3 +222,33 @@ def test_lds_only_decoder_as_first_choice():
     env["TRICO_HIP_DECODE_ROBUST"] = "1"
     out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "BATCH OK" in out.stdout, out.stdout + out.stderr
+
+
+ENC_CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r + "/tests")
+from trico_amd import api
+from oracle import oracle as O
+from streams import mesh_streams
+for kind, W, H in (("grid", 256, 128), ("walk", 300, 77), ("grid", 16, 8), ("walk", 1000, 1000)):
+    s = mesh_streams(kind, W, H)
+    a = api.Archive.open_for_writing(1 << 16)
+    o = O.OracleArchive()
+    for name, data, count in s:
+        assert a.write(name, data, count) == 1, api.last_error()
+        o.write(name, data, count)
+    assert a.tobytes() == o.tobytes(), (kind, W, H)
+    a.close(); o.close()
+print("ENCODE OK")
+"""
+
+
+def test_tagged_table_code_sweep_writes_the_same_bytes():
+    """TRICO_FPC32_ATOMIC=1: the float encoder's code sweep with 64-bit {tag, payload} table entries and one ds_max_rtn_u64 per
+    predictor and step instead of the ballot match (k_fpc32_encode.hip, resolve_atomic): byte-identical archives."""
+    env = dict(os.environ)
+    env["TRICO_FPC32_ATOMIC"] = "1"
+    out = subprocess.run([sys.executable, "-c", ENC_CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ENCODE OK" in out.stdout, out.stdout + out.stderr

@@ -109,8 +109,12 @@ int launch_lz4_decode_serial(const uint8_t* const d_payloads[8], const uint32_t 
 
 // throughput float encoder (k_fpc32_encode.hip): segmented 2-sweep scheme, see the file header
 size_t fpc32_encode_workspace(uint32_t n, int arity);
+// d_sizes: 4 words - payload bytes of components 0..2, then a flag: non-zero if the tagged-table code sweep found the LDS unit
+// applying an atomic out of lane order (the result is then not to be used: fpc32_distrust_atomic() and encode again).
+// allow_atomic = false: always the ballot kernel (what the decoders' self-check uses).
 int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
-                        uint8_t* d_ws, size_t ws_bytes);
+                        uint8_t* d_ws, size_t ws_bytes, bool allow_atomic = true);
+void fpc32_distrust_atomic();
 int launch_fpc32_gather(uint32_t n, int arity, int c, const uint8_t* d_ws, uint8_t* d_dst);
 int launch_fpc32_gather_all(uint32_t n, int arity, const uint8_t* d_ws, uint8_t* const d_dst[3]);
 int launch_fpc32_compare(uint32_t n, int arity, const uint8_t* d_ws, const uint32_t* d_sizes, const uint8_t* const d_pay[3],

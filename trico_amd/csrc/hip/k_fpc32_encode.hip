@@ -305,6 +305,7 @@ __global__ void __launch_bounds__(256) k_fpc32_scan_b(const uint32_t* __restrict
 constexpr int STAGE_LIVE = 544;                   // < 256 unflushed + <= 280 of the step, rounded
 constexpr int STAGE = STAGE_LIVE + 256;           // + 4 dump bytes per lane
 constexpr int LDSW_C = TAB + STAGE / 4;           // per-wave LDS words, sweep C (4,960 B: 10 x 3 waves per CU)
+constexpr int LDSW_CA = 2 * TAB + STAGE / 4;      // ... of the variant whose table entries carry a tag (9,120 B: 5 x 3 waves per CU)
 
 struct LaneK                                      // per-lane constants
   {
@@ -320,6 +321,8 @@ struct Sweep                                      // wave-uniform running state
   uint32_t kc1, kc2;                              // classes of the previous step's last value
   bool pend1, pend2;                              // its table writes are still pending
   uint32_t posl, flushed;                         // bytes staged in LDS / bytes already in the slot
+  uint32_t tag;                                   // resolve_atomic: number of the resolving step, << 6
+  uint32_t viol;                                  // resolve_atomic: the LDS unit applied an atomic out of lane order
   };
 
 // lanes whose class equals mine, for B-bit classes (B even): one ballot per class bit.  `diff` collects the lanes that differ
@@ -405,6 +408,61 @@ __device__ __forceinline__ void resolve(uint32_t k1, uint32_t k2, bool st1, bool
   if (D2) { sw.kc2 = (uint32_t)__builtin_amdgcn_readlane((int)k2, 63); sw.pend2 = false; }
   }
 
+// The same lookup as ONE LDS instruction per predictor.  Table entries are 64 bits: {tag, payload}, tag = (number of the resolving
+// step << 6 | lane) of the value that wrote the entry (0 for what the segment came in with).  Every run END does
+// ds_max_rtn_u64(entry of its class, {its tag, its payload}); a run START that is not an end does the same with {0, 0}, which changes
+// nothing.  What comes back is the entry as it was when the lane's turn came: on gfx950 the LDS unit applies the lanes of one atomic
+// instruction in increasing lane order (tools/ubench/lds_atomic_order.hip: 7.7 M instructions, key sets from 1 to 1024 keys, not one
+// lane out of order), so a start lane gets the payload of the nearest lower lane of its class if this step has one - necessarily a
+// run end - and otherwise what earlier steps left, i.e. exactly what the reference's table holds when it codes the value
+// (fpsc.c:133-143).  The table is up to date afterwards too: the maximum is the highest lane's entry.  The order is not documented,
+// so it is CHECKED in every step: in any other order some lane sees a tag of this step that is not below its own; such a step
+// raises `viol`, the host throws the encode away and repeats it with the ballot kernel (never seen to happen).
+template <bool FULL, bool D1, bool D2>
+__device__ __forceinline__ void resolve_atomic(uint32_t k1, uint32_t k2, bool st1, bool st2, bool act, uint32_t v, uint32_t s,
+                                               uint32_t& p1, uint32_t& p2, unsigned long long* __restrict__ T, Sweep& sw, const LaneK& lk)
+  {
+  sw.tag += 64u;
+  const uint32_t mytag = sw.tag | (uint32_t)lk.lane;
+  // pending writes of the previous step's last value: it is later than everything the table holds and earlier than this step
+  if (lk.lane == 0)
+    {
+    if (D1 && sw.pend1) T[sw.kc1] = ((unsigned long long)(sw.tag - 1u) << 32) | sw.cy.m1;
+    if (D2 && sw.pend2) T[sw.kc2] = ((unsigned long long)(sw.tag - 1u) << 32) | (uint32_t)(sw.cy.m1 - sw.cy.m2);
+    }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  bool bad = false;
+  if (D1)
+    {
+    const bool en = (FULL || act) && k1 != dpp_shl1(0xfffffffeu, k1);           // last lane of a run (lane 63 always)
+    if (st1 || en)
+      {
+      const unsigned long long mine = en ? (((unsigned long long)mytag << 32) | v) : 0ull;
+      const unsigned long long old = atomicMax(&T[k1], mine);
+      const uint32_t ot = (uint32_t)(old >> 32);
+      bad = (ot >> 6) == (sw.tag >> 6) && (ot & 63u) >= (uint32_t)lk.lane;
+      p1 = st1 ? (uint32_t)old : p1;
+      }
+    }
+  if (D2)
+    {
+    const bool en = (FULL || act) && k2 != dpp_shl1(0xfffffffeu, k2);
+    if (st2 || en)
+      {
+      const unsigned long long mine = en ? (((unsigned long long)mytag << 32) | s) : 0ull;
+      const unsigned long long old = atomicMax(&T[k2], mine);
+      const uint32_t ot = (uint32_t)(old >> 32);
+      bad = bad || ((ot >> 6) == (sw.tag >> 6) && (ot & 63u) >= (uint32_t)lk.lane);
+      p2 = st2 ? (uint32_t)old : p2;
+      }
+    }
+  if (__ballot(bad))
+    sw.viol = 1u;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (D1) { sw.kc1 = (uint32_t)__builtin_amdgcn_readlane((int)k1, 63); sw.pend1 = false; }
+  if (D2) { sw.kc2 = (uint32_t)__builtin_amdgcn_readlane((int)k2, 63); sw.pend2 = false; }
+  }
+
 // store the bytes of staged word `w` (byte offset off inside the slot, multiple of 4) that lie below hi
 __device__ __forceinline__ void store_span(uint8_t* __restrict__ gbase, uint32_t off, uint32_t w, uint32_t hi)
   {
@@ -429,7 +487,7 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x)
   }
 
 // one step: 64 values starting at index i0 (FULL: all of them inside the segment)
-template <bool FULL>
+template <bool FULL, bool ATOMIC>
 __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_end, uint32_t n, uint32_t* __restrict__ T,
                                           uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase,
                                           Sweep& sw, const LaneK& lk)
@@ -450,7 +508,25 @@ __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_en
   const bool any1 = __ballot(st1) != 0ull, any2 = __ballot(st2) != 0ull;
   const uint32_t s = v - a;
   uint32_t p1 = a, p2 = s1;                                 // inside a run: previous value / previous stride
-  if (any1 && any2)
+  if (ATOMIC)
+    {
+    unsigned long long* T64 = (unsigned long long*)T;
+    if (any1 && any2)
+      resolve_atomic<FULL, true, true>(k1, k2, st1, st2, act, v, s, p1, p2, T64, sw, lk);
+    else if (any1)
+      {
+      resolve_atomic<FULL, true, false>(k1, k2, st1, st2, act, v, s, p1, p2, T64, sw, lk);
+      sw.pend2 = true;
+      }
+    else if (any2)
+      {
+      resolve_atomic<FULL, false, true>(k1, k2, st1, st2, act, v, s, p1, p2, T64, sw, lk);
+      sw.pend1 = true;
+      }
+    else
+      sw.pend1 = sw.pend2 = true;
+    }
+  else if (any1 && any2)
     resolve<FULL, true, true>(k1, k2, st1, st2, act, v, s, p1, p2, T, sw, lk);
   else if (any1)
     {
@@ -532,15 +608,19 @@ __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_en
   next_carry(sw.cy, v);
   }
 
+// ATOMIC: table entries of 64 bits and resolve_atomic (one LDS instruction per predictor and step); else 32-bit entries and resolve
+// (ballots).  `flags`: word 0 is raised when an ATOMIC step found the LDS unit out of lane order.
+template <bool ATOMIC>
 __global__ void __launch_bounds__(192) k_fpc32_code(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t L, uint32_t S,
                                                     const uint32_t* __restrict__ inc, uint8_t* __restrict__ slots, size_t slot_stride,
-                                                    uint32_t segcap, uint32_t* __restrict__ segbytes)
+                                                    uint32_t segcap, uint32_t* __restrict__ segbytes, uint32_t* __restrict__ flags)
   {
-  extern __shared__ uint32_t lds[];
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t g = blockIdx.x;
-  uint32_t* T = lds + c * LDSW_C;                      // [TAB] payload table
-  uint8_t* stage = (uint8_t*)(T + TAB);                // [STAGE] packed bytes of the steps not yet flushed + dump
+  constexpr int TW = ATOMIC ? 2 * TAB : TAB;           // table words
+  uint32_t* T = lds + c * (ATOMIC ? LDSW_CA : LDSW_C); // [TAB] payload table (ATOMIC: {payload, tag} pairs)
+  uint8_t* stage = (uint8_t*)(T + TW);                 // [STAGE] packed bytes of the steps not yet flushed + dump
   // incoming table: payload of the last writer of every class before this segment (0 if none)
   const uint32_t* row = inc + ((size_t)g * arity + c) * ROW;
   for (int k = lane; k < TAB; k += 64)
@@ -553,7 +633,10 @@ __global__ void __launch_bounds__(192) k_fpc32_code(const uint32_t* __restrict__
       const uint32_t vp = idx >= 2u ? src[(size_t)(idx - 2u) * arity + c] : 0u;
       pay = k < 16 ? vi : vi - vp;
       }
-    T[k] = pay;
+    if (ATOMIC)
+      ((unsigned long long*)T)[k] = pay;               // tag 0: older than every step of this segment
+    else
+      T[k] = pay;
     }
   LaneK lk;
   lk.lane = lane;
@@ -561,7 +644,7 @@ __global__ void __launch_bounds__(192) k_fpc32_code(const uint32_t* __restrict__
   lk.bit = 1ull << lane;
   lk.sh3 = 3u * ((uint32_t)lane & 7u);
   lk.grp3 = 3u * ((uint32_t)lane >> 3);
-  lk.dumpw = (uint32_t)(TAB + STAGE_LIVE / 4 + lane);
+  lk.dumpw = (uint32_t)(TW + STAGE_LIVE / 4 + lane);
   lk.dumpq = (uint32_t)(STAGE_LIVE + 4 * lane + 1);
   lk.lead = (lane & 7) == 0;
   const uint32_t i_begin = g * L;
@@ -572,6 +655,8 @@ __global__ void __launch_bounds__(192) k_fpc32_code(const uint32_t* __restrict__
   sw.pend1 = sw.pend2 = false;
   sw.posl = 0;
   sw.flushed = 0;
+  sw.tag = 0;
+  sw.viol = 0;
   if (g == 0)
     {
     if (lane == 0)
@@ -593,9 +678,9 @@ __global__ void __launch_bounds__(192) k_fpc32_code(const uint32_t* __restrict__
       {
       const uint32_t i0 = ib + 64u * pu;
       if (i0 + 64u <= i_end)
-        code_step<true>(cur[pu], i0, i_end, n, T, stage, gbase, sw, lk);
+        code_step<true, ATOMIC>(cur[pu], i0, i_end, n, T, stage, gbase, sw, lk);
       else if (i0 < i_end)
-        code_step<false>(cur[pu], i0, i_end, n, T, stage, gbase, sw, lk);
+        code_step<false, ATOMIC>(cur[pu], i0, i_end, n, T, stage, gbase, sw, lk);
       }
 #pragma unroll
     for (int pu = 0; pu < PF; ++pu)
@@ -609,12 +694,16 @@ __global__ void __launch_bounds__(192) k_fpc32_code(const uint32_t* __restrict__
   }
   if (lane == 0)
     segbytes[(size_t)c * S + g] = sw.flushed + sw.posl;
+  if (ATOMIC && sw.viol && lane == 0)
+    atomicOr(flags, 1u);
   }
 
 // ---- offsets: exclusive scan of segment sizes per component (one workgroup per component) -------------
 __global__ void __launch_bounds__(1024) k_fpc32_offsets(const uint32_t* __restrict__ segbytes, uint32_t S, uint32_t* __restrict__ segoff,
-                                                        uint32_t* __restrict__ sizes)
+                                                        uint32_t* __restrict__ sizes, const uint32_t* __restrict__ flags)
   {
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    sizes[3] = flags[0];                           // read back with the sizes: "the code sweep distrusts its LDS atomics"
   __shared__ uint32_t part[1024];
   const uint32_t c = blockIdx.x;
   const uint32_t per = (S + 1023u) / 1024u;
@@ -722,9 +811,23 @@ __global__ void k_fpc32_empty(uint8_t* out, size_t out_stride, uint32_t* sizes)
   const uint8_t bts[16] = { 0x25, 0, 0, 0, 0, 0x24, 0x92, 0x49, 0, 0, 0, 0, 0, 0, 0, 0 };
   for (int i = 0; i < 16; ++i) o[i] = bts[i];
   sizes[blockIdx.x] = 16;
+  if (blockIdx.x == 0)
+    sizes[3] = 0;
   }
 
-struct Plan { uint32_t L, S, segcap, nch; size_t rows, slot_stride, off_summ, off_inc, off_chmax, off_segbytes, off_segoff, off_slots, total; };
+struct Plan { uint32_t L, S, segcap, nch; size_t rows, slot_stride, off_summ, off_inc, off_chmax, off_segbytes, off_segoff, off_flags, off_slots, total; };
+
+// The tagged-table code sweep (resolve_atomic) is chosen with TRICO_FPC32_ATOMIC=1, and given up for good once a step of it has
+// found the LDS unit applying an atomic out of lane order in this process (the ballot kernel does not depend on that order).
+// It is not the default: measured on the MI355X (profiles/r03_fpc32_encode_experiments.txt) a noisy component alone codes 15 %
+// faster with it (0.503 -> 0.427 ms for 50 M values) and the walk mesh 6 % (0.982 -> 0.925 ms), but the grid mesh - two smooth
+// components, one noisy - is 1-3 % slower, because the 64-bit table halves the waves per CU for the smooth components too.
+static bool g_atomic_distrusted = false;
+bool fpc32_use_atomic()
+  {
+  static const bool env_atomic = [] { const char* e = getenv("TRICO_FPC32_ATOMIC"); return e && e[0] == '1'; }();
+  return env_atomic && !g_atomic_distrusted;
+  }
 
 Plan make_plan(uint32_t n, int arity)
   {
@@ -732,7 +835,7 @@ Plan make_plan(uint32_t n, int arity)
   if (!waves)
     {
     const char* e = getenv("TRICO_FPC32_WAVES");      // tuning knob: waves per sweep
-    waves = e ? atoi(e) : 7680;                       // 30 waves per CU: the code sweep needs 4,960 B of LDS per wave
+    waves = e ? atoi(e) : (fpc32_use_atomic() ? 3840 : 7680);   // 15 (tagged tables: 9,120 B of LDS per wave) or 30 waves per CU (4,960 B)
     if (waves < 3) waves = 3;
     }
   Plan p;
@@ -753,6 +856,7 @@ Plan make_plan(uint32_t n, int arity)
   p.off_chmax = o;     o += align_up((size_t)p.nch * arity * TAB * 4, 256);
   p.off_segbytes = o;  o += align_up(p.rows * 4, 256);
   p.off_segoff = o;    o += align_up(p.rows * 4, 256);
+  p.off_flags = o;     o += 256;
   p.off_slots = o;     o += p.slot_stride * arity;
   p.total = o + 256;
   return p;
@@ -765,8 +869,10 @@ size_t fpc32_encode_workspace(uint32_t n, int arity)
   return make_plan(n, arity).total;
   }
 
+void fpc32_distrust_atomic() { g_atomic_distrusted = true; }
+
 int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
-                        uint8_t* d_ws, size_t ws_bytes)
+                        uint8_t* d_ws, size_t ws_bytes, bool allow_atomic)
   {
   hipStream_t st = current_stream();
   if (n == 0)
@@ -798,9 +904,16 @@ int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
   const unsigned colblocks = ((unsigned)arity * TAB + 255u) / 256u;
   hipLaunchKernelGGL(k_fpc32_scan_a, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax);
   hipLaunchKernelGGL(k_fpc32_scan_b, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax, inc);
-  hipLaunchKernelGGL(k_fpc32_code, dim3(p.S), dim3(threads), (size_t)arity * LDSW_C * 4, st,
-                     src, n, arity, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes);
-  hipLaunchKernelGGL(k_fpc32_offsets, dim3(arity), dim3(1024), 0, st, segbytes, p.S, segoff, d_sizes);
+  uint32_t* flags = (uint32_t*)(d_ws + p.off_flags);
+  if (!hip_ok(hipMemsetAsync(flags, 0, 4, st), "memset(flags)"))
+    return 0;
+  if (allow_atomic && fpc32_use_atomic())
+    hipLaunchKernelGGL(k_fpc32_code<true>, dim3(p.S), dim3(threads), (size_t)arity * LDSW_CA * 4, st,
+                       src, n, arity, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes, flags);
+  else
+    hipLaunchKernelGGL(k_fpc32_code<false>, dim3(p.S), dim3(threads), (size_t)arity * LDSW_C * 4, st,
+                       src, n, arity, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes, flags);
+  hipLaunchKernelGGL(k_fpc32_offsets, dim3(arity), dim3(1024), 0, st, segbytes, p.S, segoff, d_sizes, flags);
   return hip_ok(hipGetLastError(), "fpc32 encode kernels") ? 1 : 0;
   }
 

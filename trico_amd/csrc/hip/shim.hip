@@ -511,7 +511,25 @@ int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int
   else if (!launch_fpc_encode_serial(d_src, n, arity, width, ctx->out.p, stride, d_sizes, d_tables, e1, e2))
     return 0;
   }
-  if (!read_back_words(ctx, d_sizes, arity, ctx->out_sizes))
+  if (width == 4 && defaults && !force_serial_stage(1) && n != 0)
+    {
+    // sizes + the flag of the tagged-table code sweep (k_fpc32_encode.hip): raised, the payloads are not to be trusted
+    uint32_t four[4] = { 0, 0, 0, 0 };
+    if (!read_back_words(ctx, d_sizes, 4, four))
+      return 0;
+    if (four[3] != 0)
+      {
+      fpc32_distrust_atomic();
+      if (getenv("TRICO_HIP_DEBUG"))
+        fprintf(stderr, "trico_hip: the LDS unit applied an atomic out of lane order; encoding again with the ballot kernel\n");
+      if (!launch_fpc32_encode(d_src, n, arity, ctx->out.p, stride, d_sizes, ctx->tmp.p, ctx->tmp.cap) || !read_back_words(ctx, d_sizes, 4, four) ||
+          four[3] != 0)
+        return 0;
+      }
+    for (int c = 0; c < arity; ++c)
+      ctx->out_sizes[c] = four[c];
+    }
+  else if (!read_back_words(ctx, d_sizes, arity, ctx->out_sizes))
     return 0;
   ctx->out_count = arity;
   for (int c = 0; c < arity; ++c)
@@ -567,7 +585,8 @@ int fpc_selfcheck_launch(const void* d_vals, uint32_t n, int arity, int width, c
     const size_t ws = fpc32_encode_workspace(n, arity);
     if (!vws.reserve(ws))
       return 0;
-    return launch_fpc32_encode(d_vals, n, arity, nullptr, 0, d_vsizes, vws.p, vws.cap) &&
+    // (always the ballot kernel: the check does not depend on the order the LDS unit applies atomics in)
+    return launch_fpc32_encode(d_vals, n, arity, nullptr, 0, d_vsizes, vws.p, vws.cap, false) &&
            launch_fpc32_compare(n, arity, vws.p, d_vsizes, d_pay, sizes, d_status, 0x100u);
     }
   const size_t stride = align_up(fpc_bound(n, 8), 256);
