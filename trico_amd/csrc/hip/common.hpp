@@ -25,6 +25,7 @@ struct DevBuf
   {
   uint8_t* p = nullptr;
   size_t cap = 0;
+  int kind = 0;                 // buffers are recycled only among buffers of the same kind (1: scratch of the chain decoders)
   bool reserve(size_t bytes);   // grow-only, contents NOT preserved
   void release();               // returns the memory to a process-wide pool
   };
@@ -46,6 +47,8 @@ struct trico_hip_ctx
   trico::DevBuf ws;        // large kernel workspaces (chunked LZ4 descriptors / tables)
   trico::DevBuf unit;      // de-interleaved components / planes of the unit encoders (dist.hip)
   trico::DevBuf vws;       // self-check of the chain decoders: workspace and payloads of the re-encode (shim.hip)
+  trico::DevBuf chain;     // tables / rings of the chain decoders (scalar-cache resident): never recycled into anything else
+  trico_hip_ctx() { chain.kind = 1; }
   // the decode the self-check belongs to (it may have to be repeated)
   bool chk_active = false;
   const uint8_t* chk_pay[3] = { nullptr, nullptr, nullptr };

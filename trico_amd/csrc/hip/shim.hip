@@ -47,7 +47,7 @@ bool force_serial_stage(int bit) { return (serial_mask() & bit) != 0; }
 
 // Device workspaces are recycled across contexts (one context per archive handle): hipMalloc / hipFree of
 // multi-GB buffers cost hundreds of milliseconds and an implicit device sync each.
-struct PoolEntry { uint8_t* p; size_t cap; };
+struct PoolEntry { uint8_t* p; size_t cap; int kind; };
 static PoolEntry g_pool[1024];  // eight archives read at once park ~8 x 2 streams x 5 buffers
 static int g_pool_n = 0;
 static std::mutex g_pool_mutex;
@@ -61,7 +61,7 @@ bool DevBuf::reserve(size_t bytes)
   std::lock_guard<std::mutex> lock(g_pool_mutex);
   int best = -1;
   for (int i = 0; i < g_pool_n; ++i)
-    if (g_pool[i].cap >= bytes && (best < 0 || g_pool[i].cap < g_pool[best].cap))
+    if (g_pool[i].kind == kind && g_pool[i].cap >= bytes && (best < 0 || g_pool[i].cap < g_pool[best].cap))
       best = i;
   if (best >= 0 && g_pool[best].cap <= 4 * bytes + (64u << 20))
     {
@@ -95,7 +95,7 @@ void DevBuf::release()
     (void)hipStreamSynchronize(current_stream());
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     if (g_pool_n < (int)(sizeof(g_pool) / sizeof(g_pool[0])))
-      g_pool[g_pool_n++] = PoolEntry{ p, cap };
+      g_pool[g_pool_n++] = PoolEntry{ p, cap, kind };
     else
       (void)hipFree(p);
     }
@@ -254,6 +254,7 @@ void trico_hip_ctx_destroy(trico_hip_ctx* ctx)
   ctx->ws.release();
   ctx->unit.release();
   ctx->vws.release();
+  ctx->chain.release();
   if (ctx->h_pinned)
     (void)hipHostFree(ctx->h_pinned);
   delete ctx;
@@ -664,8 +665,10 @@ static int fpc_chain_decode(trico_hip_ctx* ctx, int attempt)
   const int arity = ctx->chk_arity, width = ctx->chk_width;
   const uint32_t n = ctx->chk_n;
   uint32_t* d_status = (uint32_t*)ctx->aux.p;
+  // tables and rings of the chain kernels: memory that is only ever chain scratch (a dirty line written back late from a compute
+  // unit the wave has left can then only land in another chain's scratch, whose decode is checked)
   const size_t tb = width == 8 ? (size_t)arity * 2 * ((size_t)1 << 20) * 8 + 3 * FPC64_DECODE_SCRATCH_BYTES : 3 * FPC32_DECODE_TABLE_BYTES;
-  if (!ctx->tmp.reserve(tb))
+  if (!ctx->chain.reserve(tb))
     return 0;
   int ok;
   if (width == 4 && (attempt >= 2 || decode_robust_first()))
@@ -680,8 +683,8 @@ static int fpc_chain_decode(trico_hip_ctx* ctx, int attempt)
     ok = launch_fpc32_decode_robust(d_jobs, (uint32_t)arity);
     }
   else
-    ok = width == 4 ? launch_fpc32_decode(ctx->chk_pay, ctx->chk_sizes, arity, n, ctx->chk_dst, d_status, (uint32_t*)ctx->tmp.p)
-                    : launch_fpc64_decode(ctx->chk_pay, ctx->chk_sizes, arity, n, ctx->chk_dst, (uint64_t*)ctx->tmp.p, d_status);
+    ok = width == 4 ? launch_fpc32_decode(ctx->chk_pay, ctx->chk_sizes, arity, n, ctx->chk_dst, d_status, (uint32_t*)ctx->chain.p)
+                    : launch_fpc64_decode(ctx->chk_pay, ctx->chk_sizes, arity, n, ctx->chk_dst, (uint64_t*)ctx->chain.p, d_status);
   return ok && decode_sabotage(attempt, ctx->chk_dst, n, arity, width) && fpc_check_launch(ctx, d_status);
   }
 
@@ -758,11 +761,20 @@ static int fpc_decode_launch(trico_hip_ctx* ctx, const uint8_t* const payloads[3
   if (width == 8 || !lds_tables)
     {
     const size_t tb = (size_t)arity * table_stride * (size_t)width;
-    if (!ctx->tmp.reserve(tb + 3 * FPC64_DECODE_SCRATCH_BYTES))
+    // the exponents come from a byte of the payload: a stream may ask for up to 48 GiB of tables.  The reference would calloc them;
+    // here a request beyond half of the free device memory is refused instead of being tried
+    if (!standard && tb > (size_t)(trico_hip_device_free_bytes() / 2))
+      {
+      set_error("trico_hip_fpc_decode: the stream's table exponents need more device memory than is free");
       return 0;
-    if (!standard || force_serial_stage(2))          // the throughput double decoder zeroes its tables itself, through the scalar cache
+      }
+    if (!standard || force_serial_stage(2))          // (the chain decoders bring their own scratch: fpc_chain_decode)
+      {
+      if (!ctx->tmp.reserve(tb + 256))
+        return 0;
       TRICO_HIP_TRY(hipMemsetAsync(ctx->tmp.p, 0, tb, current_stream()));
-    d_tables = (uint64_t*)ctx->tmp.p;
+      d_tables = (uint64_t*)ctx->tmp.p;
+      }
     }
   ctx->chk_active = false;
   if (standard && !force_serial_stage(2))
