@@ -20,7 +20,7 @@ roofline_all / decode_model: every other stage of the step against the same HBM 
             live hipEvent spans), and what bounds the chain decoders: nanoseconds and cycles per value of each component chain.
 other_mesh / pcie_inclusive / decode_concurrent / config3: the same step on the walk mesh, through host pointers, BASELINE
             configs[4]'s shape on one GPU (8 / 32 / 64 archives decoded as ONE batch, trico_hip_read_archives, with the hardware
-            queue count unset, 4 and 32), and BASELINE configs[2] (double vertices + normals + float uv, + u64 triangles so that the
+            queue count unset, 1, 4 and 32), and BASELINE configs[2] (double vertices + normals + float uv, + u64 triangles so that the
             archive is the reference's golden) - N = 1 only, outside the timed region.  --quick skips them.
 `python bench.py --gpus N` starts its N ranks itself (torch.distributed.run, RCCL) when no launcher did.
 """
@@ -371,11 +371,11 @@ def extras(args, api, meshgen, dev, d_v, d_t, nv, nt, raw_bytes):
     if Ks:
         from bench_batch_decode import batch_rows
         rows = batch_rows(Ks, d_v, d_t, nv, nt, raw_bytes, passes=2)
-        # the same batch with the hardware queue count of the process set to 4 and to 32: child processes (the variable is read
-        # when HIP initialises); round 2's one-launch-per-stream decoder went from 7 GB/s to wrong results between these two
+        # the same batch with the hardware queue count of the process set to 1, 4 and 32: child processes (the variable is read
+        # when HIP initialises); round 2's one-launch-per-stream decoder went from 7 GB/s to wrong results between the last two
         variants = []
         kq = 32 if 32 in Ks else Ks[-1]
-        for q in ("4", "32"):
+        for q in ("1", "4", "32"):
             env = dict(os.environ, GPU_MAX_HW_QUEUES=q)
             try:
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_batch_decode.py"), "--mesh", args.mesh, "--W", str(W),

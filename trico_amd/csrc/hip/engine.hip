@@ -90,9 +90,21 @@ bool engine_init()
   {
   if (E.ready)
     return true;
-  if (!hip_ok(hipStreamCreateWithFlags(&E.s32, hipStreamNonBlocking), "hipStreamCreate") ||
-      !hip_ok(hipStreamCreateWithFlags(&E.s64, hipStreamNonBlocking), "hipStreamCreate") ||
-      !hip_ok(hipStreamCreateWithFlags(&E.sint, hipStreamNonBlocking), "hipStreamCreate") ||
+  // The three streams must be three hardware queues (the chain grids run for seconds; whatever shares their queue waits).  The
+  // runtime spreads streams of ONE priority over at most GPU_MAX_HW_QUEUES queues in an order the library does not control -
+  // with 4 queues two of these streams were seen on one (32 archives: 4.1 s instead of 1.9 s) - but it keeps a pool of queues per
+  // priority level, so the streams get three different levels: float chains highest (two waves per chain, latency is everything),
+  // double chains normal, integer streams lowest (wide throughput kernels that fill what the chains leave).
+  int prio_least = 0, prio_greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess)
+    {
+    (void)hipGetLastError();
+    prio_least = prio_greatest = 0;
+    }
+  const int prio_mid = (prio_least + prio_greatest) / 2;
+  if (!hip_ok(hipStreamCreateWithPriority(&E.s32, hipStreamNonBlocking, prio_greatest), "hipStreamCreate") ||
+      !hip_ok(hipStreamCreateWithPriority(&E.s64, hipStreamNonBlocking, prio_mid), "hipStreamCreate") ||
+      !hip_ok(hipStreamCreateWithPriority(&E.sint, hipStreamNonBlocking, prio_least), "hipStreamCreate") ||
       !hip_ok(hipEventCreateWithFlags(&E.ev_user, hipEventDisableTiming), "hipEventCreate") ||
       !hip_ok(hipEventCreateWithFlags(&E.ev32, hipEventDisableTiming), "hipEventCreate") ||
       !hip_ok(hipEventCreateWithFlags(&E.ev64, hipEventDisableTiming), "hipEventCreate") ||
