@@ -215,11 +215,11 @@ enum trico_hip_kernel_id
   TRICO_HIP_K_LZ4_DECODE   = 7,
   TRICO_HIP_K_COUNT        = 8
   };
-/* diagnostics of this thread: out[0] = LZ4 chunks accepted by the stitch pass of the last trico_hip_int_encode,
+/* diagnostics: out[0] (this thread) = LZ4 chunks accepted by the stitch pass of the last trico_hip_int_encode,
  * out[1] = of those re-parsed serially (speculation not provably equivalent); 0,0 for small planes;
- * out[2] = float / double stream decodes that this thread had to repeat because the decoded values did not code
+ * out[2] (process-wide) = float / double stream decodes that had to be repeated because the decoded values did not code
  * back to the payload (the decoders check themselves, see shim.hip; counts up, never reset);
- * out[3] = streams whose values, decoded in reference order at the end of the repeat ladder, still do not code back to their
+ * out[3] (process-wide) = streams whose values, decoded in reference order at the end of the repeat ladder, still do not code back to their
  * payload: payloads the reference's encoder would not have written (decoded all the same; counts up, never reset) */
 TRICO_API void trico_hip_last_stats(uint32_t out[4]);
 TRICO_API void trico_hip_profile_enable(int on);

@@ -252,3 +252,40 @@ def test_tagged_table_code_sweep_writes_the_same_bytes():
     env["TRICO_FPC32_ATOMIC"] = "1"
     out = subprocess.run([sys.executable, "-c", ENC_CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ENCODE OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_threads_with_one_archive_each_share_a_batch(api):
+    """The reference's threading model: one archive handle per thread.  Six threads read six different archives at the same time
+    through the plain trico_read_* calls; the engine combines what arrives together into one batch (engine.hip, "callers from
+    several threads").  Every thread gets its own streams back, bit for bit."""
+    import threading
+    sets = [mesh_streams("grid", 256, 128), mesh_streams("walk", 100, 77), mesh_streams("multi", 64, 33),
+            mesh_streams("grid", 193, 50, seed=0x12345679), mesh_streams("walk", 64, 9), mesh_streams("grid", 64, 64)]
+    blobs = [oracle_archive(s) for s in sets]
+    errs = []
+    gate = threading.Barrier(len(sets))
+
+    def work(k):
+        try:
+            r = api.Archive.open_for_reading(blobs[k])
+            gate.wait()
+            for name, data, count in sets[k]:
+                got = np.zeros_like(data)
+                if r.read(name, got) != 1:
+                    errs.append((k, name, api.last_error()))
+                    return
+                if got.tobytes() != data.tobytes():
+                    errs.append((k, name, "differs"))
+                    return
+            r.close()
+        except Exception as e:      # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    for rep in range(3):
+        th = [threading.Thread(target=work, args=(k,)) for k in range(len(sets))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(300)
+        assert all(not t.is_alive() for t in th)
+        assert not errs, errs

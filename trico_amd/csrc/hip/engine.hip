@@ -19,6 +19,8 @@
 // behind the scalar data cache) is memory of its own that is never handed to anything else.
 #include "common.hpp"
 
+#include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
@@ -264,12 +266,9 @@ int trico_hip_decode_jobs_reserve(const trico_hip_decode_job* jobs, int count)
   return ok;
   }
 
-int trico_hip_decode_jobs(trico_hip_decode_job* jobs, int count)
+// one batch, start to finish (the callers' streams have been drained by their own threads)
+static int run_batch(trico_hip_decode_job* jobs, int count)
   {
-  if (!device_ready() || !jobs || count < 0)
-    return 0;
-  if (count == 0)
-    return 1;
   Kind* kind = (Kind*)malloc(sizeof(Kind) * (size_t)count);
   const uint8_t* (*d_pay)[8] = (const uint8_t* (*)[8])calloc((size_t)count, sizeof(const uint8_t*[8]));
   void** d_dst = (void**)calloc((size_t)count, sizeof(void*));
@@ -290,14 +289,6 @@ int trico_hip_decode_jobs(trico_hip_decode_job* jobs, int count)
   const Plan plan = make_plan(jobs, count, kind);
   hipStream_t user = current_stream();
   bool launched = engine_init() && reserve_all(plan, count);
-  if (launched)
-    {
-    // whatever produced the payloads on the caller's stream comes first
-    launched = hip_ok(hipEventRecord(E.ev_user, user), "hipEventRecord") &&
-               hip_ok(hipStreamWaitEvent(E.s32, E.ev_user, 0), "hipStreamWaitEvent") &&
-               hip_ok(hipStreamWaitEvent(E.s64, E.ev_user, 0), "hipStreamWaitEvent") &&
-               hip_ok(hipStreamWaitEvent(E.sint, E.ev_user, 0), "hipStreamWaitEvent");
-    }
   uint32_t* d_status = (uint32_t*)E.status.p;
   if (launched)
     launched = hip_ok(hipMemsetAsync(d_status, 0, (size_t)count * STATUS_WORDS * 4, E.s32), "memset(status)") &&
@@ -463,5 +454,94 @@ int trico_hip_decode_jobs(trico_hip_decode_job* jobs, int count)
   free(d_dst);
   return all_ok;
   }
+
+// ---- callers from several threads become ONE batch -----------------------------------------------------------------------
+// The reference's threading model is one archive handle per thread, so an application that decodes N archives
+// does it from N threads.  A batch keeps the engine for seconds; calls that simply queued behind each other would run one
+// after the other (8 threads: 8 x 1.8 s), and calls with engines of their own would put N chain grids on however many hardware
+// queues the process has (round 2).  So the calls are combined: the first thread to arrive leads - it waits a moment for
+// others that were started together, takes every job that has been handed in, runs ONE batch and hands the results back;
+// threads that arrive while a batch is running form the next one.
+namespace {
+struct Waiter { trico_hip_decode_job* jobs; int count; bool done; int result; Waiter* next; };
+std::mutex q_mu;
+std::condition_variable q_cv;
+Waiter* q_head = nullptr;
+Waiter* q_tail = nullptr;
+bool q_leading = false;
+}
+
+int trico_hip_decode_jobs(trico_hip_decode_job* jobs, int count)
+  {
+  if (!device_ready() || !jobs || count < 0)
+    return 0;
+  if (count == 0)
+    return 1;
+  // whatever produced the payloads on this thread's stream comes first (the batch may be launched by another thread)
+  if (!hip_ok(hipStreamSynchronize(current_stream()), "hipStreamSynchronize"))
+    return 0;
+  Waiter me = { jobs, count, false, 0, nullptr };
+  std::unique_lock<std::mutex> lk(q_mu);
+  if (q_tail) q_tail->next = &me; else q_head = &me;
+  q_tail = &me;
+  while (q_leading && !me.done)
+    q_cv.wait(lk);
+  if (me.done)
+    {
+    if (!me.result)
+      set_error("trico_hip_decode_jobs: a stream of this call's jobs failed (decoded in a batch led by another thread)");
+    return me.result;
+    }
+  q_leading = true;
+  q_cv.wait_for(lk, std::chrono::microseconds(150), [] { return false; });       // threads started together land in this batch
+  Waiter* batch = q_head;
+  q_head = q_tail = nullptr;
+  lk.unlock();
+  int total = 0;
+  for (Waiter* w = batch; w; w = w->next)
+    total += w->count;
+  int result_all;
+  if (batch == &me && !me.next)
+    result_all = run_batch(jobs, count);                                          // the common case: nobody else
+  else
+    {
+    trico_hip_decode_job* all = (trico_hip_decode_job*)malloc(sizeof(trico_hip_decode_job) * (size_t)total);
+    if (!all)
+      result_all = -1;
+    else
+      {
+      int at = 0;
+      for (Waiter* w = batch; w; w = w->next)
+        {
+        memcpy(all + at, w->jobs, sizeof(trico_hip_decode_job) * (size_t)w->count);
+        at += w->count;
+        }
+      result_all = run_batch(all, total);
+      at = 0;
+      for (Waiter* w = batch; w; w = w->next)
+        {
+        for (int i = 0; i < w->count; ++i)
+          w->jobs[i].ok = all[at + i].ok;
+        at += w->count;
+        }
+      free(all);
+      }
+    }
+  lk.lock();
+  for (Waiter* w = batch; w;)
+    {
+    Waiter* nx = w->next;                       // (a follower's Waiter lives on its stack: gone once it is woken with done set)
+    int r = result_all < 0 ? 0 : 1;
+    for (int i = 0; r && i < w->count; ++i)
+      r = w->jobs[i].ok ? 1 : 0;
+    w->result = r;
+    w->done = true;
+    w = nx;
+    }
+  q_leading = false;
+  q_cv.notify_all();
+  return me.result;
+  }
+
 
 } // extern "C"

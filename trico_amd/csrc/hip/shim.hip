@@ -2,6 +2,7 @@
 // host<->device staging and dispatch to the gfx950 kernels.  No compute happens on the host.
 #include "common.hpp"
 
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <stdio.h>
@@ -163,9 +164,10 @@ ProfSpan::~ProfSpan()
   }
 
 static int g_device_state = 0;   // 0 unknown, 1 ok, -1 none
-static thread_local uint32_t g_stats[4] = { 0, 0, 0, 0 };
+static thread_local uint32_t g_stats[4] = { 0, 0, 0, 0 };      // words 0, 1: the last trico_hip_int_encode of this thread
+static std::atomic<uint32_t> g_repeats{ 0 }, g_other_writer{ 0 };   // words 2, 3: process-wide (a batch may be led by another thread)
 
-void stats_count_repeat() { g_stats[2] += 1; }
+void stats_count_repeat() { g_repeats += 1; }
 void set_current_stream(hipStream_t s) { g_stream = s; }
 
 bool device_ready()
@@ -809,7 +811,7 @@ static int decode_complete(trico_hip_ctx* ctx, const char* what)
     {
     // the payload parsed but the values do not code back to it: the chain went wrong (see fpc_chain_decode).  Twice more, then
     // in reference order without the scalar cache (20x slower).
-    g_stats[2] += 1;
+    g_repeats += 1;
     if (getenv("TRICO_HIP_DEBUG"))
       fprintf(stderr, "trico_hip: decode self-check failed (status %#x, %d x %u values of %d bytes), attempt %d\n", st, ctx->chk_arity, ctx->chk_n,
               ctx->chk_width, attempt + 1);
@@ -848,7 +850,7 @@ static int decode_complete(trico_hip_ctx* ctx, const char* what)
       // reference's, fpsc.c:308-326).  If that does not code back to the payload either, the payload was not written by the
       // reference's encoder (another writer may choose other, equally decodable codes): the values stand, and word 3 of
       // trico_hip_last_stats counts the stream so that a caller can see it.
-      g_stats[3] += 1;
+      g_other_writer += 1;
       st = 0;
       }
     }
@@ -1270,7 +1272,10 @@ const uint8_t* trico_hip_payload_device_pointer(trico_hip_ctx* ctx, int c)
 
 void trico_hip_last_stats(uint32_t out[4])
   {
-  for (int i = 0; i < 4; ++i) out[i] = g_stats[i];
+  out[0] = g_stats[0];
+  out[1] = g_stats[1];
+  out[2] = g_repeats.load();
+  out[3] = g_other_writer.load();
   }
 
 void trico_hip_profile_enable(int on) { g_prof_on = on != 0; }
