@@ -1,5 +1,6 @@
 """BASELINE config 5 on one GPU: K .trc archives (config-2 meshes, different seeds) decoded concurrently, one host
-thread per archive (ctypes releases the GIL; every archive handle owns its contexts and HIP streams).
+thread per archive (ctypes releases the GIL) through the plain trico_read_* calls; the decode engine combines the calls that
+arrive together into one batch (tools/bench_batch_decode.py hands the archives over as a batch explicitly).
 Prints aggregate decode throughput (decoded bytes / wall time) for K = 1, 2, 4, 8 (TRICO_BENCH_READERS=1,8,16,32 for other
 counts: readers beyond the eighth decode the archives of the first eight again, into buffers of their own).
 
@@ -10,10 +11,6 @@ import sys
 import threading
 import time
 
-# ROCm maps HIP streams onto 4 hardware queues by default; kernels that share a queue run one after the other, and a
-# float decode occupies its queue for seconds.  libtrico asks for 16 when it makes the first HIP call of a process;
-# here torch may get there first, so it is set explicitly (before the HIP runtime initialises).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch

@@ -493,7 +493,25 @@ int trico_hip_decode_jobs(trico_hip_decode_job* jobs, int count)
     return me.result;
     }
   q_leading = true;
-  q_cv.wait_for(lk, std::chrono::microseconds(150), [] { return false; });       // threads started together land in this batch
+  {
+  // Threads started together should land in this batch: wait while calls keep arriving, for a time that is small against what the
+  // batch itself will take (the longest float / double chain at ~35 ns per value decides that): at most 1 % of it, at most 10 ms.
+  double est_us = 0.0;
+  for (int i = 0; i < count; ++i)
+    if (!jobs[i].is_int && jobs[i].dst)
+      est_us = est_us > 0.035 * jobs[i].n ? est_us : 0.035 * jobs[i].n;
+  long window = (long)(est_us / 100.0);
+  window = window < 40 ? 40 : (window > 10000 ? 10000 : window);
+  const auto t_start = std::chrono::steady_clock::now();
+  for (;;)
+    {
+    const Waiter* seen = q_tail;
+    q_cv.wait_for(lk, std::chrono::microseconds(window / 4 + 10), [] { return false; });
+    const long waited = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_start).count();
+    if (waited >= window || (q_tail == seen && waited >= window / 2))
+      break;
+    }
+  }
   Waiter* batch = q_head;
   q_head = q_tail = nullptr;
   lk.unlock();
