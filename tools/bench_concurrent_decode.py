@@ -45,7 +45,7 @@ def decode(k, errs):
 
 
 results = []
-for K in KS:
+for K in [k for k in KS for _ in range(2)]:      # every count twice: the second pass finds its device buffers in the library's pool
     errs = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
