@@ -240,8 +240,19 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
       cand = uni(tab[h]);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       if (lane == 0) tab[h] = ip;
-      if (cand + MAXD >= ip && uni(ld32(src + cand)) == uni(ld32(src + ip)))
+      // (8 bytes at both places instead of 4: ip < n - 11 and cand < ip, so both reads stay inside the block; a match that ends
+      // within them - the usual case on a plane of short sequences - then needs no counting round trip, like the hits of the search)
+      const uint64_t wcand = ld64(src + cand), wip = ld64(src + ip);
+      if (cand + MAXD >= ip && uni((uint32_t)wcand) == uni((uint32_t)wip))
+        {
         have_match = true;                                                         // lz4.c:1101-1138: literal length 0, no catch-up
+        const uint32_t dx = uni((uint32_t)((wcand ^ wip) >> 32));
+        if (dx)
+          {
+          fast = true;
+          fast_extra = (uint32_t)__builtin_ctz(dx) >> 3;                           // equal bytes behind the first four: 0 .. 3
+          }
+        }
       else
         ++ip;
       at_match_end = false;
@@ -404,7 +415,6 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
       const uint32_t cap = c_hi - (ip + 4u);
       if (cap < limit) limit = cap;
       }
-    // (have_match without a search - the test right behind a match - has no bytes at hand: fast is false there)
     const uint32_t m = (fast && fast_extra < limit) ? fast_extra : wave_count<NW>(src + ip + 4u, src + cand + 4u, limit, lane, wave, xch);
     if (!emit && limit < room && m >= limit)
       break;                                                                       // ran past c_hi during warm-up
