@@ -91,3 +91,54 @@ def test_stream_sharded_write_on_the_gpu_matches_the_reference_archive():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r = subprocess.run([sys.executable, "-c", SHARD_WORKER % (ROOT, ROOT, ROOT)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-500:] + r.stderr[-2500:]
+
+
+GLOO_SHARD_WORKER = r'''
+import os, sys, hashlib, json
+sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, torch
+import torch.distributed as dist
+from trico_amd import api
+from trico_amd.parallel import sharded_write, hip_unit_encoder
+from streams import mesh_streams
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+hashes = json.load(open(os.path.join(%r, "tests", "golden", "hashes.json")))
+enc = hip_unit_encoder(api)
+for kind in ("grid", "multi"):
+    streams = mesh_streams(kind, 1000, 1000)
+    dev = [(n, torch.from_numpy(a.view(np.uint8)).cuda(), c) for n, a, c in streams]
+    a = sharded_write(dist, api, dev, enc, root=0, device_archive=False)
+    if rank == 0:
+        blob = a.tobytes()
+        a.close()
+        g = hashes["%%s_1000x1000" %% kind]
+        assert len(blob) == g["size"] and hashlib.sha256(blob).hexdigest() == g["sha256"], kind
+    else:
+        assert a is None
+enc.close()
+dist.barrier()
+dist.destroy_process_group()
+print("RANK", rank, "OK")
+'''
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_stream_sharded_write_with_several_ranks_on_one_gpu(world):
+    """More than one rank with the REAL unit encoders: `world` processes share this box's GPU (every rank encodes its units of the
+    grid's 7 and the multi mesh's 16 on it), the exchange runs over gloo through host memory, rank 0 assembles.  The archive is the
+    reference's (sha256 of config 1 and its multi sibling).  What this does not exercise is RCCL between GPUs: there is one GPU."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world))
+        procs.append(subprocess.Popen([sys.executable, "-c", GLOO_SHARD_WORKER % (ROOT, ROOT, ROOT)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for r, (p, (o, e)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "OK" in o, "rank %d: %s %s" % (r, o[-300:], e[-1500:])

@@ -130,7 +130,9 @@ def sharded_write(dist, api, streams, encode_unit, root=0, device_archive=False,
     units = stream_units(streams)
     mine = shard_units(len(units), world, rank)
     payloads = [encode_unit(streams[units[u][0]][0], streams[units[u][0]][1], streams[units[u][0]][2], units[u][1]) for u in mine]
-    dev = payloads[0].device if payloads else collective_device(dist)
+    dev = collective_device(dist)
+    # (gloo moves host tensors: payloads encoded on a GPU travel through host memory then; under nccl they stay where they are)
+    payloads = [p if p.device.type == dev.type else p.to(dev) for p in payloads]
     # every rank's unit sizes, padded to the same length: one small all-gather
     per = (len(units) + world - 1) // world
     mysz = torch.zeros(per, dtype=torch.int64, device=dev)
