@@ -1,7 +1,7 @@
 """Stress: K readers decode full-size archives (grid / walk, optionally multi) at once, repeatedly; every decoded stream is compared with
 its input.  Prints the failures with reader, round and stream.   python tools/stress_concurrent.py [rounds] [with_multi]"""
 import os, sys, threading, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# (no queue setting: the decode engine needs none)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
