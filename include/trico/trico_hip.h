@@ -74,15 +74,6 @@ TRICO_API int trico_hip_int_encode(trico_hip_ctx* ctx, const void* src, uint32_t
 TRICO_API int trico_hip_int_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[8], const uint32_t sizes[8],
                                    int width, uint32_t count, void* dst);
 
-/* Read-ahead decode: _begin stages the payloads of one stream (is_int: `width` byte planes; otherwise `arity`
- * components of `width`-byte reals) and launches its decode on a stream private to `ctx`, parking the
- * result in the context; _finish waits for it, returns 0 if the payload was malformed, and copies the n
- * decoded elements to dst (host or device; NULL drops them).  The archive readers use one context per
- * stream of an archive so that all streams decode concurrently (trico.c:943-1668 decodes them one by one). */
-TRICO_API int trico_hip_decode_begin(trico_hip_ctx* ctx, int is_int, const uint8_t* const* payloads, const uint32_t* sizes,
-                                     int arity, int width, uint32_t n);
-TRICO_API int trico_hip_decode_finish(trico_hip_ctx* ctx, void* dst);
-
 /* ---- batched decode: one launch for all chains -------------------------------------------------
  * The format leaves ONE serial chain per floating-point component (fpsc.c:308-326), so decode throughput is the number of
  * chains in flight.  A job is one stream (what one trico_read_* call decodes, trico.c:943-1668); a batch may hold the streams

@@ -66,11 +66,6 @@ struct trico_hip_ctx
   int slots_arity = 0;
   bool out_materialized[3] = { false, false, false };
   uint32_t* h_pinned = nullptr;   // 64 words of pinned host memory for size/status read-back
-  // read-ahead decode (trico_hip_decode_begin / _finish): private stream, result parked in `out`
-  hipStream_t stream = nullptr;
-  hipEvent_t ready = nullptr;
-  bool pending = false;
-  size_t pending_bytes = 0;
   };
 
 namespace trico {

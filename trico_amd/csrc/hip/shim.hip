@@ -243,12 +243,6 @@ void trico_hip_ctx_destroy(trico_hip_ctx* ctx)
   if (!ctx)
     return;
   (void)hipStreamSynchronize(current_stream());
-  if (ctx->stream)
-    {
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamDestroy(ctx->stream);
-    (void)hipEventDestroy(ctx->ready);
-    }
   ctx->in.release();
   ctx->out.release();
   ctx->tmp.release();
@@ -1059,59 +1053,6 @@ int trico_hip_int_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[8], c
     TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
     }
   return 1;
-  }
-
-// ---- read-ahead: decode into the context on a private stream, collect later -----------------------
-// The format leaves one serial chain per component stream, so a single stream keeps a handful of waves busy
-// for seconds while 250 CUs idle.  An archive reader therefore starts the decode of every stream it can see
-// (each on its own context and HIP stream) and the trico_read_* calls only collect results.
-
-int trico_hip_decode_begin(trico_hip_ctx* ctx, int is_int, const uint8_t* const* payloads, const uint32_t* sizes,
-                           int arity, int width, uint32_t n)
-  {
-  if (!ctx || !device_ready() || ctx->pending)
-    return 0;
-  if (is_int ? (width != 1 && width != 2 && width != 4 && width != 8) : (arity < 1 || arity > 3 || (width != 4 && width != 8)))
-    return 0;
-  if (!ctx->stream)
-    {
-    if (!hip_ok(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate") ||
-        !hip_ok(hipEventCreateWithFlags(&ctx->ready, hipEventDisableTiming), "hipEventCreate"))
-      return 0;
-    }
-  // whatever produced the payloads on the caller's stream comes first
-  hipStream_t user = g_stream;
-  TRICO_HIP_TRY(hipEventRecord(ctx->ready, user));
-  TRICO_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ready, 0));
-  g_stream = ctx->stream;
-  const int ok = is_int ? int_decode_launch(ctx, payloads, sizes, width, n, nullptr)
-                        : fpc_decode_launch(ctx, payloads, sizes, arity, width, n, nullptr);
-  g_stream = user;
-  if (!ok)
-    {
-    (void)hipStreamSynchronize(ctx->stream);
-    return 0;
-    }
-  ctx->pending = true;
-  ctx->pending_bytes = (size_t)n * (size_t)width * (size_t)(is_int ? 1 : arity);
-  return 1;
-  }
-
-int trico_hip_decode_finish(trico_hip_ctx* ctx, void* dst)
-  {
-  if (!ctx || !ctx->pending)
-    return 0;
-  ctx->pending = false;
-  hipStream_t user = g_stream;
-  g_stream = ctx->stream;
-  int ok = decode_complete(ctx, "trico read-ahead: malformed payload");
-  if (ok && dst && ctx->pending_bytes)
-    {
-    ok = hip_ok(hipMemcpyAsync(dst, ctx->out.p, ctx->pending_bytes, hipMemcpyDefault, ctx->stream), "read-ahead copy") &&
-         hip_ok(hipStreamSynchronize(ctx->stream), "read-ahead copy") ? 1 : 0;
-    }
-  g_stream = user;
-  return ok;
   }
 
 // ---- stand-alone transposes (the reference's transpose_aos_to_soa.h) ------------------------------
