@@ -97,6 +97,9 @@ TRICO_API int trico_hip_decode_jobs(trico_hip_decode_job* jobs, int count);
 /* allocates (and keeps) the device workspaces a batch of this shape needs, without decoding: takes the allocation out of the
  * latency of the first trico_hip_decode_jobs call.  Later batches of the same or a smaller shape allocate nothing either way. */
 TRICO_API int trico_hip_decode_jobs_reserve(const trico_hip_decode_job* jobs, int count);
+/* The engine's workspaces and the library's pool of recycled device buffers are kept for the next call (grow-only); this gives
+ * all of that memory back to the device (buffers owned by live archive handles stay).  Not to be called while another thread decodes. */
+TRICO_API void trico_hip_release_workspaces(void);
 
 /* ---- whole archives at once --------------------------------------------------------------------
  * trico_hip_list_streams: describes the streams from the cursor of a read archive to its end, without consuming them

@@ -83,6 +83,18 @@ def test_read_archives_equals_one_by_one(api, allstreams, where):
     assert stats[2] == repeats_before, "a chain decode had to be repeated"
 
 
+def test_release_workspaces_and_decode_again(api, allstreams):
+    """trico_hip_release_workspaces gives the engine's buffers and the pool back; the next batch allocates again and decodes the same."""
+    blob, streams = some_archives(allstreams)[0]
+    for _ in range(2):
+        r = api.Archive.open_for_reading(blob)
+        outs = empty_like_streams(streams)
+        assert api.read_archives([r], [outs]) == 1, api.last_error()
+        assert all(o.tobytes() == d.tobytes() for o, (_, d, _) in zip(outs, streams))
+        r.close()
+        api.lib().trico_hip_release_workspaces()
+
+
 def test_read_archives_prefix_and_skips(api, allstreams):
     """nstreams smaller than what is left: the rest stays unread; a NULL destination skips its stream."""
     blob, streams = some_archives(allstreams)[5]

@@ -59,7 +59,7 @@ HIP_SYMBOLS = [
     "trico_hip_open_archive_for_writing_device", "trico_hip_profile_enable", "trico_hip_profile_reset",
     "trico_hip_profile_ms", "trico_hip_last_stats",
     "trico_hip_decode_jobs", "trico_hip_decode_jobs_reserve", "trico_hip_list_streams", "trico_hip_read_archives",
-    "trico_hip_walk_frames",
+    "trico_hip_walk_frames", "trico_hip_release_workspaces",
 ]
 
 
@@ -190,6 +190,7 @@ def lib():
     L.trico_hip_list_streams.restype = ci
     L.trico_hip_read_archives.argtypes = [ctypes.POINTER(vp), ci, ctypes.POINTER(ctypes.POINTER(vp)), ctypes.POINTER(ci)]
     L.trico_hip_read_archives.restype = ci
+    L.trico_hip_release_workspaces.restype = None
     _lib = L
     return L
 

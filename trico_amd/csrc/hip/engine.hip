@@ -249,6 +249,22 @@ using namespace trico;
 
 extern "C" {
 
+void trico_hip_release_workspaces(void)
+  {
+  if (!device_ready())
+    return;
+  std::lock_guard<std::mutex> lock(E.mu);
+  (void)hipDeviceSynchronize();
+  DevBuf* bufs[] = { &E.jobs32, &E.jobs64, &E.status, &E.in, &E.parked, &E.vws32, &E.vws64, &E.lz4ws, &E.planes };
+  for (DevBuf* b : bufs)
+    b->release();                                   // to the pool ...
+  trim_pool();                                      // ... which is freed as a whole
+  if (E.scratch32) (void)hipFree(E.scratch32);
+  if (E.chain64) (void)hipFree(E.chain64);
+  E.scratch32 = E.chain64 = nullptr;
+  E.scratch32_cap = E.chain64_cap = 0;
+  }
+
 int trico_hip_decode_jobs_reserve(const trico_hip_decode_job* jobs, int count)
   {
   if (!device_ready() || !jobs || count < 0)
