@@ -50,4 +50,8 @@ for rnd in range(rounds):
     print("round %d: %.2f s, failures so far: %d" % (rnd, time.perf_counter() - t0, len(fails)), flush=True)
 for f in fails:
     print("FAIL", f)
-print("done: %d failures in %d rounds" % (len(fails), rounds))
+import ctypes
+st = (ctypes.c_uint32 * 4)()
+api.lib().trico_hip_last_stats(st)
+print("done: %d failures in %d rounds of %d readers; chain decodes repeated by the self-check: %d; payloads of another writer: %d"
+      % (len(fails), rounds, len(order), st[2], st[3]))
