@@ -301,3 +301,26 @@ def test_threads_with_one_archive_each_share_a_batch(api):
             t.join(300)
         assert all(not t.is_alive() for t in th)
         assert not errs, errs
+
+
+def test_batch_with_an_empty_stream_and_a_bad_job(api):
+    """An empty float stream (count 0: header + pad group here, undefined in the reference) inside a batch goes through the
+    single-stream path; a job with a nonsensical shape fails alone."""
+    v = np.zeros(0, np.float32)
+    t = np.arange(12, dtype=np.uint32)
+    a = api.Archive.open_for_writing(64)
+    assert a.write("vertices", v, 0) == 1 and a.write("triangles", t, 4) == 1, api.last_error()
+    blob = a.tobytes()
+    a.close()
+    r = api.Archive.open_for_reading(blob)
+    infos = api.list_streams(r)
+    assert [i.n for i in infos] == [0, 12] and [i.decoded_bytes for i in infos] == [0, 48]
+    out_v, out_t = np.zeros(1, np.float32), np.zeros(12, np.uint32)
+    assert api.read_archives([r], [[out_v, out_t]]) == 1, api.last_error()
+    assert out_t.tolist() == t.tolist() and r.get_next_stream_type() == api.trico_empty
+    r.close()
+    good = np.arange(64, dtype=np.uint8)
+    jobs = api.make_jobs([{"is_int": 1, "width": 3, "n": 64, "payloads": [(good, 64)], "dst": np.zeros(64, np.uint8)},
+                          {"is_int": 0, "arity": 7, "width": 4, "n": 64, "payloads": [(good, 64)], "dst": np.zeros(64, np.float32)}])
+    assert api.lib().trico_hip_decode_jobs(jobs, 2) == 0
+    assert jobs[0].ok == 0 and jobs[1].ok == 0
