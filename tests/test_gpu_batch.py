@@ -266,6 +266,20 @@ def test_tagged_table_code_sweep_writes_the_same_bytes():
     assert out.returncode == 0 and "ENCODE OK" in out.stdout, out.stdout + out.stderr
 
 
+@pytest.mark.parametrize("env_add", [{"TRICO_FPC32_TILE": "3"}, {"TRICO_FPC32_TILE": "1"}, {"TRICO_FPC32_TILE": "2"},
+                                     {"TRICO_FPC32_TILE": "3", "TRICO_FPC32_ATOMIC": "1"}, {"TRICO_FPC32_PRIO": "0"},
+                                     {"TRICO_FPC32_PRIO": "3"}])
+def test_encoder_variants_write_the_same_bytes(env_add):
+    """The opt-in shapes of the float encoder (k_fpc32_encode.hip): TRICO_FPC32_TILE bit 0 / bit 1 = the index / code sweep with one
+    wave per segment that walks all three components of whole vertices (the interleaved array is read once per sweep);
+    TRICO_FPC32_PRIO = who gets the issue slots among the component waves of a workgroup (default 8: whoever is behind).  They
+    decide time and traffic, never bytes."""
+    env = dict(os.environ)
+    env.update(env_add)
+    out = subprocess.run([sys.executable, "-c", ENC_CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ENCODE OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_threads_with_one_archive_each_share_a_batch(api):
     """The reference's threading model: one archive handle per thread.  Six threads read six different archives at the same time
     through the plain trico_read_* calls; the engine combines what arrives together into one batch (engine.hip, "callers from

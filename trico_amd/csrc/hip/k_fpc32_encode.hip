@@ -240,6 +240,88 @@ __global__ void __launch_bounds__(192) k_fpc32_index(const uint32_t* __restrict_
     }
   }
 
+// ---- tile variant of sweep A: one wave owns a segment with ALL its components ---------------------------------------------
+// Lane l loads vertex i0 + l whole (A consecutive dwords: the 64 lanes of a load cover 64 * A * 4 contiguous bytes), so every
+// cache line of the interleaved array is requested once per sweep, by one wave, with no staging through LDS and no barrier.
+// The wave walks the components of a tile one after the other; their tables sit side by side in its LDS.  No sub-ranges
+// (the whole GPU is covered by S one-wave workgroups), so the rows are written directly and need no zeroing.
+template <int A> struct __attribute__((packed, aligned(4))) VertexT { uint32_t w[A]; };
+constexpr int PFT = 2;         // tiles (of 64 vertices) whose loads are kept in flight beside the block being worked on
+
+constexpr int PFI = 8;         // ... in sweep A, which has nothing but its loads to wait for
+
+template <int A, int P>
+__device__ __forceinline__ void load_tiles(uint32_t (&r)[P][A], const uint32_t* __restrict__ src, uint32_t i0, uint32_t i_end, int lane)
+  {
+#pragma unroll
+  for (int pu = 0; pu < P; ++pu)
+    {
+    const uint32_t i = i0 + 64u * pu + lane;
+    VertexT<A> t = {};
+    if (i0 < i_end && i < i_end)
+      t = *(const VertexT<A>*)(src + (size_t)i * A);
+#pragma unroll
+    for (int c = 0; c < A; ++c)
+      r[pu][c] = t.w[c];
+    }
+  }
+
+template <int A>
+__global__ void __launch_bounds__(64) k_fpc32_index_t(const uint32_t* __restrict__ src, uint32_t n, uint32_t L, uint32_t* __restrict__ summ)
+  {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int lane = threadIdx.x;
+  const uint32_t g = blockIdx.x;
+  for (int i = lane; i < A * TAB; i += 64)
+    lds[i] = 0u;
+  const uint32_t i_begin = g * L;
+  const uint32_t i_end = (n - i_begin < L) ? n : i_begin + L;
+  Carry cy[A];
+#pragma unroll
+  for (int c = 0; c < A; ++c)
+    cy[c] = load_carry(src, i_begin, A, c);
+  uint32_t cur[PFI][A], nxt[PFI][A];
+  load_tiles<A, PFI>(cur, src, i_begin, i_end, lane);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (uint32_t ib = i_begin; ib < i_end; ib += 64u * PFI)
+    {
+    load_tiles<A, PFI>(nxt, src, ib + 64u * PFI, i_end, lane);
+#pragma unroll
+    for (int pu = 0; pu < PFI; ++pu)
+      {
+      const uint32_t i0 = ib + 64u * pu;
+      if (i0 < i_end)
+        {
+        const uint32_t i = i0 + lane;
+        const bool act = i < i_end;
+#pragma unroll
+        for (int c = 0; c < A; ++c)
+          {
+          uint32_t* T = lds + c * TAB;
+          const uint32_t v = cur[pu][c];
+          uint32_t a, b, k1, k2;
+          classes(v, cy[c], act, a, b, k1, k2);
+          const uint32_t kn1 = dpp_shl1(0xfffffffeu, k1), kn2 = dpp_shl1(0xfffffffeu, k2);
+          if (act && k1 != kn1) atomicMax(&T[k1], i + 1u);
+          if (act && k2 != kn2) atomicMax(&T[k2], i + 1u);
+          next_carry(cy[c], v);
+          }
+        }
+      }
+#pragma unroll
+    for (int pu = 0; pu < PFI; ++pu)
+#pragma unroll
+      for (int c = 0; c < A; ++c)
+        cur[pu][c] = nxt[pu][c];
+    }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  uint32_t* row = summ + (size_t)g * A * ROW;
+#pragma unroll
+  for (int c = 0; c < A; ++c)
+    for (int i = lane; i < TAB; i += 64)
+      row[c * ROW + i] = lds[c * TAB + i];
+  }
+
 // ---- scan: incoming index table of segment g = max over earlier segments -----------------------------
 __global__ void __launch_bounds__(256) k_fpc32_scan_a(const uint32_t* __restrict__ summ, uint32_t S, int arity,
                                                       uint32_t* __restrict__ chmax)
@@ -323,7 +405,24 @@ struct Sweep                                      // wave-uniform running state
   uint32_t posl, flushed;                         // bytes staged in LDS / bytes already in the slot
   uint32_t tag;                                   // resolve_atomic: number of the resolving step, << 6
   uint32_t viol;                                  // resolve_atomic: the LDS unit applied an atomic out of lane order
+  uint32_t fl_nb, fl_off;                         // flush in flight: 256-byte blocks (0 = none) and their offset in the slot
+  uint32_t fw0, fw1, ft;                          // ... per lane: its words of the blocks and of what moves to the front
   };
+
+// second half of a flush (see the end of code_step): the words read from the staging area a step ago go to the slot, the
+// unflushed rest moves to the front.  Must run before the next byte is staged.
+__device__ __forceinline__ void flush_end(Sweep& sw, uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase, const LaneK& lk)
+  {
+  if (sw.fl_nb)
+    {
+    *(uint32_t*)(gbase + sw.fl_off + 4u * (uint32_t)lk.lane) = sw.fw0;
+    if (sw.fl_nb == 2u)
+      *(uint32_t*)(gbase + sw.fl_off + 256u + 4u * (uint32_t)lk.lane) = sw.fw1;
+    ((uint32_t*)stage)[lk.lane] = sw.ft;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    sw.fl_nb = 0u;
+    }
+  }
 
 // lanes whose class equals mine, for B-bit classes (B even): one ballot per class bit.  `diff` collects the lanes that differ
 // from me in some bit: diff |= ballot(bit) ^ mybit, one v_bitop3 per half; the caller takes live & ~diff.  Four vector
@@ -569,6 +668,7 @@ __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_en
   bc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bc, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
   bc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bc, 0x141, 0xf, 0xf, true);    // row_half_mirror
   const uint32_t hq = sw.posl + lk.grp3 + pre;               // my group's header (if I lead it), my residual starts at hq + 3
+  flush_end(sw, stage, gbase, lk);
   {
   const uint32_t re = len ? hq + len : lk.dumpq;             // residual end - 3
   // most significant byte first, in this order (a zero byte of lane l must not overtake the byte its owner writes);
@@ -592,16 +692,17 @@ __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_en
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (sw.posl >= 256u)
     {
-    // full 256-byte blocks go to the slot as aligned dwords, the rest moves to the front of the staging area
+    // Full 256-byte blocks go to the slot as aligned dwords, the rest moves to the front of the staging area.  Only the LDS reads
+    // are issued here; their data is used by flush_end() in the next step, right before its first byte is staged (LDS operations
+    // of a wave execute in order), so the wave never waits for the round trip.
     const uint32_t* stw = (const uint32_t*)stage;
     const uint32_t nb = sw.posl >> 8;                        // 1 or 2
-    *(uint32_t*)(gbase + sw.flushed + 4u * (uint32_t)lk.lane) = stw[lk.lane];
-    if (nb == 2u)
-      *(uint32_t*)(gbase + sw.flushed + 256u + 4u * (uint32_t)lk.lane) = stw[64 + lk.lane];
-    const uint32_t t = stw[nb * 64u + (uint32_t)lk.lane];
+    sw.fw0 = stw[lk.lane];
+    sw.fw1 = stw[64 + lk.lane];
+    sw.ft = stw[nb * 64u + (uint32_t)lk.lane];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    ((uint32_t*)stage)[lk.lane] = t;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    sw.fl_nb = nb;
+    sw.fl_off = sw.flushed;
     sw.flushed += nb << 8;
     sw.posl &= 255u;
     }
@@ -611,14 +712,18 @@ __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_en
 // ATOMIC: table entries of 64 bits and resolve_atomic (one LDS instruction per predictor and step); else 32-bit entries and resolve
 // (ballots).  `flags`: word 0 is raised when an ATOMIC step found the LDS unit out of lane order.
 template <bool ATOMIC>
-__global__ void __launch_bounds__(192) k_fpc32_code(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t L, uint32_t S,
+__global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))) k_fpc32_code(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t L, uint32_t S,
                                                     const uint32_t* __restrict__ inc, uint8_t* __restrict__ slots, size_t slot_stride,
-                                                    uint32_t segcap, uint32_t* __restrict__ segbytes, uint32_t* __restrict__ flags)
+                                                    uint32_t segcap, uint32_t* __restrict__ segbytes, uint32_t* __restrict__ flags,
+                                                    uint32_t prio_mode)
   {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t g = blockIdx.x;
   constexpr int TW = ATOMIC ? 2 * TAB : TAB;           // table words
+  volatile uint32_t* prog = lds + arity * (ATOMIC ? LDSW_CA : LDSW_C);   // [4] progress of the component waves (prio_mode 8)
+  if (prio_mode >= 1u && prio_mode <= 3u && (uint32_t)c == prio_mode - 1u)
+    __builtin_amdgcn_s_setprio(3);
   uint32_t* T = lds + c * (ATOMIC ? LDSW_CA : LDSW_C); // [TAB] payload table (ATOMIC: {payload, tag} pairs)
   uint8_t* stage = (uint8_t*)(T + TW);                 // [STAGE] packed bytes of the steps not yet flushed + dump
   // incoming table: payload of the last writer of every class before this segment (0 if none)
@@ -657,6 +762,7 @@ __global__ void __launch_bounds__(192) k_fpc32_code(const uint32_t* __restrict__
   sw.flushed = 0;
   sw.tag = 0;
   sw.viol = 0;
+  sw.fl_nb = 0;
   if (g == 0)
     {
     if (lane == 0)
@@ -670,9 +776,25 @@ __global__ void __launch_bounds__(192) k_fpc32_code(const uint32_t* __restrict__
   sw.cy = load_carry(src, i_begin, arity, c);
   uint32_t cur[PF], nxt[PF];
   load_block(cur, src, i_begin, i_end, arity, c, lane);
+  if (prio_mode == 8u && lane == 0)
+    prog[c] = i_begin;
   for (uint32_t ib = i_begin; ib < i_end; ib += 64u * PF)
     {
     load_block(nxt, src, ib + 64u * PF, i_end, arity, c, lane);
+    if (prio_mode == 8u)
+      {
+      // the component that is behind gets the issue slots first: the waves of a workgroup hold their LDS until the last of them
+      // is done, and the sweep ends when the slowest component does
+      if (lane == 0)
+        prog[c] = ib;
+      uint32_t ahead = 0;
+      for (int o = 0; o < arity; ++o)
+        ahead = max(ahead, (uint32_t)__builtin_amdgcn_readfirstlane((int)prog[o]) + 1u);
+      if (ib + 1u + 64u * PF <= ahead)
+        __builtin_amdgcn_s_setprio(3);
+      else
+        __builtin_amdgcn_s_setprio(0);
+      }
 #pragma unroll
     for (int pu = 0; pu < PF; ++pu)
       {
@@ -687,14 +809,143 @@ __global__ void __launch_bounds__(192) k_fpc32_code(const uint32_t* __restrict__
       cur[pu] = nxt[pu];
     }
   // what is left in the staging area (< 256 bytes)
+  flush_end(sw, stage, gbase, lk);
   {
   const uint32_t off = 4u * (uint32_t)lane;
   if (off < sw.posl)
     store_span(gbase + sw.flushed, off, ((const uint32_t*)stage)[lane], sw.posl);
   }
+  if (prio_mode == 8u && lane == 0)
+    prog[c] = 0u;                                      // done: nobody is behind me any more
   if (lane == 0)
     segbytes[(size_t)c * S + g] = sw.flushed + sw.posl;
   if (ATOMIC && sw.viol && lane == 0)
+    atomicOr(flags, 1u);
+  }
+
+// ---- tile variant of sweep C: one wave codes ALL components of its segment (see k_fpc32_index_t) --------------------------
+// Same steps, same tables and staging areas per component (side by side in the wave's LDS), same slots: only who walks them
+// differs.  The interleaved array is read once, 64 whole vertices per load.
+template <int A, bool ATOMIC>
+__global__ void __launch_bounds__(64) k_fpc32_code_t(const uint32_t* __restrict__ src, uint32_t n, uint32_t L, uint32_t S,
+                                                     const uint32_t* __restrict__ inc, uint8_t* __restrict__ slots, size_t slot_stride,
+                                                     uint32_t segcap, uint32_t* __restrict__ segbytes, uint32_t* __restrict__ flags)
+  {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int lane = threadIdx.x;
+  const uint32_t g = blockIdx.x;
+  constexpr int TW = ATOMIC ? 2 * TAB : TAB;
+  constexpr int LW = ATOMIC ? LDSW_CA : LDSW_C;
+  // incoming tables: payload of the last writer of every class before this segment (0 if none); the loads of all components
+  // of an iteration are independent
+  const uint32_t* row = inc + (size_t)g * A * ROW;
+  for (int k = lane; k < TAB; k += 64)
+    {
+    uint32_t idx[A], vi[A], vp[A];
+#pragma unroll
+    for (int c = 0; c < A; ++c)
+      idx[c] = row[c * ROW + k];
+#pragma unroll
+    for (int c = 0; c < A; ++c)
+      {
+      vi[c] = idx[c] ? src[(size_t)(idx[c] - 1u) * A + c] : 0u;
+      vp[c] = idx[c] >= 2u ? src[(size_t)(idx[c] - 2u) * A + c] : 0u;
+      }
+#pragma unroll
+    for (int c = 0; c < A; ++c)
+      {
+      const uint32_t pay = idx[c] ? (k < 16 ? vi[c] : vi[c] - vp[c]) : 0u;
+      if (ATOMIC)
+        ((unsigned long long*)(lds + c * LW))[k] = pay;
+      else
+        lds[c * LW + k] = pay;
+      }
+    }
+  LaneK lk;
+  lk.lane = lane;
+  lk.lt = (1ull << lane) - 1ull;
+  lk.bit = 1ull << lane;
+  lk.sh3 = 3u * ((uint32_t)lane & 7u);
+  lk.grp3 = 3u * ((uint32_t)lane >> 3);
+  lk.dumpw = (uint32_t)(TW + STAGE_LIVE / 4 + lane);
+  lk.dumpq = (uint32_t)(STAGE_LIVE + 4 * lane + 1);
+  lk.lead = (lane & 7) == 0;
+  const uint32_t i_begin = g * L;
+  const uint32_t i_end = (n - i_begin < L) ? n : i_begin + L;
+  Sweep sw[A];
+#pragma unroll
+  for (int c = 0; c < A; ++c)
+    {
+    sw[c].kc1 = sw[c].kc2 = 0xfffffffeu;
+    sw[c].pend1 = sw[c].pend2 = false;
+    sw[c].posl = 0;
+    sw[c].flushed = 0;
+    sw[c].tag = 0;
+    sw[c].viol = 0;
+    sw[c].fl_nb = 0;
+    if (g == 0)
+      {
+      uint8_t* stage = (uint8_t*)(lds + c * LW + TW);
+      if (lane == 0)
+        {
+        stage[0] = 0x25;
+        stage[1] = (uint8_t)(n >> 24); stage[2] = (uint8_t)(n >> 16); stage[3] = (uint8_t)(n >> 8); stage[4] = (uint8_t)n;
+        }
+      sw[c].posl = 5u;
+      }
+    sw[c].cy = load_carry(src, i_begin, A, c);
+    }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  uint32_t cur[PFT][A], nxt[PFT][A];
+  load_tiles<A, PFT>(cur, src, i_begin, i_end, lane);
+  uint32_t ib = i_begin;
+  for (; ib + 64u * PFT <= i_end; ib += 64u * PFT)
+    {
+    load_tiles<A, PFT>(nxt, src, ib + 64u * PFT, i_end, lane);
+#pragma unroll
+    for (int pu = 0; pu < PFT; ++pu)
+#pragma unroll
+      for (int c = 0; c < A; ++c)
+        code_step<true, ATOMIC>(cur[pu][c], ib + 64u * pu, i_end, n, lds + c * LW, (uint8_t*)(lds + c * LW + TW),
+                                slots + (size_t)c * slot_stride + (size_t)g * segcap, sw[c], lk);
+#pragma unroll
+    for (int pu = 0; pu < PFT; ++pu)
+#pragma unroll
+      for (int c = 0; c < A; ++c)
+        cur[pu][c] = nxt[pu][c];
+    }
+  // fewer than PFT tiles are left; only the last one of a stream can be partial
+  for (; ib < i_end; ib += 64u)
+    {
+    const uint32_t i = ib + (uint32_t)lane;
+    VertexT<A> t = {};
+    if (i < i_end)
+      t = *(const VertexT<A>*)(src + (size_t)i * A);
+#pragma unroll
+    for (int c = 0; c < A; ++c)
+      {
+      if (ib + 64u <= i_end)
+        code_step<true, ATOMIC>(t.w[c], ib, i_end, n, lds + c * LW, (uint8_t*)(lds + c * LW + TW),
+                                slots + (size_t)c * slot_stride + (size_t)g * segcap, sw[c], lk);
+      else
+        code_step<false, ATOMIC>(t.w[c], ib, i_end, n, lds + c * LW, (uint8_t*)(lds + c * LW + TW),
+                                 slots + (size_t)c * slot_stride + (size_t)g * segcap, sw[c], lk);
+      }
+    }
+  uint32_t viol = 0;
+#pragma unroll
+  for (int c = 0; c < A; ++c)
+    {
+    uint8_t* gb = slots + (size_t)c * slot_stride + (size_t)g * segcap;
+    flush_end(sw[c], (uint8_t*)(lds + c * LW + TW), gb, lk);
+    const uint32_t off = 4u * (uint32_t)lane;
+    if (off < sw[c].posl)
+      store_span(gb + sw[c].flushed, off, (lds + c * LW + TW)[lane], sw[c].posl);
+    if (lane == 0)
+      segbytes[(size_t)c * S + g] = sw[c].flushed + sw[c].posl;
+    viol |= sw[c].viol;
+    }
+  if (ATOMIC && viol && lane == 0)
     atomicOr(flags, 1u);
   }
 
@@ -894,6 +1145,37 @@ int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
   uint8_t* slots = d_ws + p.off_slots;
   const uint32_t* src = (const uint32_t*)d_src;
   const unsigned threads = 64u * (unsigned)arity;
+  static const int tile = [] { const char* e = getenv("TRICO_FPC32_TILE"); return e ? atoi(e) : 0; }();
+  uint32_t* flags = (uint32_t*)(d_ws + p.off_flags);
+  if (tile && arity == 3)
+    {
+    // tile variants (bit 0: sweep A, bit 1: sweep C): one wave per segment walks all components (the interleaved array is read
+    // once per sweep)
+    if (!hip_ok(hipMemsetAsync(flags, 0, 4, st), "memset(flags)"))
+      return 0;
+    if (tile & 1)
+      hipLaunchKernelGGL(k_fpc32_index_t<3>, dim3(p.S), dim3(64), (size_t)3 * TAB * 4, st, src, n, p.L, summ);
+    else
+      {
+      if (!hip_ok(hipMemsetAsync(summ, 0, p.rows * ROW * 4, st), "memset(summ)"))
+        return 0;
+      hipLaunchKernelGGL(k_fpc32_index<false>, dim3(p.S, ISPLIT), dim3(192), ((size_t)BLOCK_V * 3 + (size_t)3 * LDSW_A) * 4, st, src, n, arity, p.L, summ);
+      }
+    const unsigned colblocks = (3u * TAB + 255u) / 256u;
+    hipLaunchKernelGGL(k_fpc32_scan_a, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax);
+    hipLaunchKernelGGL(k_fpc32_scan_b, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax, inc);
+    if (!(tile & 2))
+      hipLaunchKernelGGL(k_fpc32_code<false>, dim3(p.S), dim3(192), (size_t)3 * LDSW_C * 4 + 16, st,
+                         src, n, arity, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes, flags, 8u);
+    else if (allow_atomic && fpc32_use_atomic())
+      hipLaunchKernelGGL((k_fpc32_code_t<3, true>), dim3(p.S), dim3(64), (size_t)3 * LDSW_CA * 4, st,
+                         src, n, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes, flags);
+    else
+      hipLaunchKernelGGL((k_fpc32_code_t<3, false>), dim3(p.S), dim3(64), (size_t)3 * LDSW_C * 4, st,
+                         src, n, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes, flags);
+    hipLaunchKernelGGL(k_fpc32_offsets, dim3(arity), dim3(1024), 0, st, segbytes, p.S, segoff, d_sizes, flags);
+    return hip_ok(hipGetLastError(), "fpc32 encode kernels (tile)") ? 1 : 0;
+    }
   if (!hip_ok(hipMemsetAsync(summ, 0, p.rows * ROW * 4, st), "memset(summ)"))
     return 0;
   const size_t lds_a = ((size_t)BLOCK_V * arity + (size_t)arity * LDSW_A) * 4;
@@ -904,15 +1186,15 @@ int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
   const unsigned colblocks = ((unsigned)arity * TAB + 255u) / 256u;
   hipLaunchKernelGGL(k_fpc32_scan_a, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax);
   hipLaunchKernelGGL(k_fpc32_scan_b, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax, inc);
-  uint32_t* flags = (uint32_t*)(d_ws + p.off_flags);
   if (!hip_ok(hipMemsetAsync(flags, 0, 4, st), "memset(flags)"))
     return 0;
+  static const uint32_t prio_mode = [] { const char* e = getenv("TRICO_FPC32_PRIO"); return e ? (uint32_t)atoi(e) : 8u; }();
   if (allow_atomic && fpc32_use_atomic())
-    hipLaunchKernelGGL(k_fpc32_code<true>, dim3(p.S), dim3(threads), (size_t)arity * LDSW_CA * 4, st,
-                       src, n, arity, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes, flags);
+    hipLaunchKernelGGL(k_fpc32_code<true>, dim3(p.S), dim3(threads), (size_t)arity * LDSW_CA * 4 + 16, st,
+                       src, n, arity, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes, flags, prio_mode);
   else
-    hipLaunchKernelGGL(k_fpc32_code<false>, dim3(p.S), dim3(threads), (size_t)arity * LDSW_C * 4, st,
-                       src, n, arity, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes, flags);
+    hipLaunchKernelGGL(k_fpc32_code<false>, dim3(p.S), dim3(threads), (size_t)arity * LDSW_C * 4 + 16, st,
+                       src, n, arity, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes, flags, prio_mode);
   hipLaunchKernelGGL(k_fpc32_offsets, dim3(arity), dim3(1024), 0, st, segbytes, p.S, segoff, d_sizes, flags);
   return hip_ok(hipGetLastError(), "fpc32 encode kernels") ? 1 : 0;
   }
