@@ -268,12 +268,13 @@ def test_tagged_table_code_sweep_writes_the_same_bytes():
 
 @pytest.mark.parametrize("env_add", [{"TRICO_FPC32_TILE": "3"}, {"TRICO_FPC32_TILE": "1"}, {"TRICO_FPC32_TILE": "2"},
                                      {"TRICO_FPC32_TILE": "3", "TRICO_FPC32_ATOMIC": "1"}, {"TRICO_FPC32_PRIO": "0"},
-                                     {"TRICO_FPC32_PRIO": "3"}])
+                                     {"TRICO_FPC32_PRIO": "3"}, {"TRICO_FPC32_XCHG": "0"}, {"TRICO_FPC32_XCHG": "0", "TRICO_FPC32_TILE": "3"}])
 def test_encoder_variants_write_the_same_bytes(env_add):
     """The opt-in shapes of the float encoder (k_fpc32_encode.hip): TRICO_FPC32_TILE bit 0 / bit 1 = the index / code sweep with one
     wave per segment that walks all three components of whole vertices (the interleaved array is read once per sweep);
-    TRICO_FPC32_PRIO = who gets the issue slots among the component waves of a workgroup (default 8: whoever is behind).  They
-    decide time and traffic, never bytes."""
+    TRICO_FPC32_PRIO = who gets the issue slots among the component waves of a workgroup (default 8: whoever is behind);
+    TRICO_FPC32_XCHG=0 = run starts resolved with ballots instead of one lane-ordered LDS exchange (the default once the device has
+    passed the order test).  They decide time and traffic, never bytes."""
     env = dict(os.environ)
     env.update(env_add)
     out = subprocess.run([sys.executable, "-c", ENC_CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)

@@ -32,6 +32,7 @@
 // CU), not HBM.
 #include "common.hpp"
 #include <stdlib.h>
+#include <mutex>
 
 namespace trico {
 
@@ -324,8 +325,10 @@ __global__ void __launch_bounds__(64) k_fpc32_index_t(const uint32_t* __restrict
 
 // ---- scan: incoming index table of segment g = max over earlier segments -----------------------------
 __global__ void __launch_bounds__(256) k_fpc32_scan_a(const uint32_t* __restrict__ summ, uint32_t S, int arity,
-                                                      uint32_t* __restrict__ chmax)
+                                                      uint32_t* __restrict__ chmax, uint32_t* __restrict__ flags)
   {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    flags[0] = 0u;                                           // the code sweep's "LDS order violated" word (a memset of 4 bytes costs 7 us)
   const uint32_t col = blockIdx.x * 256u + threadIdx.x;      // (component, class)
   const uint32_t ncol = (uint32_t)arity * TAB;
   if (col >= ncol)
@@ -562,6 +565,51 @@ __device__ __forceinline__ void resolve_atomic(uint32_t k1, uint32_t k2, bool st
   if (D2) { sw.kc2 = (uint32_t)__builtin_amdgcn_readlane((int)k2, 63); sw.pend2 = false; }
   }
 
+// The same lookup with 32-bit entries and NO tags: ds_wrxchg_rtn_b32.  The reference codes a value by reading the entry of its class
+// and then writing its own payload there (fpsc.c:133-143), value after value; an exchange is exactly that pair, and the LDS unit of
+// gfx950 applies the active lanes of one exchange instruction in increasing lane order (tools/ubench/lds_xchg_order.hip: 131 M
+// instructions, 1 to 1024 keys, random exec masks, four waves per workgroup on the same LDS: every lane got the payload of the nearest
+// lower active lane of its key, or what earlier steps had left, and the entry ended with the highest lane's payload).  Only the lanes
+// where a run of equal classes starts or ends take part (inside a run the previous lane is the predecessor, DPP): a start takes what
+// comes back; a start that is not an end leaves its payload there for a moment, and the end lane of its run - a higher lane of the
+// same instruction - replaces it.  Ten ballots, a table read, a ds_bpermute and a table write become one LDS instruction, and the
+// table stays at 4 bytes per entry (30 waves per CU, unlike resolve_atomic).  The order is not documented, so the library tests it on
+// the device before the first encode (fpc32_xchg_usable(), below) and falls back to the ballot kernel if the test fails; the decoders'
+// self-check always re-encodes with the ballot kernel, which does not depend on it.
+template <bool FULL, bool D1, bool D2>
+__device__ __forceinline__ void resolve_xchg(uint32_t k1, uint32_t k2, bool st1, bool st2, bool act, uint32_t v, uint32_t s,
+                                             uint32_t& p1, uint32_t& p2, uint32_t* __restrict__ T, Sweep& sw, const LaneK& lk)
+  {
+  // pending writes of the previous step's last value
+  if (lk.lane == 0)
+    {
+    if (D1 && sw.pend1) T[sw.kc1] = sw.cy.m1;
+    if (D2 && sw.pend2) T[sw.kc2] = sw.cy.m1 - sw.cy.m2;
+    }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (D1)
+    {
+    const bool en = (FULL || act) && k1 != dpp_shl1(0xfffffffeu, k1);           // last lane of a run (lane 63 always)
+    if (st1 || en)
+      {
+      const uint32_t old = __hip_atomic_exchange(&T[k1], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      p1 = st1 ? old : p1;
+      }
+    }
+  if (D2)
+    {
+    const bool en = (FULL || act) && k2 != dpp_shl1(0xfffffffeu, k2);
+    if (st2 || en)
+      {
+      const uint32_t old = __hip_atomic_exchange(&T[k2], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      p2 = st2 ? old : p2;
+      }
+    }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (D1) { sw.kc1 = (uint32_t)__builtin_amdgcn_readlane((int)k1, 63); sw.pend1 = false; }
+  if (D2) { sw.kc2 = (uint32_t)__builtin_amdgcn_readlane((int)k2, 63); sw.pend2 = false; }
+  }
+
 // store the bytes of staged word `w` (byte offset off inside the slot, multiple of 4) that lie below hi
 __device__ __forceinline__ void store_span(uint8_t* __restrict__ gbase, uint32_t off, uint32_t w, uint32_t hi)
   {
@@ -586,7 +634,10 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x)
   }
 
 // one step: 64 values starting at index i0 (FULL: all of them inside the segment)
-template <bool FULL, bool ATOMIC>
+// MODE: how run starts find their predecessor - 0 ballots (resolve), 1 tagged 64-bit entries (resolve_atomic), 2 exchange (resolve_xchg)
+constexpr int M_BALLOT = 0, M_TAGGED = 1, M_XCHG = 2;
+
+template <bool FULL, int MODE>
 __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_end, uint32_t n, uint32_t* __restrict__ T,
                                           uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase,
                                           Sweep& sw, const LaneK& lk)
@@ -607,7 +658,24 @@ __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_en
   const bool any1 = __ballot(st1) != 0ull, any2 = __ballot(st2) != 0ull;
   const uint32_t s = v - a;
   uint32_t p1 = a, p2 = s1;                                 // inside a run: previous value / previous stride
-  if (ATOMIC)
+  if (MODE == M_XCHG)
+    {
+    if (any1 && any2)
+      resolve_xchg<FULL, true, true>(k1, k2, st1, st2, act, v, s, p1, p2, T, sw, lk);
+    else if (any1)
+      {
+      resolve_xchg<FULL, true, false>(k1, k2, st1, st2, act, v, s, p1, p2, T, sw, lk);
+      sw.pend2 = true;
+      }
+    else if (any2)
+      {
+      resolve_xchg<FULL, false, true>(k1, k2, st1, st2, act, v, s, p1, p2, T, sw, lk);
+      sw.pend1 = true;
+      }
+    else
+      sw.pend1 = sw.pend2 = true;
+    }
+  else if (MODE == M_TAGGED)
     {
     unsigned long long* T64 = (unsigned long long*)T;
     if (any1 && any2)
@@ -709,9 +777,9 @@ __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_en
   next_carry(sw.cy, v);
   }
 
-// ATOMIC: table entries of 64 bits and resolve_atomic (one LDS instruction per predictor and step); else 32-bit entries and resolve
-// (ballots).  `flags`: word 0 is raised when an ATOMIC step found the LDS unit out of lane order.
-template <bool ATOMIC>
+// MODE M_TAGGED: table entries of 64 bits and resolve_atomic; else 32-bit entries and resolve (ballots) or resolve_xchg.
+// `flags`: word 0 is raised when a tagged step found the LDS unit out of lane order.
+template <int MODE>
 __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))) k_fpc32_code(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t L, uint32_t S,
                                                     const uint32_t* __restrict__ inc, uint8_t* __restrict__ slots, size_t slot_stride,
                                                     uint32_t segcap, uint32_t* __restrict__ segbytes, uint32_t* __restrict__ flags,
@@ -720,6 +788,7 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t g = blockIdx.x;
+  constexpr bool ATOMIC = MODE == M_TAGGED;
   constexpr int TW = ATOMIC ? 2 * TAB : TAB;           // table words
   volatile uint32_t* prog = lds + arity * (ATOMIC ? LDSW_CA : LDSW_C);   // [4] progress of the component waves (prio_mode 8)
   if (prio_mode >= 1u && prio_mode <= 3u && (uint32_t)c == prio_mode - 1u)
@@ -800,9 +869,9 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
       {
       const uint32_t i0 = ib + 64u * pu;
       if (i0 + 64u <= i_end)
-        code_step<true, ATOMIC>(cur[pu], i0, i_end, n, T, stage, gbase, sw, lk);
+        code_step<true, MODE>(cur[pu], i0, i_end, n, T, stage, gbase, sw, lk);
       else if (i0 < i_end)
-        code_step<false, ATOMIC>(cur[pu], i0, i_end, n, T, stage, gbase, sw, lk);
+        code_step<false, MODE>(cur[pu], i0, i_end, n, T, stage, gbase, sw, lk);
       }
 #pragma unroll
     for (int pu = 0; pu < PF; ++pu)
@@ -826,7 +895,7 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
 // ---- tile variant of sweep C: one wave codes ALL components of its segment (see k_fpc32_index_t) --------------------------
 // Same steps, same tables and staging areas per component (side by side in the wave's LDS), same slots: only who walks them
 // differs.  The interleaved array is read once, 64 whole vertices per load.
-template <int A, bool ATOMIC>
+template <int A, int MODE>
 __global__ void __launch_bounds__(64) k_fpc32_code_t(const uint32_t* __restrict__ src, uint32_t n, uint32_t L, uint32_t S,
                                                      const uint32_t* __restrict__ inc, uint8_t* __restrict__ slots, size_t slot_stride,
                                                      uint32_t segcap, uint32_t* __restrict__ segbytes, uint32_t* __restrict__ flags)
@@ -834,6 +903,7 @@ __global__ void __launch_bounds__(64) k_fpc32_code_t(const uint32_t* __restrict_
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int lane = threadIdx.x;
   const uint32_t g = blockIdx.x;
+  constexpr bool ATOMIC = MODE == M_TAGGED;
   constexpr int TW = ATOMIC ? 2 * TAB : TAB;
   constexpr int LW = ATOMIC ? LDSW_CA : LDSW_C;
   // incoming tables: payload of the last writer of every class before this segment (0 if none); the loads of all components
@@ -906,7 +976,7 @@ __global__ void __launch_bounds__(64) k_fpc32_code_t(const uint32_t* __restrict_
     for (int pu = 0; pu < PFT; ++pu)
 #pragma unroll
       for (int c = 0; c < A; ++c)
-        code_step<true, ATOMIC>(cur[pu][c], ib + 64u * pu, i_end, n, lds + c * LW, (uint8_t*)(lds + c * LW + TW),
+        code_step<true, MODE>(cur[pu][c], ib + 64u * pu, i_end, n, lds + c * LW, (uint8_t*)(lds + c * LW + TW),
                                 slots + (size_t)c * slot_stride + (size_t)g * segcap, sw[c], lk);
 #pragma unroll
     for (int pu = 0; pu < PFT; ++pu)
@@ -925,10 +995,10 @@ __global__ void __launch_bounds__(64) k_fpc32_code_t(const uint32_t* __restrict_
     for (int c = 0; c < A; ++c)
       {
       if (ib + 64u <= i_end)
-        code_step<true, ATOMIC>(t.w[c], ib, i_end, n, lds + c * LW, (uint8_t*)(lds + c * LW + TW),
+        code_step<true, MODE>(t.w[c], ib, i_end, n, lds + c * LW, (uint8_t*)(lds + c * LW + TW),
                                 slots + (size_t)c * slot_stride + (size_t)g * segcap, sw[c], lk);
       else
-        code_step<false, ATOMIC>(t.w[c], ib, i_end, n, lds + c * LW, (uint8_t*)(lds + c * LW + TW),
+        code_step<false, MODE>(t.w[c], ib, i_end, n, lds + c * LW, (uint8_t*)(lds + c * LW + TW),
                                  slots + (size_t)c * slot_stride + (size_t)g * segcap, sw[c], lk);
       }
     }
@@ -1068,16 +1138,88 @@ __global__ void k_fpc32_empty(uint8_t* out, size_t out_stride, uint32_t* sizes)
 
 struct Plan { uint32_t L, S, segcap, nch; size_t rows, slot_stride, off_summ, off_inc, off_chmax, off_segbytes, off_segoff, off_flags, off_slots, total; };
 
-// The tagged-table code sweep (resolve_atomic) is chosen with TRICO_FPC32_ATOMIC=1, and given up for good once a step of it has
-// found the LDS unit applying an atomic out of lane order in this process (the ballot kernel does not depend on that order).
-// It is not the default: measured on the MI355X (profiles/r03_fpc32_encode_experiments.txt) a noisy component alone codes 15 %
-// faster with it (0.503 -> 0.427 ms for 50 M values) and the walk mesh 6 % (0.982 -> 0.925 ms), but the grid mesh - two smooth
-// components, one noisy - is 1-3 % slower, because the 64-bit table halves the waves per CU for the smooth components too.
+// Before resolve_xchg is trusted on a device, the device shows that its LDS unit applies the active lanes of one ds_wrxchg_rtn_b32
+// in increasing lane order (the property the kernel rests on; see resolve_xchg): 1024 waves x 96 exchanges with random keys (1 to
+// 1024 distinct ones, per workgroup), random exec masks and four waves per workgroup, every returned value and every final entry
+// compared with what ballots say it has to be.  ~0.3 ms, once per device and process.
+__global__ void __launch_bounds__(256) k_fpc32_xchg_selftest(uint32_t rounds, uint32_t* __restrict__ bad)
+  {
+  __shared__ uint32_t T[4][1024];
+  __shared__ uint32_t shadow[4][1024];
+  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  for (uint32_t i = lane; i < 1024u; i += 64u) { T[w][i] = 0u; shadow[w][i] = 0u; }
+  __syncthreads();
+  const uint32_t nkeys = 1u << (blockIdx.x % 11u);
+  uint32_t x = (blockIdx.x * 0x9E3779B9u) ^ (threadIdx.x * 0x85EBCA6Bu) ^ 0x2545F491u;
+  uint32_t wrong = 0;
+  for (uint32_t r = 0; r < rounds; ++r)
+    {
+    x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+    const uint32_t k = (x >> 8) & (nkeys - 1u);
+    const bool active = ((x >> 3) & 7u) != 0u || (r & 15u) == 0u;
+    const uint32_t val = ((r + 1u) << 6) | lane;
+    uint32_t expect = shadow[w][k];
+    bool last = true;
+    for (uint32_t j = 0; j < 64u; ++j)
+      {
+      const uint32_t kj = (uint32_t)__shfl((int)k, (int)j, 64), vj = (uint32_t)__shfl((int)val, (int)j, 64);
+      const bool aj = __shfl((int)active, (int)j, 64) != 0;
+      if (aj && kj == k) { if (j < lane) expect = vj; if (j > lane) last = false; }
+      }
+    uint32_t old = 0;
+    if (active)
+      old = __hip_atomic_exchange(&T[w][k], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (active && old != expect) ++wrong;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (active && last) shadow[w][k] = val;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (active && last && T[w][k] != val) ++wrong;
+    }
+  if (wrong)
+    atomicAdd(bad, wrong);
+  }
+
+// Which code sweep?  TRICO_FPC32_ATOMIC=1: tagged 64-bit entries (resolve_atomic; checks the lane order in every step, given up for
+// good once a step has seen a violation).  Otherwise the exchange sweep (resolve_xchg) if this device passes the test above, unless
+// TRICO_FPC32_XCHG=0; else ballots (resolve).  Measured on the MI355X (profiles/r03_fpc32_encode_experiments.txt): tagged entries make
+// a noisy component alone 15 % faster but halve the waves per CU (9,120 B of LDS per wave), which costs the smooth components more.
 static bool g_atomic_distrusted = false;
 bool fpc32_use_atomic()
   {
   static const bool env_atomic = [] { const char* e = getenv("TRICO_FPC32_ATOMIC"); return e && e[0] == '1'; }();
   return env_atomic && !g_atomic_distrusted;
+  }
+
+bool fpc32_xchg_usable()
+  {
+  static const bool env_off = [] { const char* e = getenv("TRICO_FPC32_XCHG"); return e && e[0] == '0'; }();
+  if (env_off)
+    return false;
+  static std::mutex mu;
+  static int state[32] = { 0 };                  // per device: 0 not tested, 1 passed, 2 failed
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32)
+    return false;
+  std::lock_guard<std::mutex> lock(mu);
+  if (state[dev] == 0)
+    {
+    uint32_t* d_bad = nullptr;
+    uint32_t h_bad = 1;
+    state[dev] = 2;
+    if (hipMalloc(&d_bad, 4) == hipSuccess)
+      {
+      hipStream_t st = current_stream();
+      if (hipMemsetAsync(d_bad, 0, 4, st) == hipSuccess)
+        {
+        hipLaunchKernelGGL(k_fpc32_xchg_selftest, dim3(256), dim3(256), 0, st, 96u, d_bad);
+        if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+            hipStreamSynchronize(st) == hipSuccess && h_bad == 0u)
+          state[dev] = 1;
+        }
+      (void)hipFree(d_bad);
+      }
+    }
+  return state[dev] == 1;
   }
 
 Plan make_plan(uint32_t n, int arity)
@@ -1146,13 +1288,12 @@ int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
   const uint32_t* src = (const uint32_t*)d_src;
   const unsigned threads = 64u * (unsigned)arity;
   static const int tile = [] { const char* e = getenv("TRICO_FPC32_TILE"); return e ? atoi(e) : 0; }();
+  const int mode = !allow_atomic ? M_BALLOT : (fpc32_use_atomic() ? M_TAGGED : (fpc32_xchg_usable() ? M_XCHG : M_BALLOT));
   uint32_t* flags = (uint32_t*)(d_ws + p.off_flags);
   if (tile && arity == 3)
     {
     // tile variants (bit 0: sweep A, bit 1: sweep C): one wave per segment walks all components (the interleaved array is read
     // once per sweep)
-    if (!hip_ok(hipMemsetAsync(flags, 0, 4, st), "memset(flags)"))
-      return 0;
     if (tile & 1)
       hipLaunchKernelGGL(k_fpc32_index_t<3>, dim3(p.S), dim3(64), (size_t)3 * TAB * 4, st, src, n, p.L, summ);
     else
@@ -1162,16 +1303,19 @@ int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
       hipLaunchKernelGGL(k_fpc32_index<false>, dim3(p.S, ISPLIT), dim3(192), ((size_t)BLOCK_V * 3 + (size_t)3 * LDSW_A) * 4, st, src, n, arity, p.L, summ);
       }
     const unsigned colblocks = (3u * TAB + 255u) / 256u;
-    hipLaunchKernelGGL(k_fpc32_scan_a, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax);
+    hipLaunchKernelGGL(k_fpc32_scan_a, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax, flags);
     hipLaunchKernelGGL(k_fpc32_scan_b, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax, inc);
     if (!(tile & 2))
-      hipLaunchKernelGGL(k_fpc32_code<false>, dim3(p.S), dim3(192), (size_t)3 * LDSW_C * 4 + 16, st,
+      hipLaunchKernelGGL(k_fpc32_code<M_BALLOT>, dim3(p.S), dim3(192), (size_t)3 * LDSW_C * 4 + 16, st,
                          src, n, arity, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes, flags, 8u);
-    else if (allow_atomic && fpc32_use_atomic())
-      hipLaunchKernelGGL((k_fpc32_code_t<3, true>), dim3(p.S), dim3(64), (size_t)3 * LDSW_CA * 4, st,
+    else if (mode == M_TAGGED)
+      hipLaunchKernelGGL((k_fpc32_code_t<3, M_TAGGED>), dim3(p.S), dim3(64), (size_t)3 * LDSW_CA * 4, st,
+                         src, n, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes, flags);
+    else if (mode == M_XCHG)
+      hipLaunchKernelGGL((k_fpc32_code_t<3, M_XCHG>), dim3(p.S), dim3(64), (size_t)3 * LDSW_C * 4, st,
                          src, n, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes, flags);
     else
-      hipLaunchKernelGGL((k_fpc32_code_t<3, false>), dim3(p.S), dim3(64), (size_t)3 * LDSW_C * 4, st,
+      hipLaunchKernelGGL((k_fpc32_code_t<3, M_BALLOT>), dim3(p.S), dim3(64), (size_t)3 * LDSW_C * 4, st,
                          src, n, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes, flags);
     hipLaunchKernelGGL(k_fpc32_offsets, dim3(arity), dim3(1024), 0, st, segbytes, p.S, segoff, d_sizes, flags);
     return hip_ok(hipGetLastError(), "fpc32 encode kernels (tile)") ? 1 : 0;
@@ -1184,16 +1328,17 @@ int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
   else
     hipLaunchKernelGGL(k_fpc32_index<false>, dim3(p.S, ISPLIT), dim3(threads), lds_a, st, src, n, arity, p.L, summ);
   const unsigned colblocks = ((unsigned)arity * TAB + 255u) / 256u;
-  hipLaunchKernelGGL(k_fpc32_scan_a, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax);
+  hipLaunchKernelGGL(k_fpc32_scan_a, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax, flags);
   hipLaunchKernelGGL(k_fpc32_scan_b, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax, inc);
-  if (!hip_ok(hipMemsetAsync(flags, 0, 4, st), "memset(flags)"))
-    return 0;
   static const uint32_t prio_mode = [] { const char* e = getenv("TRICO_FPC32_PRIO"); return e ? (uint32_t)atoi(e) : 8u; }();
-  if (allow_atomic && fpc32_use_atomic())
-    hipLaunchKernelGGL(k_fpc32_code<true>, dim3(p.S), dim3(threads), (size_t)arity * LDSW_CA * 4 + 16, st,
+  if (mode == M_TAGGED)
+    hipLaunchKernelGGL(k_fpc32_code<M_TAGGED>, dim3(p.S), dim3(threads), (size_t)arity * LDSW_CA * 4 + 16, st,
+                       src, n, arity, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes, flags, prio_mode);
+  else if (mode == M_XCHG)
+    hipLaunchKernelGGL(k_fpc32_code<M_XCHG>, dim3(p.S), dim3(threads), (size_t)arity * LDSW_C * 4 + 16, st,
                        src, n, arity, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes, flags, prio_mode);
   else
-    hipLaunchKernelGGL(k_fpc32_code<false>, dim3(p.S), dim3(threads), (size_t)arity * LDSW_C * 4 + 16, st,
+    hipLaunchKernelGGL(k_fpc32_code<M_BALLOT>, dim3(p.S), dim3(threads), (size_t)arity * LDSW_C * 4 + 16, st,
                        src, n, arity, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes, flags, prio_mode);
   hipLaunchKernelGGL(k_fpc32_offsets, dim3(arity), dim3(1024), 0, st, segbytes, p.S, segoff, d_sizes, flags);
   return hip_ok(hipGetLastError(), "fpc32 encode kernels") ? 1 : 0;
