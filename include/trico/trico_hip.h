@@ -216,6 +216,10 @@ enum trico_hip_kernel_id
  * out[3] (process-wide) = streams whose values, decoded in reference order at the end of the repeat ladder, still do not code back to their
  * payload: payloads the reference's encoder would not have written (decoded all the same; counts up, never reset) */
 TRICO_API void trico_hip_last_stats(uint32_t out[4]);
+/* which code sweep the float encoder (k_fpc32_encode.hip) uses on the current device: 0 = run starts resolved with ballots, 1 = tagged
+ * 64-bit table entries (TRICO_FPC32_ATOMIC=1), 2 = one lane-ordered LDS exchange per predictor and step (the default once the device
+ * has passed the order test, which the first call runs: ~0.3 ms; TRICO_FPC32_XCHG=0 turns it off).  All three write the same bytes. */
+TRICO_API int trico_hip_fpc32_code_sweep(void);
 TRICO_API void trico_hip_profile_enable(int on);
 TRICO_API void trico_hip_profile_reset(void);
 /* returns accumulated milliseconds and number of timed spans for kernel id `k` (syncs first) */

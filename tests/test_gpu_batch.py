@@ -266,6 +266,15 @@ def test_tagged_table_code_sweep_writes_the_same_bytes():
     assert out.returncode == 0 and "ENCODE OK" in out.stdout, out.stdout + out.stderr
 
 
+def test_the_device_passes_the_lane_order_test_of_the_exchange_sweep(api):
+    """The float encoder's default code sweep resolves run starts with one ds_wrxchg_rtn_b32 per predictor and step, which rests on the
+    LDS unit applying the lanes of one instruction in increasing lane order; the library tests that on the device before it uses the
+    kernel (k_fpc32_xchg_selftest) and would silently fall back to ballots otherwise.  On an MI355X the test has to pass."""
+    if os.environ.get("TRICO_FPC32_XCHG") == "0" or os.environ.get("TRICO_FPC32_ATOMIC") == "1":
+        pytest.skip("code sweep chosen by the environment")
+    assert api.lib().trico_hip_fpc32_code_sweep() == 2
+
+
 @pytest.mark.parametrize("env_add", [{"TRICO_FPC32_TILE": "3"}, {"TRICO_FPC32_TILE": "1"}, {"TRICO_FPC32_TILE": "2"},
                                      {"TRICO_FPC32_TILE": "3", "TRICO_FPC32_ATOMIC": "1"}, {"TRICO_FPC32_PRIO": "0"},
                                      {"TRICO_FPC32_PRIO": "3"}, {"TRICO_FPC32_XCHG": "0"}, {"TRICO_FPC32_XCHG": "0", "TRICO_FPC32_TILE": "3"}])

@@ -17,19 +17,24 @@
 //            with, as value indices (0 = never written = the reference's zeroed table).
 //   sweep C  (k_fpc32_code):   loads the incoming table (payloads gathered from the input by index),
 //            then per step: the latest earlier value of my class is the previous lane inside a run
-//            of equal classes (runs span steps through the carry); run starts are resolved with ballots
-//            (the lanes of my class) + the wave-private payload table, only in steps that have
-//            any (see the comment block above code_step).  Codes, residual lengths, wave prefix sums
-//            (mbcnt), 3-byte group headers (DPP or-reduce), bytes staged in a linear LDS buffer and
-//            flushed as aligned dwords into the segment's slot.
+//            of equal classes (runs span steps through the carry); the lanes where a run starts or ends
+//            do ONE exchange on the wave-private payload table per predictor (resolve_xchg: the LDS unit
+//            applies the lanes of an instruction in lane order, which is the reference's read-then-write,
+//            value after value; tested on the device before use, ballots otherwise: resolve), only in
+//            steps that have any (see the comment block above code_step).  Codes, residual lengths, wave
+//            prefix sums (DPP scan), 3-byte group headers (DPP or-reduce), bytes staged in a linear LDS
+//            buffer and flushed as aligned dwords into the segment's slot.
 //   offsets  (k_fpc32_offsets): exclusive scan of the segment byte counts per component.
 //   gather   (k_fpc32_gather): slot -> final position (this is the copy the reference does with
 //            memcpy into the archive, trico.c:57-63; it targets the archive buffer directly).
 //
-// HBM traffic: 2 x raw input + 2 x payload bytes + table traffic (measured 3.3 x algorithmic, DESIGN.md
-// 4.1).  No MFMA: integer bit-twiddling; algorithmic bytes per value = 4 + its payload share.  The bound
-// today is the vector ALU (121 instructions per 64-value step at 4 cycles each; SQ counters: 78 % VALU busy at 30 waves per
-// CU), not HBM.
+// Tile variants of both sweeps (k_fpc32_index_t / k_fpc32_code_t, TRICO_FPC32_TILE): one wave walks all components of whole
+// vertices, so the interleaved array is read once per sweep; less traffic, more time.
+//
+// HBM traffic: 2 x raw input + 2 x payload bytes + table traffic (measured 3.9 x algorithmic, DESIGN.md
+// 4.1: the component waves drift apart and re-fetch lines).  No MFMA: integer bit-twiddling; algorithmic bytes per
+// value = 4 + its payload share.  The bound is the vector ALU (80-100 instructions per 64-value step at 4 cycles
+// each, 30 waves per CU), not HBM.
 #include "common.hpp"
 #include <stdlib.h>
 #include <mutex>
@@ -207,22 +212,49 @@ __global__ void __launch_bounds__(192) k_fpc32_index(const uint32_t* __restrict_
     const bool more = ib + BLOCK_V < i_end;
     if (more)
       block_fetch<X4>(regs, src, (uint64_t)(ib + BLOCK_V) * arity, total, threads, tid);
+    // the wave's values of the whole block leave the staging area together (one LDS round trip per block, not per step)
+    uint32_t vv[PF];
 #pragma unroll
     for (int pu = 0; pu < PF; ++pu)
+      vv[pu] = stage[(uint32_t)(64 * pu + lane) * (uint32_t)arity + (uint32_t)c];
+    if (ib + BLOCK_V <= i_end)
       {
-      const uint32_t i0 = ib + 64u * pu;
-      if (i0 >= i_end)
-        break;
-      const uint32_t i = i0 + lane;
-      const bool act = i < i_end;
-      const uint32_t v = stage[(uint32_t)(64 * pu + lane) * (uint32_t)arity + (uint32_t)c];
-      uint32_t a, b, k1, k2;
-      classes(v, cy, act, a, b, k1, k2);
-      // only the last lane of a run of equal classes can be the class's last writer in this step
-      const uint32_t kn1 = dpp_shl1(0xfffffffeu, k1), kn2 = dpp_shl1(0xfffffffeu, k2);
-      if (act && k1 != kn1) atomicMax(&T[k1], i + 1u);
-      if (act && k2 != kn2) atomicMax(&T[k2], i + 1u);
-      next_carry(cy, v);
+      // every value of the block is inside the range: no activity masks
+#pragma unroll
+      for (int pu = 0; pu < PF; ++pu)
+        {
+        const uint32_t i = ib + 64u * pu + lane;
+        const uint32_t v = vv[pu];
+        uint32_t a, b, k1, k2;
+        classes(v, cy, true, a, b, k1, k2);
+        // only the last lane of a run of equal classes can be the class's last writer in this step
+        const uint32_t kn1 = dpp_shl1(0xfffffffeu, k1), kn2 = dpp_shl1(0xfffffffeu, k2);
+        if (k1 != kn1) atomicMax(&T[k1], i + 1u);
+        if (k2 != kn2) atomicMax(&T[k2], i + 1u);
+        next_carry(cy, v);
+        }
+      }
+    else
+      {
+#pragma unroll 1
+      for (int pu = 0; pu < PF; ++pu)
+        {
+        const uint32_t i0 = ib + 64u * pu;
+        if (i0 >= i_end)
+          break;
+        const uint32_t i = i0 + lane;
+        const bool act = i < i_end;
+        uint32_t v = vv[0];
+#pragma unroll
+        for (int q = 1; q < PF; ++q)
+          v = pu == q ? vv[q] : v;
+        uint32_t a, b, k1, k2;
+        classes(v, cy, act, a, b, k1, k2);
+        const uint32_t kn1 = dpp_shl1(0xfffffffeu, k1), kn2 = dpp_shl1(0xfffffffeu, k2);
+        if (act && k1 != kn1) atomicMax(&T[k1], i + 1u);
+        if (act && k2 != kn2) atomicMax(&T[k2], i + 1u);
+        next_carry(cy, v);
+        }
       }
     if (more)
       {
@@ -336,6 +368,7 @@ __global__ void __launch_bounds__(256) k_fpc32_scan_a(const uint32_t* __restrict
   const uint32_t c = col / TAB, k = col % TAB;
   const uint32_t g0 = blockIdx.y * CH, g1 = (g0 + CH < S) ? g0 + CH : S;
   uint32_t m = 0;
+#pragma unroll 8
   for (uint32_t g = g0; g < g1; ++g)
     m = max(m, summ[((size_t)g * arity + c) * ROW + k]);
   chmax[(size_t)blockIdx.y * ncol + col] = m;
@@ -353,6 +386,7 @@ __global__ void __launch_bounds__(256) k_fpc32_scan_b(const uint32_t* __restrict
   for (uint32_t j = 0; j < blockIdx.y; ++j)
     carry = max(carry, chmax[(size_t)j * ncol + col]);
   const uint32_t g0 = blockIdx.y * CH, g1 = (g0 + CH < S) ? g0 + CH : S;
+#pragma unroll 8
   for (uint32_t g = g0; g < g1; ++g)
     {
     const size_t r = ((size_t)g * arity + c) * ROW + k;
@@ -795,22 +829,40 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
     __builtin_amdgcn_s_setprio(3);
   uint32_t* T = lds + c * (ATOMIC ? LDSW_CA : LDSW_C); // [TAB] payload table (ATOMIC: {payload, tag} pairs)
   uint8_t* stage = (uint8_t*)(T + TW);                 // [STAGE] packed bytes of the steps not yet flushed + dump
-  // incoming table: payload of the last writer of every class before this segment (0 if none)
+  // incoming table: payload of the last writer of every class before this segment (0 if none).  Every wave of the sweep is here at the
+  // same time, so nobody covers anybody's latency: the index loads of a batch of entries are issued together, then the value loads
+  // they point at (two round trips per batch of nine instead of two per entry).
   const uint32_t* row = inc + ((size_t)g * arity + c) * ROW;
-  for (int k = lane; k < TAB; k += 64)
+  constexpr int TB = 9;                                // 17 entries per lane = 9 + 8
+#pragma unroll 1
+  for (int k0 = lane; k0 < TAB; k0 += 64 * TB)
     {
-    const uint32_t idx = row[k];
-    uint32_t pay = 0;
-    if (idx)
+    uint32_t idx[TB], vi[TB], vp[TB];
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
       {
-      const uint32_t vi = src[(size_t)(idx - 1u) * arity + c];
-      const uint32_t vp = idx >= 2u ? src[(size_t)(idx - 2u) * arity + c] : 0u;
-      pay = k < 16 ? vi : vi - vp;
+      const int k = k0 + 64 * j;
+      idx[j] = k < TAB ? row[k] : 0u;
       }
-    if (ATOMIC)
-      ((unsigned long long*)T)[k] = pay;               // tag 0: older than every step of this segment
-    else
-      T[k] = pay;
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+      {
+      vi[j] = idx[j] ? src[(size_t)(idx[j] - 1u) * arity + c] : 0u;
+      vp[j] = idx[j] >= 2u ? src[(size_t)(idx[j] - 2u) * arity + c] : 0u;
+      }
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+      {
+      const int k = k0 + 64 * j;
+      const uint32_t pay = idx[j] ? (k < 16 ? vi[j] : vi[j] - vp[j]) : 0u;
+      if (k < TAB)
+        {
+        if (ATOMIC)
+          ((unsigned long long*)T)[k] = pay;           // tag 0: older than every step of this segment
+        else
+          T[k] = pay;
+        }
+      }
     }
   LaneK lk;
   lk.lane = lane;
@@ -1264,6 +1316,8 @@ size_t fpc32_encode_workspace(uint32_t n, int arity)
 
 void fpc32_distrust_atomic() { g_atomic_distrusted = true; }
 
+int fpc32_code_sweep_mode() { return fpc32_use_atomic() ? M_TAGGED : (fpc32_xchg_usable() ? M_XCHG : M_BALLOT); }
+
 int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
                         uint8_t* d_ws, size_t ws_bytes, bool allow_atomic)
   {
@@ -1288,7 +1342,7 @@ int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
   const uint32_t* src = (const uint32_t*)d_src;
   const unsigned threads = 64u * (unsigned)arity;
   static const int tile = [] { const char* e = getenv("TRICO_FPC32_TILE"); return e ? atoi(e) : 0; }();
-  const int mode = !allow_atomic ? M_BALLOT : (fpc32_use_atomic() ? M_TAGGED : (fpc32_xchg_usable() ? M_XCHG : M_BALLOT));
+  const int mode = allow_atomic ? fpc32_code_sweep_mode() : M_BALLOT;
   uint32_t* flags = (uint32_t*)(d_ws + p.off_flags);
   if (tile && arity == 3)
     {

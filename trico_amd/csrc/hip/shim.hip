@@ -1211,6 +1211,13 @@ const uint8_t* trico_hip_payload_device_pointer(trico_hip_ctx* ctx, int c)
 
 // ---- profiling ----------------------------------------------------------------------------------
 
+int trico_hip_fpc32_code_sweep(void)
+  {
+  if (!device_ready())
+    return 0;
+  return fpc32_code_sweep_mode();
+  }
+
 void trico_hip_last_stats(uint32_t out[4])
   {
   out[0] = g_stats[0];
