@@ -671,39 +671,54 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x)
 // MODE: how run starts find their predecessor - 0 ballots (resolve), 1 tagged 64-bit entries (resolve_atomic), 2 exchange (resolve_xchg)
 constexpr int M_BALLOT = 0, M_TAGGED = 1, M_XCHG = 2;
 
-template <bool FULL, int MODE>
-__device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_end, uint32_t n, uint32_t* __restrict__ T,
-                                          uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase,
-                                          Sweep& sw, const LaneK& lk)
+// The step in phases, so that a wave that walks several components (tile_step) can run the same phase of all of them back to back:
+// the phases of different components are independent instruction streams inside one basic block, and each covers the others' waits.
+struct StepRegs                                  // per-lane values a step carries from phase to phase
   {
-  const uint32_t i = i0 + (uint32_t)lk.lane;
-  const bool act = FULL || i < i_end;
-  // classes (fpsc.c:76-84 with e1 = 4, e2 = 10): k1 from v[i-1], k2 from the strides of v[i-1] and v[i-2]
-  const uint32_t a = dpp_shr1(sw.cy.m1, v);                 // v[i-1]
-  const uint32_t b = dpp_shr1(sw.cy.m2, a);                 // v[i-2]
-  const uint32_t s1 = a - b;                                // stride of v[i-1]
+  uint32_t v, a, s, k1, k2, p1, p2;
+  bool act, st1, st2, any1, any2;
+  };
+
+// classes (fpsc.c:76-84 with e1 = 4, e2 = 10): k1 from v[i-1], k2 from the strides of v[i-1] and v[i-2]; run starts
+template <bool FULL>
+__device__ __forceinline__ void step_head(StepRegs& r, uint32_t v, uint32_t i, uint32_t i_end, const Sweep& sw)
+  {
+  r.v = v;
+  r.act = FULL || i < i_end;
+  r.a = dpp_shr1(sw.cy.m1, v);                              // v[i-1]
+  const uint32_t b = dpp_shr1(sw.cy.m2, r.a);               // v[i-2]
+  const uint32_t s1 = r.a - b;                              // stride of v[i-1]
   const uint32_t s2 = dpp_shr1(sw.cy.m2 - sw.cy.m3, s1);    // stride of v[i-2]
-  uint32_t k1 = a >> 28;
-  uint32_t k2 = 16u + ((((s2 >> 22) & 31u) << 5) ^ (s1 >> 22));
-  if (!FULL && !act)
-    k1 = k2 = 0xffffffffu;
-  bool st1 = k1 != dpp_shr1(sw.kc1, k1), st2 = k2 != dpp_shr1(sw.kc2, k2);
-  if (!FULL) { st1 = st1 && act; st2 = st2 && act; }
-  const bool any1 = __ballot(st1) != 0ull, any2 = __ballot(st2) != 0ull;
-  const uint32_t s = v - a;
-  uint32_t p1 = a, p2 = s1;                                 // inside a run: previous value / previous stride
+  r.k1 = r.a >> 28;
+  r.k2 = 16u + ((((s2 >> 22) & 31u) << 5) ^ (s1 >> 22));
+  if (!FULL && !r.act)
+    r.k1 = r.k2 = 0xffffffffu;
+  r.st1 = r.k1 != dpp_shr1(sw.kc1, r.k1);
+  r.st2 = r.k2 != dpp_shr1(sw.kc2, r.k2);
+  if (!FULL) { r.st1 = r.st1 && r.act; r.st2 = r.st2 && r.act; }
+  r.any1 = __ballot(r.st1) != 0ull;
+  r.any2 = __ballot(r.st2) != 0ull;
+  r.s = v - r.a;
+  r.p1 = r.a;                                               // inside a run: previous value / previous stride
+  r.p2 = s1;
+  }
+
+// predictions of the run starts (only in steps that have any), MODE as above
+template <bool FULL, int MODE>
+__device__ __forceinline__ void step_resolve(StepRegs& r, uint32_t* __restrict__ T, Sweep& sw, const LaneK& lk)
+  {
   if (MODE == M_XCHG)
     {
-    if (any1 && any2)
-      resolve_xchg<FULL, true, true>(k1, k2, st1, st2, act, v, s, p1, p2, T, sw, lk);
-    else if (any1)
+    if (r.any1 && r.any2)
+      resolve_xchg<FULL, true, true>(r.k1, r.k2, r.st1, r.st2, r.act, r.v, r.s, r.p1, r.p2, T, sw, lk);
+    else if (r.any1)
       {
-      resolve_xchg<FULL, true, false>(k1, k2, st1, st2, act, v, s, p1, p2, T, sw, lk);
+      resolve_xchg<FULL, true, false>(r.k1, r.k2, r.st1, r.st2, r.act, r.v, r.s, r.p1, r.p2, T, sw, lk);
       sw.pend2 = true;
       }
-    else if (any2)
+    else if (r.any2)
       {
-      resolve_xchg<FULL, false, true>(k1, k2, st1, st2, act, v, s, p1, p2, T, sw, lk);
+      resolve_xchg<FULL, false, true>(r.k1, r.k2, r.st1, r.st2, r.act, r.v, r.s, r.p1, r.p2, T, sw, lk);
       sw.pend1 = true;
       }
     else
@@ -712,37 +727,44 @@ __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_en
   else if (MODE == M_TAGGED)
     {
     unsigned long long* T64 = (unsigned long long*)T;
-    if (any1 && any2)
-      resolve_atomic<FULL, true, true>(k1, k2, st1, st2, act, v, s, p1, p2, T64, sw, lk);
-    else if (any1)
+    if (r.any1 && r.any2)
+      resolve_atomic<FULL, true, true>(r.k1, r.k2, r.st1, r.st2, r.act, r.v, r.s, r.p1, r.p2, T64, sw, lk);
+    else if (r.any1)
       {
-      resolve_atomic<FULL, true, false>(k1, k2, st1, st2, act, v, s, p1, p2, T64, sw, lk);
+      resolve_atomic<FULL, true, false>(r.k1, r.k2, r.st1, r.st2, r.act, r.v, r.s, r.p1, r.p2, T64, sw, lk);
       sw.pend2 = true;
       }
-    else if (any2)
+    else if (r.any2)
       {
-      resolve_atomic<FULL, false, true>(k1, k2, st1, st2, act, v, s, p1, p2, T64, sw, lk);
+      resolve_atomic<FULL, false, true>(r.k1, r.k2, r.st1, r.st2, r.act, r.v, r.s, r.p1, r.p2, T64, sw, lk);
       sw.pend1 = true;
       }
     else
       sw.pend1 = sw.pend2 = true;
     }
-  else if (any1 && any2)
-    resolve<FULL, true, true>(k1, k2, st1, st2, act, v, s, p1, p2, T, sw, lk);
-  else if (any1)
+  else if (r.any1 && r.any2)
+    resolve<FULL, true, true>(r.k1, r.k2, r.st1, r.st2, r.act, r.v, r.s, r.p1, r.p2, T, sw, lk);
+  else if (r.any1)
     {
-    resolve<FULL, true, false>(k1, k2, st1, st2, act, v, s, p1, p2, T, sw, lk);
+    resolve<FULL, true, false>(r.k1, r.k2, r.st1, r.st2, r.act, r.v, r.s, r.p1, r.p2, T, sw, lk);
     sw.pend2 = true;
     }
-  else if (any2)
+  else if (r.any2)
     {
-    resolve<FULL, false, true>(k1, k2, st1, st2, act, v, s, p1, p2, T, sw, lk);
+    resolve<FULL, false, true>(r.k1, r.k2, r.st1, r.st2, r.act, r.v, r.s, r.p1, r.p2, T, sw, lk);
     sw.pend1 = true;
     }
   else
     sw.pend1 = sw.pend2 = true;
+  }
+
+// residual selection, byte layout of the step, bytes into the staging area (flush_end must have run)
+template <bool FULL>
+__device__ __forceinline__ void step_tail(const StepRegs& r, uint32_t i, uint32_t i_end, uint32_t n, uint8_t* __restrict__ stage, Sweep& sw,
+                                          const LaneK& lk)
+  {
   // residual selection (fpsc.c:146-189)
-  const uint32_t x1 = v ^ p1, x2 = v ^ (a + p2);
+  const uint32_t x1 = r.v ^ r.p1, x2 = r.v ^ (r.a + r.p2);
   const uint32_t n1 = (39u - (uint32_t)__clz((int)x1)) >> 3;
   const uint32_t n2 = (39u - (uint32_t)__clz((int)(x2 | 1u))) >> 3;        // DFCM residuals take at least one byte
   // n2 >= 1, so n2 < n1 already says n1 > 1: one comparison decides, the length is the minimum, and 4 + n2 = 4 | n2 (n2 <= 3 here)
@@ -753,8 +775,8 @@ __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_en
   bool slot = true;
   if (!FULL)
     {
-    slot = act || (i_end == n && i < ((n + 7u) & ~7u));      // value or tail padding slot (fpsc.c:196-204)
-    if (!act)
+    slot = r.act || (i_end == n && i < ((n + 7u) & ~7u));    // value or tail padding slot (fpsc.c:196-204)
+    if (!r.act)
       {
       code = slot ? 1u : 0u;
       len = code;
@@ -770,7 +792,6 @@ __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_en
   bc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bc, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
   bc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bc, 0x141, 0xf, 0xf, true);    // row_half_mirror
   const uint32_t hq = sw.posl + lk.grp3 + pre;               // my group's header (if I lead it), my residual starts at hq + 3
-  flush_end(sw, stage, gbase, lk);
   {
   const uint32_t re = len ? hq + len : lk.dumpq;             // residual end - 3
   // most significant byte first, in this order (a zero byte of lane l must not overtake the byte its owner writes);
@@ -791,12 +812,15 @@ __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_en
   }
   const uint32_t hdr = FULL ? 24u : 3u * ((uint32_t)__popcll(__ballot(slot)) >> 3);
   sw.posl += hdr + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+
+// first half of a flush: full 256-byte blocks go to the slot as aligned dwords, the rest moves to the front of the staging area.  Only
+// the LDS reads are issued here; their data is used by flush_end() in the next step, right before its first byte is staged (LDS
+// operations of a wave execute in order), so the wave never waits for the round trip.
+__device__ __forceinline__ void flush_begin(Sweep& sw, const uint8_t* __restrict__ stage, const LaneK& lk)
+  {
   if (sw.posl >= 256u)
     {
-    // Full 256-byte blocks go to the slot as aligned dwords, the rest moves to the front of the staging area.  Only the LDS reads
-    // are issued here; their data is used by flush_end() in the next step, right before its first byte is staged (LDS operations
-    // of a wave execute in order), so the wave never waits for the round trip.
     const uint32_t* stw = (const uint32_t*)stage;
     const uint32_t nb = sw.posl >> 8;                        // 1 or 2
     sw.fw0 = stw[lk.lane];
@@ -808,7 +832,70 @@ __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_en
     sw.flushed += nb << 8;
     sw.posl &= 255u;
     }
+  }
+
+// one step of one component: 64 values starting at index i0 (FULL: all of them inside the segment)
+template <bool FULL, int MODE>
+__device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_end, uint32_t n, uint32_t* __restrict__ T,
+                                          uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase,
+                                          Sweep& sw, const LaneK& lk)
+  {
+  const uint32_t i = i0 + (uint32_t)lk.lane;
+  StepRegs r;
+  step_head<FULL>(r, v, i, i_end, sw);
+  step_resolve<FULL, MODE>(r, T, sw, lk);
+  flush_end(sw, stage, gbase, lk);
+  step_tail<FULL>(r, i, i_end, n, stage, sw, lk);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  flush_begin(sw, stage, lk);
   next_carry(sw.cy, v);
+  }
+
+// one step of all A components of a tile of 64 vertices (k_fpc32_code_t), phase by phase
+template <int A, bool FULL, int MODE, int LW, int TW>
+__device__ __forceinline__ void tile_step(const uint32_t (&v)[A], uint32_t i0, uint32_t i_end, uint32_t n, uint32_t* __restrict__ lds,
+                                          uint8_t* __restrict__ slots, size_t slot_stride, size_t slot_off, Sweep (&sw)[A], const LaneK& lk)
+  {
+  const uint32_t i = i0 + (uint32_t)lk.lane;
+  StepRegs r[A];
+#pragma unroll
+  for (int c = 0; c < A; ++c)
+    step_head<FULL>(r[c], v[c], i, i_end, sw[c]);
+  bool any = false, anyfl = false;
+#pragma unroll
+  for (int c = 0; c < A; ++c)
+    {
+    any = any || r[c].any1 || r[c].any2;
+    anyfl = anyfl || sw[c].fl_nb != 0u;
+    }
+  if (any)
+    {
+#pragma unroll
+    for (int c = 0; c < A; ++c)
+      step_resolve<FULL, MODE>(r[c], lds + c * LW, sw[c], lk);
+    }
+  else
+    {
+#pragma unroll
+    for (int c = 0; c < A; ++c)
+      sw[c].pend1 = sw[c].pend2 = true;
+    }
+  if (anyfl)
+    {
+#pragma unroll
+    for (int c = 0; c < A; ++c)
+      flush_end(sw[c], (uint8_t*)(lds + c * LW + TW), slots + (size_t)c * slot_stride + slot_off, lk);
+    }
+#pragma unroll
+  for (int c = 0; c < A; ++c)
+    step_tail<FULL>(r[c], i, i_end, n, (uint8_t*)(lds + c * LW + TW), sw[c], lk);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+  for (int c = 0; c < A; ++c)
+    flush_begin(sw[c], (const uint8_t*)(lds + c * LW + TW), lk);
+#pragma unroll
+  for (int c = 0; c < A; ++c)
+    next_carry(sw[c].cy, v[c]);
   }
 
 // MODE M_TAGGED: table entries of 64 bits and resolve_atomic; else 32-bit entries and resolve (ballots) or resolve_xchg.
@@ -1026,10 +1113,7 @@ __global__ void __launch_bounds__(64) k_fpc32_code_t(const uint32_t* __restrict_
     load_tiles<A, PFT>(nxt, src, ib + 64u * PFT, i_end, lane);
 #pragma unroll
     for (int pu = 0; pu < PFT; ++pu)
-#pragma unroll
-      for (int c = 0; c < A; ++c)
-        code_step<true, MODE>(cur[pu][c], ib + 64u * pu, i_end, n, lds + c * LW, (uint8_t*)(lds + c * LW + TW),
-                                slots + (size_t)c * slot_stride + (size_t)g * segcap, sw[c], lk);
+      tile_step<A, true, MODE, LW, TW>(cur[pu], ib + 64u * pu, i_end, n, lds, slots, slot_stride, (size_t)g * segcap, sw, lk);
 #pragma unroll
     for (int pu = 0; pu < PFT; ++pu)
 #pragma unroll
@@ -1043,16 +1127,10 @@ __global__ void __launch_bounds__(64) k_fpc32_code_t(const uint32_t* __restrict_
     VertexT<A> t = {};
     if (i < i_end)
       t = *(const VertexT<A>*)(src + (size_t)i * A);
-#pragma unroll
-    for (int c = 0; c < A; ++c)
-      {
-      if (ib + 64u <= i_end)
-        code_step<true, MODE>(t.w[c], ib, i_end, n, lds + c * LW, (uint8_t*)(lds + c * LW + TW),
-                                slots + (size_t)c * slot_stride + (size_t)g * segcap, sw[c], lk);
-      else
-        code_step<false, MODE>(t.w[c], ib, i_end, n, lds + c * LW, (uint8_t*)(lds + c * LW + TW),
-                                 slots + (size_t)c * slot_stride + (size_t)g * segcap, sw[c], lk);
-      }
+    if (ib + 64u <= i_end)
+      tile_step<A, true, MODE, LW, TW>(t.w, ib, i_end, n, lds, slots, slot_stride, (size_t)g * segcap, sw, lk);
+    else
+      tile_step<A, false, MODE, LW, TW>(t.w, ib, i_end, n, lds, slots, slot_stride, (size_t)g * segcap, sw, lk);
     }
   uint32_t viol = 0;
 #pragma unroll
