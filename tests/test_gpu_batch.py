@@ -277,13 +277,16 @@ def test_the_device_passes_the_lane_order_test_of_the_exchange_sweep(api):
 
 @pytest.mark.parametrize("env_add", [{"TRICO_FPC32_TILE": "3"}, {"TRICO_FPC32_TILE": "1"}, {"TRICO_FPC32_TILE": "2"},
                                      {"TRICO_FPC32_TILE": "3", "TRICO_FPC32_ATOMIC": "1"}, {"TRICO_FPC32_PRIO": "0"},
-                                     {"TRICO_FPC32_PRIO": "3"}, {"TRICO_FPC32_XCHG": "0"}, {"TRICO_FPC32_XCHG": "0", "TRICO_FPC32_TILE": "3"}])
+                                     {"TRICO_FPC32_PRIO": "3"}, {"TRICO_FPC32_XCHG": "0"}, {"TRICO_FPC32_XCHG": "0", "TRICO_FPC32_TILE": "3"},
+                                     {"TRICO_FPC32_SWEEPS": "1"}, {"TRICO_FPC32_SWEEPS": "1", "TRICO_FPC32_PRIO": "0"}])
 def test_encoder_variants_write_the_same_bytes(env_add):
     """The opt-in shapes of the float encoder (k_fpc32_encode.hip): TRICO_FPC32_TILE bit 0 / bit 1 = the index / code sweep with one
     wave per segment that walks all three components of whole vertices (the interleaved array is read once per sweep);
     TRICO_FPC32_PRIO = who gets the issue slots among the component waves of a workgroup (default 8: whoever is behind);
     TRICO_FPC32_XCHG=0 = run starts resolved with ballots instead of one lane-ordered LDS exchange (the default once the device has
-    passed the order test).  They decide time and traffic, never bytes."""
+    passed the order test); TRICO_FPC32_SWEEPS=1 = the one-sweep encoder (k_fpc32_sweep1: segments coded without their incoming
+    tables, the values that depend on them deferred to k_fpc32_fixup and put in place by the gather).  They decide time and traffic,
+    never bytes."""
     env = dict(os.environ)
     env.update(env_add)
     out = subprocess.run([sys.executable, "-c", ENC_CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)

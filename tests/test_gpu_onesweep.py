@@ -1,0 +1,75 @@
+"""The one-sweep float encoder (TRICO_FPC32_SWEEPS=1; k_fpc32_sweep1 / k_fpc32_pscan_* / k_fpc32_fixup and the record path of
+k_fpc32_gather in k_fpc32_encode.hip) against the oracle: the archives have to be the reference's bytes, through the whole
+parity suite and on streams built to stress the deferred values - a stream whose every DFCM class is new (a record per value at
+the start of every segment), exact hits that are deferred (residual length 0: four unused bytes in a row), one- and two-component
+streams, and streams shorter than a segment.  The switch is read once per process, hence the child process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r + "/tests")
+from trico_amd import api
+from oracle import oracle as O
+assert api.lib().trico_hip_fpc32_code_sweep() == 2
+rng = np.random.default_rng(7)
+def bits(u):
+    return np.ascontiguousarray(u.astype(np.uint32)).view(np.float32)
+cases = []
+# every value a new DFCM class for a long while: strides with distinct top bits
+n = 300000
+cases.append(("vertices", bits(np.cumsum(rng.integers(0, 1 << 31, n * 3, dtype=np.int64)) & 0xffffffff), n))
+# long runs of exact FCM hits interrupted by jumps into new classes (deferred values of length 0 and 4)
+v = np.repeat(rng.integers(0, 1 << 32, 4000, dtype=np.int64), 97)[: 120000 * 3]
+cases.append(("vertices", bits(v), 120000))
+# constant stream, and a ramp (one class, stride hits)
+cases.append(("vertices", bits(np.full(90000 * 3, 0x3f800000, dtype=np.int64)), 90000))
+cases.append(("vertex_normals", (np.arange(200001 * 3, dtype=np.float32) * 0.25), 200001))
+# two components and one component, lengths around the step and segment sizes
+for nn in (1, 7, 63, 64, 65, 1023, 1024, 1025, 70001):
+    cases.append(("uv_per_vertex", rng.standard_normal(nn * 2).astype(np.float32), nn))
+    cases.append(("attributes_float", (rng.integers(0, 50, nn) * 0.5).astype(np.float32), nn))
+a = api.Archive.open_for_writing(1 << 16)
+o = O.OracleArchive()
+for name, data, count in cases:
+    assert a.write(name, data, count) == 1, (name, count, api.last_error())
+    o.write(name, data, count)
+x, y = a.tobytes(), o.tobytes()
+assert len(x) == len(y), (len(x), len(y))
+assert x == y, [i for i in range(len(x)) if x[i] != y[i]][:8]
+# and back
+r = api.Archive.open_for_reading(x)
+for name, data, count in cases:
+    if name == "attributes_float":
+        got = r.read_alloc(name, count, np.float32)
+        assert got is not None, (name, api.last_error())
+    else:
+        got = np.zeros_like(data)
+        assert r.read(name, got) == 1, (name, api.last_error())
+    assert got.tobytes() == data.tobytes(), name
+print("ONESWEEP OK", len(x))
+"""
+
+
+def test_one_sweep_encoder_writes_the_reference_bytes():
+    env = dict(os.environ)
+    env["TRICO_FPC32_SWEEPS"] = "1"
+    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ONESWEEP OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_one_sweep_encoder_through_the_parity_suite():
+    """tests/test_gpu_parity.py in a child process with the one-sweep encoder switched on."""
+    env = dict(os.environ)
+    env["TRICO_FPC32_SWEEPS"] = "1"
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q"], env=env,
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]

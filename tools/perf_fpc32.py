@@ -26,9 +26,16 @@ for it in range(6):
     if it == 0:
         dst = torch.empty(sum(sizes) + 1024, dtype=torch.uint8, device="cuda")
     off = 0
-    for c in range(3):          # payloads gathered straight to their (device) destination, as the archive writer does
-        assert L.trico_hip_fetch_payload(ctx, c, dst.data_ptr() + off) == 1, api.last_error()
-        off += sizes[c]
+    if os.environ.get("PERF_GATHER_ALL", "1") == "1":   # all payloads with ONE gather launch, as the archive writer does
+        ptrs = (ctypes.c_void_p * 3)()
+        for c in range(3):
+            ptrs[c] = dst.data_ptr() + off
+            off += sizes[c]
+        assert L.trico_hip_fetch_payloads(ctx, 3, ptrs) == 1, api.last_error()
+    else:
+        for c in range(3):      # one launch per component
+            assert L.trico_hip_fetch_payload(ctx, c, dst.data_ptr() + off) == 1, api.last_error()
+            off += sizes[c]
     L.trico_hip_synchronize()
     t1 = time.perf_counter()
     print("iter", it, "wall ms %.3f" % ((t1 - t0) * 1e3), list(sizes), flush=True)

@@ -156,6 +156,8 @@ def lib():
     L.trico_hip_int_decode.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u32), ci, u32, vp]
     L.trico_hip_int_decode.restype = ci
     L.trico_hip_fetch_payload.argtypes = [vp, ci, vp]
+    L.trico_hip_fetch_payloads.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    L.trico_hip_fetch_payloads.restype = ctypes.c_int
     L.trico_hip_fetch_payload.restype = ci
     L.trico_hip_payload_device_pointer.argtypes = [vp, ci]
     L.trico_hip_payload_device_pointer.restype = vp

@@ -357,10 +357,15 @@ __global__ void __launch_bounds__(64) k_fpc32_index_t(const uint32_t* __restrict
 
 // ---- scan: incoming index table of segment g = max over earlier segments -----------------------------
 __global__ void __launch_bounds__(256) k_fpc32_scan_a(const uint32_t* __restrict__ summ, uint32_t S, int arity,
-                                                      uint32_t* __restrict__ chmax, uint32_t* __restrict__ flags)
+                                                      uint32_t* __restrict__ chmax, uint32_t* __restrict__ flags, uint32_t* __restrict__ nrec)
   {
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
-    flags[0] = 0u;                                           // the code sweep's "LDS order violated" word (a memset of 4 bytes costs 7 us)
+  if (blockIdx.x == 0 && blockIdx.y == 0)
+    {
+    if (threadIdx.x == 0)
+      flags[0] = 0u;                                         // the code sweep's "LDS order violated" word (a memset of 4 bytes costs 7 us)
+    for (uint32_t r = threadIdx.x; r < S * (uint32_t)arity; r += 256u)
+      nrec[r] = 0u;                                          // two sweeps: no deferred values for the gather to skip around
+    }
   const uint32_t col = blockIdx.x * 256u + threadIdx.x;      // (component, class)
   const uint32_t ncol = (uint32_t)arity * TAB;
   if (col >= ncol)
@@ -644,6 +649,64 @@ __device__ __forceinline__ void resolve_xchg(uint32_t k1, uint32_t k2, bool st1,
   if (D2) { sw.kc2 = (uint32_t)__builtin_amdgcn_readlane((int)k2, 63); sw.pend2 = false; }
   }
 
+// resolve_xchg for the one-sweep encoder (k_fpc32_sweep1): the segment's incoming table is not known while it is coded.  The table
+// starts filled with a sentinel and a bitmap of the classes written so far; a run start that gets the sentinel back for a class
+// not in the bitmap has met the incoming entry (ft = first touch): its value is coded later (k_fpc32_fixup).  A payload that
+// happens to equal the sentinel is told apart by the bitmap.
+constexpr uint32_t SENT = 0x7fc0dead;
+
+template <bool FULL, bool D1, bool D2>
+__device__ __forceinline__ void resolve_xchg_h(uint32_t k1, uint32_t k2, bool st1, bool st2, bool act, uint32_t v, uint32_t s,
+                                               uint32_t& p1, uint32_t& p2, bool& ft1, bool& ft2, uint32_t* __restrict__ T,
+                                               uint32_t* __restrict__ seen, Sweep& sw, const LaneK& lk)
+  {
+  if (lk.lane == 0)
+    {
+    if (D1 && sw.pend1) T[sw.kc1] = sw.cy.m1;
+    if (D2 && sw.pend2) T[sw.kc2] = sw.cy.m1 - sw.cy.m2;
+    }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  bool c1 = false, c2 = false;
+  if (D1)
+    {
+    const bool en = (FULL || act) && k1 != dpp_shl1(0xfffffffeu, k1);
+    if (st1 || en)
+      {
+      const uint32_t old = __hip_atomic_exchange(&T[k1], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      p1 = st1 ? old : p1;
+      c1 = st1 && old == SENT;
+      }
+    }
+  if (D2)
+    {
+    const bool en = (FULL || act) && k2 != dpp_shl1(0xfffffffeu, k2);
+    if (st2 || en)
+      {
+      const uint32_t old = __hip_atomic_exchange(&T[k2], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      p2 = st2 ? old : p2;
+      c2 = st2 && old == SENT;
+      }
+    }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (__ballot(c1 || c2))
+    {
+    // lane order again: of two starts of one class in this step the lower one finds the bit clear
+    if (c1)
+      {
+      const uint32_t bit = 1u << (k1 & 31u);
+      ft1 = (__hip_atomic_fetch_or(&seen[k1 >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) & bit) == 0u;
+      }
+    if (c2)
+      {
+      const uint32_t bit = 1u << (k2 & 31u);
+      ft2 = (__hip_atomic_fetch_or(&seen[k2 >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) & bit) == 0u;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  if (D1) { sw.kc1 = (uint32_t)__builtin_amdgcn_readlane((int)k1, 63); sw.pend1 = false; }
+  if (D2) { sw.kc2 = (uint32_t)__builtin_amdgcn_readlane((int)k2, 63); sw.pend2 = false; }
+  }
+
 // store the bytes of staged word `w` (byte offset off inside the slot, multiple of 4) that lie below hi
 __device__ __forceinline__ void store_span(uint8_t* __restrict__ gbase, uint32_t off, uint32_t w, uint32_t hi)
   {
@@ -677,6 +740,7 @@ struct StepRegs                                  // per-lane values a step carri
   {
   uint32_t v, a, s, k1, k2, p1, p2;
   bool act, st1, st2, any1, any2;
+  bool ft1, ft2;                                 // one-sweep encoder: the prediction is what the segment came in with, not known yet
   };
 
 // classes (fpsc.c:76-84 with e1 = 4, e2 = 10): k1 from v[i-1], k2 from the strides of v[i-1] and v[i-2]; run starts
@@ -701,6 +765,7 @@ __device__ __forceinline__ void step_head(StepRegs& r, uint32_t v, uint32_t i, u
   r.s = v - r.a;
   r.p1 = r.a;                                               // inside a run: previous value / previous stride
   r.p2 = s1;
+  r.ft1 = r.ft2 = false;
   }
 
 // predictions of the run starts (only in steps that have any), MODE as above
@@ -759,9 +824,11 @@ __device__ __forceinline__ void step_resolve(StepRegs& r, uint32_t* __restrict__
   }
 
 // residual selection, byte layout of the step, bytes into the staging area (flush_end must have run)
-template <bool FULL>
+struct RecSink { uint32_t* recs; uint32_t off, count; }; // one-sweep encoder: all record lists, word offset of this wave's, its length (4 words each)
+
+template <bool FULL, bool HOLES = false>
 __device__ __forceinline__ void step_tail(const StepRegs& r, uint32_t i, uint32_t i_end, uint32_t n, uint8_t* __restrict__ stage, Sweep& sw,
-                                          const LaneK& lk)
+                                          const LaneK& lk, RecSink* sink = nullptr)
   {
   // residual selection (fpsc.c:146-189)
   const uint32_t x1 = r.v ^ r.p1, x2 = r.v ^ (r.a + r.p2);
@@ -782,6 +849,15 @@ __device__ __forceinline__ void step_tail(const StepRegs& r, uint32_t i, uint32_
       len = code;
       x = 0u;
       }
+    }
+  const bool hole = HOLES && (r.ft1 || r.ft2);
+  if (hole)
+    {
+    // four zero bytes and code 0 for now; k_fpc32_fixup writes the residual (front of the four bytes) and ORs the code in,
+    // the gather drops what the residual does not need
+    len = 4u;
+    code = 0u;
+    x = 0u;
     }
   // byte layout of the step: [hdr g0][residuals 0..7][hdr g1][residuals 8..15]...
   // bytes of the residuals below my lane: one DPP scan (six adds) instead of three ballots and their six mbcnt
@@ -810,6 +886,28 @@ __device__ __forceinline__ void step_tail(const StepRegs& r, uint32_t i, uint32_
   stage[ha + 1u] = (uint8_t)(bc >> 8);
   stage[ha + 2u] = (uint8_t)bc;
   }
+  if (HOLES)
+    {
+    const uint64_t hm = __ballot(hole);
+    if (hm)
+      {
+      // record: where the four bytes are (offset in the slot) and how far behind its group header, which value, which classes are
+      // open, the prediction that is known if only one is open
+      const uint32_t pre_lead = (uint32_t)__builtin_amdgcn_ds_bpermute((lk.lane & ~7) << 2, (int)pre);
+      const uint32_t pos = sw.flushed + hq + 3u, dh = 3u + pre - pre_lead;
+      const uint32_t idx = sink->count + popc_below(hm);
+      if (hole)
+        {
+        u32x4 w;
+        w[0] = pos | (dh << 27);
+        w[1] = i;
+        w[2] = r.k1 | ((r.k2 - 16u) << 4) | ((uint32_t)r.ft1 << 14) | ((uint32_t)r.ft2 << 15) | (((uint32_t)lk.lane & 7u) << 16);
+        w[3] = r.ft1 ? (r.ft2 ? 0u : r.p2) : r.p1;
+        *(u32x4*)(sink->recs + sink->off + 4u * idx) = w;
+        }
+      sink->count += (uint32_t)__popcll(hm);
+      }
+    }
   const uint32_t hdr = FULL ? 24u : 3u * ((uint32_t)__popcll(__ballot(slot)) >> 3);
   sw.posl += hdr + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   }
@@ -1031,6 +1129,287 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
     atomicOr(flags, 1u);
   }
 
+// ---- ONE sweep: code every segment without knowing what it comes in with --------------------------------------------------------
+// The two-sweep scheme reads the input twice because a segment's first lookup of a class needs the latest writer of that class in
+// everything before it.  Those lookups are few (one per class the segment touches: a handful for a smooth coordinate, a few hundred of
+// 19,584 values for a noisy one), and nothing else depends on them - a value's prediction only decides ITS residual and code.  So:
+//   k_fpc32_sweep1  the code sweep with the exchange resolve (resolve_xchg_h), tables starting as "unknown".  A value whose prediction
+//                   would come from the incoming table gets four zero bytes and code 0 and a 16-byte record; at the end the wave
+//                   publishes its table (= what the segment leaves behind, per class) and the bitmap of the classes it wrote.
+//   k_fpc32_pscan_* incoming payload of every (segment, class) = the entry of the nearest earlier segment that wrote the class.
+//   k_fpc32_fixup   one thread per record: residual and code from the incoming entry; residual bytes into the front of the four
+//                   reserved bytes, code ORed into the group header, the unused bytes counted per segment.
+//   k_fpc32_offsets, k_fpc32_gather (which skips the unused bytes of the records of a segment).
+// The input is read once (+ 8 bytes per record), the index sweep and its zeroing are gone.
+constexpr int SEENW = 36;                               // words of the per-wave class bitmap (1040 bits, padded)
+constexpr int LDSW_1 = TAB + STAGE / 4 + SEENW;         // per-wave LDS words of k_fpc32_sweep1 (5,104 B)
+constexpr uint32_t RCAP = 1040;                         // records per (segment, component): a class is met first at most once
+
+__global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_fpc32_sweep1(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t L, uint32_t S, uint32_t* __restrict__ outT,
+               uint32_t* __restrict__ outSeen, uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap,
+               uint32_t* __restrict__ segbytes, uint32_t* __restrict__ nrec, uint32_t* __restrict__ recs, uint32_t prio_mode)
+  {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t g = blockIdx.x;
+  volatile uint32_t* prog = lds + arity * LDSW_1;
+  uint32_t* T = lds + c * LDSW_1;
+  uint8_t* stage = (uint8_t*)(T + TAB);
+  uint32_t* seen = T + TAB + STAGE / 4;
+  for (int k = lane; k < TAB; k += 64)
+    T[k] = SENT;
+  if (lane < SEENW)
+    seen[lane] = 0u;
+  LaneK lk;
+  lk.lane = lane;
+  lk.lt = (1ull << lane) - 1ull;
+  lk.bit = 1ull << lane;
+  lk.sh3 = 3u * ((uint32_t)lane & 7u);
+  lk.grp3 = 3u * ((uint32_t)lane >> 3);
+  lk.dumpw = (uint32_t)(TAB + STAGE_LIVE / 4 + lane);
+  lk.dumpq = (uint32_t)(STAGE_LIVE + 4 * lane + 1);
+  lk.lead = (lane & 7) == 0;
+  const uint32_t i_begin = g * L;
+  const uint32_t i_end = (n - i_begin < L) ? n : i_begin + L;
+  uint8_t* gbase = slots + (size_t)c * slot_stride + (size_t)g * segcap;
+  const size_t rowi = (size_t)g * arity + c;
+  RecSink sink = { recs, (uint32_t)(rowi * RCAP * 4u), 0u };
+  Sweep sw;
+  sw.kc1 = sw.kc2 = 0xfffffffeu;
+  sw.pend1 = sw.pend2 = false;
+  sw.posl = 0;
+  sw.flushed = 0;
+  sw.tag = 0;
+  sw.viol = 0;
+  sw.fl_nb = 0;
+  if (g == 0)
+    {
+    if (lane == 0)
+      {
+      stage[0] = 0x25;                      // (4/2) << 4 | (10/2), fpsc.c:120
+      stage[1] = (uint8_t)(n >> 24); stage[2] = (uint8_t)(n >> 16); stage[3] = (uint8_t)(n >> 8); stage[4] = (uint8_t)n;
+      }
+    sw.posl = 5u;
+    }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  uint32_t cur[PF], nxt[PF];
+  sw.cy = load_carry(src, i_begin, arity, c);
+  load_block(cur, src, i_begin, i_end, arity, c, lane);
+  if (prio_mode == 8u && lane == 0)
+    prog[c] = i_begin;
+  for (uint32_t ib = i_begin; ib < i_end; ib += 64u * PF)
+    {
+    load_block(nxt, src, ib + 64u * PF, i_end, arity, c, lane);
+    if (prio_mode == 8u)
+      {
+      if (lane == 0)
+        prog[c] = ib;
+      uint32_t ahead = 0;
+      for (int o = 0; o < arity; ++o)
+        ahead = max(ahead, (uint32_t)__builtin_amdgcn_readfirstlane((int)prog[o]) + 1u);
+      if (ib + 1u + 64u * PF <= ahead)
+        __builtin_amdgcn_s_setprio(3);
+      else
+        __builtin_amdgcn_s_setprio(0);
+      }
+#pragma unroll
+    for (int pu = 0; pu < PF; ++pu)
+      {
+      const uint32_t i0 = ib + 64u * pu;
+      if (i0 >= i_end)
+        break;
+      const uint32_t i = i0 + (uint32_t)lane;
+      StepRegs r;
+      if (i0 + 64u <= i_end)
+        {
+        step_head<true>(r, cur[pu], i, i_end, sw);
+        if (r.any1 && r.any2)
+          resolve_xchg_h<true, true, true>(r.k1, r.k2, r.st1, r.st2, true, r.v, r.s, r.p1, r.p2, r.ft1, r.ft2, T, seen, sw, lk);
+        else if (r.any1)
+          {
+          resolve_xchg_h<true, true, false>(r.k1, r.k2, r.st1, r.st2, true, r.v, r.s, r.p1, r.p2, r.ft1, r.ft2, T, seen, sw, lk);
+          sw.pend2 = true;
+          }
+        else if (r.any2)
+          {
+          resolve_xchg_h<true, false, true>(r.k1, r.k2, r.st1, r.st2, true, r.v, r.s, r.p1, r.p2, r.ft1, r.ft2, T, seen, sw, lk);
+          sw.pend1 = true;
+          }
+        else
+          sw.pend1 = sw.pend2 = true;
+        flush_end(sw, stage, gbase, lk);
+        step_tail<true, true>(r, i, i_end, n, stage, sw, lk, &sink);
+        }
+      else
+        {
+        step_head<false>(r, cur[pu], i, i_end, sw);
+        if (r.any1 || r.any2)
+          resolve_xchg_h<false, true, true>(r.k1, r.k2, r.st1, r.st2, r.act, r.v, r.s, r.p1, r.p2, r.ft1, r.ft2, T, seen, sw, lk);
+        else
+          sw.pend1 = sw.pend2 = true;
+        flush_end(sw, stage, gbase, lk);
+        step_tail<false, true>(r, i, i_end, n, stage, sw, lk, &sink);
+        }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      flush_begin(sw, stage, lk);
+      next_carry(sw.cy, cur[pu]);
+      }
+#pragma unroll
+    for (int pu = 0; pu < PF; ++pu)
+      cur[pu] = nxt[pu];
+    }
+  flush_end(sw, stage, gbase, lk);
+  {
+  const uint32_t off = 4u * (uint32_t)lane;
+  if (off < sw.posl)
+    store_span(gbase + sw.flushed, off, ((const uint32_t*)stage)[lane], sw.posl);
+  }
+  if (prio_mode == 8u && lane == 0)
+    prog[c] = 0u;
+  // what the segment leaves behind: the table with the last value's writes applied, and which classes it wrote at all
+  if (lane == 0)
+    {
+    if (sw.pend1) T[sw.kc1] = sw.cy.m1;
+    if (sw.pend2) T[sw.kc2] = sw.cy.m1 - sw.cy.m2;
+    }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (int k = lane; k < TAB; k += 64)
+    outT[rowi * ROW + k] = T[k];
+  if (lane < SEENW)
+    outSeen[rowi * SEENW + lane] = seen[lane];
+  if (lane == 0)
+    {
+    segbytes[(size_t)c * S + g] = sw.flushed + sw.posl;
+    nrec[rowi] = sink.count;
+    }
+  }
+
+// incoming payload of (segment, class): the published entry of the nearest earlier segment whose bitmap has the class, else 0
+__global__ void __launch_bounds__(256) k_fpc32_pscan_a(const uint32_t* __restrict__ outT, const uint32_t* __restrict__ outSeen, uint32_t S, int arity,
+                                                       uint32_t* __restrict__ chlast, uint32_t* __restrict__ chhas, uint32_t* __restrict__ flags)
+  {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    flags[0] = 0u;                                           // read back with the sizes (k_fpc32_offsets); only the tagged sweep raises it
+  const uint32_t col = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t ncol = (uint32_t)arity * TAB;
+  if (col >= ncol)
+    return;
+  const uint32_t c = col / TAB, k = col % TAB;
+  const uint32_t g0 = blockIdx.y * CH, g1 = (g0 + CH < S) ? g0 + CH : S;
+  uint32_t last = 0, has = 0;
+#pragma unroll 8
+  for (uint32_t g = g0; g < g1; ++g)
+    {
+    const size_t r = (size_t)g * arity + c;
+    const uint32_t w = outSeen[r * SEENW + (k >> 5)], t = outT[r * ROW + k];
+    if ((w >> (k & 31u)) & 1u) { last = t; has = 1u; }
+    }
+  chlast[(size_t)blockIdx.y * ncol + col] = last;
+  chhas[(size_t)blockIdx.y * ncol + col] = has;
+  }
+
+__global__ void __launch_bounds__(256) k_fpc32_pscan_b(const uint32_t* __restrict__ outT, const uint32_t* __restrict__ outSeen, uint32_t S, int arity,
+                                                       const uint32_t* __restrict__ chlast, const uint32_t* __restrict__ chhas,
+                                                       uint32_t* __restrict__ inc)
+  {
+  const uint32_t col = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t ncol = (uint32_t)arity * TAB;
+  if (col >= ncol)
+    return;
+  const uint32_t c = col / TAB, k = col % TAB;
+  uint32_t carry = 0;
+  for (uint32_t j = 0; j < blockIdx.y; ++j)
+    if (chhas[(size_t)j * ncol + col])
+      carry = chlast[(size_t)j * ncol + col];
+  const uint32_t g0 = blockIdx.y * CH, g1 = (g0 + CH < S) ? g0 + CH : S;
+#pragma unroll 8
+  for (uint32_t g = g0; g < g1; ++g)
+    {
+    const size_t r = (size_t)g * arity + c;
+    const uint32_t w = outSeen[r * SEENW + (k >> 5)], t = outT[r * ROW + k];
+    inc[r * ROW + k] = carry;
+    if ((w >> (k & 31u)) & 1u) carry = t;
+    }
+  }
+
+// the deferred values: residual, length and code from the incoming entries (fpsc.c:133-189 for one value).  Nothing is written to the
+// slot here (scattered byte stores and atomics on 1 M fields cost 0.13 ms): the records take the result, in the form the gather wants -
+// it ORs residuals and codes into the bytes on their way through its registers and drops the unused bytes of the fields.  Record
+// afterwards: w0 = e (output position at which the unused rest of the field would start: the residual is the `length` output bytes
+// right before it), w1 = residual, w2 = code | length << 4 | index in the group << 8 | (residual start - header, in output bytes) << 12,
+// w3 = unused field bytes up to and including this record.
+__global__ void __launch_bounds__(256) k_fpc32_fixup(const uint32_t* __restrict__ src, int arity, uint32_t S, const uint32_t* __restrict__ inc,
+                                                     uint32_t* __restrict__ segbytes, const uint32_t* __restrict__ nrec, uint32_t* __restrict__ recs)
+  {
+  __shared__ uint32_t rp[RCAP], cum[RCAP], part[4];
+  const uint32_t g = blockIdx.x, c = blockIdx.y;
+  const size_t rowi = (size_t)g * arity + c;
+  const uint32_t H = nrec[rowi];
+  if (H == 0u)
+    return;
+  uint32_t* list = recs + rowi * RCAP * 4u;
+  const uint32_t* row = inc + rowi * ROW;
+  // consecutive records per thread, so that the running sum of unused bytes is a scan over threads
+  const uint32_t per = (H + 255u) / 256u;
+  const uint32_t j0 = threadIdx.x * per < H ? threadIdx.x * per : H, j1 = (j0 + per < H) ? j0 + per : H;
+  uint32_t sum = 0;
+  for (uint32_t j = j0; j < j1; ++j)
+    {
+    const u32x4 w = *(const u32x4*)(list + 4u * j);
+    const uint32_t i = w[1];
+    const uint32_t k1 = w[2] & 15u, k2 = 16u + ((w[2] >> 4) & 1023u), gi = (w[2] >> 16) & 7u;
+    const bool ft1 = (w[2] >> 14) & 1u, ft2 = (w[2] >> 15) & 1u;
+    const uint32_t v = src[(size_t)i * arity + c];
+    const uint32_t a = i ? src[(size_t)(i - 1u) * arity + c] : 0u;
+    const uint32_t p1 = ft1 ? row[k1] : w[3];
+    const uint32_t p2 = ft2 ? row[k2] : w[3];
+    const uint32_t x1 = v ^ p1, x2 = v ^ (a + p2);
+    const uint32_t n1 = blen(x1);
+    uint32_t n2 = blen(x2);
+    n2 = n2 ? n2 : 1u;
+    const bool use2 = n2 < n1;
+    const uint32_t len = use2 ? n2 : n1, x = use2 ? x2 : x1, code = use2 ? (n2 | 4u) : n1;
+    rp[j] = w[0];
+    list[4u * j + 1u] = x;
+    list[4u * j + 2u] = code | (len << 4) | (gi << 8);
+    sum += 4u - len;
+    cum[j] = 4u - len;                                    // for now: this record's unused bytes
+    }
+  const uint32_t incl = wave_scan_incl(sum);
+  if ((threadIdx.x & 63u) == 63u)
+    part[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  uint32_t run = incl - sum;
+  for (uint32_t wv = 0; wv < (threadIdx.x >> 6); ++wv)
+    run += part[wv];
+  for (uint32_t j = j0; j < j1; ++j)
+    {
+    run += cum[j];
+    cum[j] = run;
+    }
+  __syncthreads();
+  for (uint32_t j = j0; j < j1; ++j)
+    {
+    const uint32_t pos = rp[j] & 0x7ffffffu, hdr = pos - (rp[j] >> 27);
+    const uint32_t before = j ? cum[j - 1u] : 0u, u = cum[j] - before;
+    // unused bytes before the group header: those of the fields that END at or before it (the fields of the same group between the
+    // header and this record lie behind the header)
+    uint32_t jj = j, hshift = 0;
+    while (jj > 0u)
+      {
+      --jj;
+      if ((rp[jj] & 0x7ffffffu) + 4u <= hdr) { hshift = cum[jj]; break; }
+      }
+    const uint32_t rstart = pos - before;                 // output position of the field's first byte
+    list[4u * j] = rstart + 4u - u;                       // e
+    list[4u * j + 2u] |= (rstart - (hdr - hshift)) << 12;
+    list[4u * j + 3u] = cum[j];
+    }
+  if (threadIdx.x == 255u)
+    segbytes[(size_t)c * S + g] -= run;                   // thread 255 ends with the total
+  }
+
 // ---- tile variant of sweep C: one wave codes ALL components of its segment (see k_fpc32_index_t) --------------------------
 // Same steps, same tables and staging areas per component (side by side in the wave's LDS), same slots: only who walks them
 // differs.  The interleaved array is read once, 64 whole vertices per load.
@@ -1184,39 +1563,210 @@ __global__ void __launch_bounds__(1024) k_fpc32_offsets(const uint32_t* __restri
 // ---- gather: segment slots -> contiguous payload -------------------------------------------------------
 // grid (S, arity); each workgroup moves one segment.  The destination is written as aligned 16-byte vectors;
 // the source (a 256-byte aligned slot) is read as 4 + 1 dwords per vector and re-aligned with v_alignbyte.
+constexpr uint32_t GBLK = 512;                    // gather, one-sweep path: search index per 256 output bytes (segments up to 128 KiB)
+constexpr uint32_t GDIRTY = 4096;                 // ... vectors near a record that wait for the second pass (power of two)
 struct GatherDst { uint8_t* p[3]; };             // destination of every component (grid.y)
 
 __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap, uint32_t S,
                                                       const uint32_t* __restrict__ segbytes, const uint32_t* __restrict__ segoff,
-                                                      GatherDst dst)
+                                                      GatherDst dst, const uint32_t* __restrict__ nrec, const uint32_t* __restrict__ recs,
+                                                      int arity, int c0)
   {
+  __shared__ uint32_t e[RCAP], cum[RCAP], rx[RCAP], rm[RCAP], bidx[GBLK], ndirty;      // (RCAP >= 256: one speculative record per thread)
+  __shared__ uint16_t dirty[GDIRTY];
   const uint32_t g = blockIdx.x, c = blockIdx.y;
   const uint32_t len = segbytes[(size_t)c * S + g];
   const uint8_t* s = slots + (size_t)c * slot_stride + (size_t)g * segcap;       // 256-byte aligned, segcap has 280 bytes of slack
   uint8_t* d = dst.p[c] + segoff[(size_t)c * S + g];
   const uint32_t head = (uint32_t)((16u - ((uintptr_t)d & 15u)) & 15u);           // bytes until d is 16-byte aligned
   const uint32_t h = head < len ? head : len;
-  if (threadIdx.x < h)
-    d[threadIdx.x] = s[threadIdx.x];
   const uint32_t body = (len - h) >> 4;                                           // aligned destination vectors
   u32x4* dd = (u32x4*)(d + h);
-  const uint32_t* ss = (const uint32_t*)s + (h >> 2);
-  const uint32_t sh = h & 3u;
-  // destination vector t holds source bytes h + 16t .. h + 16t + 15
+  const uint32_t done = h + 16u * body;
+  const size_t rowi = (size_t)g * arity + (size_t)(c0 + (int)c);
+  const uint32_t* list = recs + rowi * RCAP * 4u;
+  // the thread's record before the number of records is known (garbage beyond it): one round trip less on the way to the first copy
+  const u32x4 spec = *(const u32x4*)(list + 4u * threadIdx.x);
+  const uint32_t H = nrec[rowi];
+  if (H == 0u)
+    {
+    if (threadIdx.x < h)
+      d[threadIdx.x] = s[threadIdx.x];
+    const uint32_t* ss = (const uint32_t*)s + (h >> 2);
+    const uint32_t sh = h & 3u;
+    // destination vector t holds source bytes h + 16t .. h + 16t + 15
+    for (uint32_t t = threadIdx.x; t < body; t += 256u)
+      {
+      const u32x4 lo = *(const u32x4*)(ss + 4u * t);                                // 4-byte aligned 16-byte load
+      const uint32_t hi = ss[4u * t + 4u];
+      u32x4 o;
+      o[0] = __builtin_amdgcn_alignbyte(lo[1], lo[0], sh);
+      o[1] = __builtin_amdgcn_alignbyte(lo[2], lo[1], sh);
+      o[2] = __builtin_amdgcn_alignbyte(lo[3], lo[2], sh);
+      o[3] = __builtin_amdgcn_alignbyte(hi, lo[3], sh);
+      dd[t] = o;
+      }
+    if (threadIdx.x < len - done)
+      d[done + threadIdx.x] = s[done + threadIdx.x];
+    return;
+    }
+  // One-sweep encoder: the slot holds H reserved fields of four zero bytes (k_fpc32_sweep1); the records say what belongs there
+  // (k_fpc32_fixup).  Output byte o is slot byte o + (unused field bytes before it); e[j] = output position at which the unused rest
+  // of field j would start - so the residual of record j is the output bytes right before e[j] - and cum[j] = unused bytes up to and
+  // including field j; e is non-decreasing (fields do not overlap), so the shift of an output position is a search in e.  Residual
+  // bytes and code bits are ORed into the vectors on their way through the registers (everything a record touches was left zero by
+  // the sweep); a record can only touch a vector that begins less than 51 bytes before its e (4 residual bytes, at most 31 from the
+  // group header to the field).
+  uint32_t bs = 8;
+  while ((len >> bs) >= GBLK - 1u)
+    ++bs;
+  if (threadIdx.x == 0)
+    ndirty = 0u;
+  e[threadIdx.x] = spec[0];
+  rx[threadIdx.x] = spec[1];
+  rm[threadIdx.x] = spec[2];
+  cum[threadIdx.x] = spec[3];
+  for (uint32_t j = threadIdx.x + 256u; j < H; j += 256u)
+    {
+    const u32x4 w = *(const u32x4*)(list + 4u * j);
+    e[j] = w[0];
+    rx[j] = w[1];
+    rm[j] = w[2];
+    cum[j] = w[3];
+    }
+  __syncthreads();
+  // first record with e > o: by bisection for a handful of records; for more, from the number of unused ranges that start at or
+  // before every 256th output position (coarser for segments beyond 128 KiB), which costs a pass and a barrier
+  const bool indexed = H > 16u;
+  if (indexed)
+    {
+    for (uint32_t bq = threadIdx.x; (bq << bs) <= len; bq += 256u)
+      {
+      const uint32_t o = bq << bs;
+      uint32_t lo = 0, hi = H;
+      while (lo < hi)
+        {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (e[mid] <= o) lo = mid + 1u; else hi = mid;
+        }
+      bidx[bq] = lo;
+      }
+    __syncthreads();
+    }
+  auto first_after = [&](uint32_t o) -> uint32_t
+    {
+    if (indexed)
+      {
+      uint32_t m = bidx[o >> bs];
+      while (m < H && e[m] <= o) ++m;
+      return m;
+      }
+    uint32_t lo = 0, hi = H;
+    while (lo < hi)
+      {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (e[mid] <= o) lo = mid + 1u; else hi = mid;
+      }
+    return lo;
+    };
+  // ORs what the records say into the 16 output bytes that begin at o (m = first record with e > o)
+  auto patch = [&](u32x4& out, uint32_t o, uint32_t m)
+    {
+    for (uint32_t j = m; j < H && e[j] < o + 51u; ++j)
+      {
+      const uint32_t x = rx[j], rmj = rm[j];
+      const uint32_t ln = (rmj >> 4) & 7u, h24 = (rmj & 7u) << (3u * ((rmj >> 8) & 7u)), oh = e[j] - ln - (rmj >> 12);
+      for (uint32_t bb = 0; bb < ln; ++bb)
+        {
+        const uint32_t q = e[j] - ln + bb - o;                                    // wraps to a huge number if before o
+        if (q < 16u)
+          out[q >> 2] |= ((x >> (8u * (ln - 1u - bb))) & 255u) << (8u * (q & 3u));
+        }
+      for (uint32_t bb = 0; bb < 3u; ++bb)
+        {
+        const uint32_t q = oh + bb - o;
+        if (q < 16u)
+          out[q >> 2] |= ((h24 >> (8u * (2u - bb))) & 255u) << (8u * (q & 3u));
+        }
+      }
+    };
+  // one output byte the slow way (head and tail bytes of the segment)
+  auto out_byte = [&](uint32_t o) -> uint8_t
+    {
+    const uint32_t m = first_after(o);
+    u32x4 v = { (uint32_t)s[o + (m ? cum[m - 1u] : 0u)], 0u, 0u, 0u };
+    patch(v, o, m);
+    return (uint8_t)v[0];
+    };
+  if (threadIdx.x < h)
+    d[threadIdx.x] = out_byte(threadIdx.x);
+  // Pass 1: the vectors no record is near are a plain copy with a shift; the others are only noted.  Pass 2 takes those, densely packed
+  // over the lanes: with a few records per KiB every wave of a single pass would walk the slow code for a handful of its lanes.
   for (uint32_t t = threadIdx.x; t < body; t += 256u)
     {
-    const u32x4 lo = *(const u32x4*)(ss + 4u * t);                                // 4-byte aligned 16-byte load
-    const uint32_t hi = ss[4u * t + 4u];
-    u32x4 o;
-    o[0] = __builtin_amdgcn_alignbyte(lo[1], lo[0], sh);
-    o[1] = __builtin_amdgcn_alignbyte(lo[2], lo[1], sh);
-    o[2] = __builtin_amdgcn_alignbyte(lo[3], lo[2], sh);
-    o[3] = __builtin_amdgcn_alignbyte(hi, lo[3], sh);
-    dd[t] = o;
+    const uint32_t o = h + 16u * t;
+    const uint32_t m = first_after(o);
+    if (m == H || e[m] >= o + 51u)
+      {
+      const uint32_t so = o + (m ? cum[m - 1u] : 0u), sh = so & 3u;
+      const uint32_t* ss = (const uint32_t*)(s + (so & ~3u));
+      const u32x4 lo = *(const u32x4*)ss;
+      const uint32_t hi = ss[4];
+      u32x4 out;
+      out[0] = __builtin_amdgcn_alignbyte(lo[1], lo[0], sh);
+      out[1] = __builtin_amdgcn_alignbyte(lo[2], lo[1], sh);
+      out[2] = __builtin_amdgcn_alignbyte(lo[3], lo[2], sh);
+      out[3] = __builtin_amdgcn_alignbyte(hi, lo[3], sh);
+      dd[t] = out;
+      }
+    else
+      dirty[atomicAdd(&ndirty, 1u) & (GDIRTY - 1u)] = (uint16_t)t;
     }
-  const uint32_t done = h + 16u * body;
+  __syncthreads();
+  const uint32_t nd = body > 65535u ? GDIRTY + 1u : ndirty;      // (16-bit vector numbers: segments beyond 1 MiB take every vector again)
+  // (more than GDIRTY of them: the list has wrapped and is useless, every vector is taken again)
+  for (uint32_t q = threadIdx.x; q < (nd <= GDIRTY ? nd : body); q += 256u)
+    {
+    const uint32_t t = nd <= GDIRTY ? (uint32_t)dirty[q] : q;
+    const uint32_t o = h + 16u * t;
+    const uint32_t m = first_after(o);
+    uint32_t shift = m ? cum[m - 1u] : 0u;
+    u32x4 out;
+    if (m == H || e[m] >= o + 16u)
+      {
+      const uint32_t so = o + shift, sh = so & 3u;
+      const uint32_t* ss = (const uint32_t*)(s + (so & ~3u));
+      const u32x4 lo = *(const u32x4*)ss;
+      const uint32_t hi = ss[4];
+      out[0] = __builtin_amdgcn_alignbyte(lo[1], lo[0], sh);
+      out[1] = __builtin_amdgcn_alignbyte(lo[2], lo[1], sh);
+      out[2] = __builtin_amdgcn_alignbyte(lo[3], lo[2], sh);
+      out[3] = __builtin_amdgcn_alignbyte(hi, lo[3], sh);
+      }
+    else
+      {
+      // unused ranges inside the vector: where every byte comes from first (LDS only), then the sixteen loads together
+      uint32_t mm = m, so[16];
+#pragma unroll
+      for (int qq = 0; qq < 16; ++qq)
+        {
+        const uint32_t ob = o + (uint32_t)qq;
+        while (mm < H && e[mm] <= ob) { shift = cum[mm]; ++mm; }
+        so[qq] = ob + shift;
+        }
+      uint8_t by[16];
+#pragma unroll
+      for (int qq = 0; qq < 16; ++qq)
+        by[qq] = s[so[qq]];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq)
+        out[qq] = (uint32_t)by[4 * qq] | ((uint32_t)by[4 * qq + 1] << 8) | ((uint32_t)by[4 * qq + 2] << 16) | ((uint32_t)by[4 * qq + 3] << 24);
+      }
+    patch(out, o, m);
+    dd[t] = out;
+    }
   if (threadIdx.x < len - done)
-    d[done + threadIdx.x] = s[done + threadIdx.x];
+    d[done + threadIdx.x] = out_byte(done + threadIdx.x);
   }
 
 // ---- compare: segment slots against an existing payload -------------------------------------------------
@@ -1266,7 +1816,7 @@ __global__ void k_fpc32_empty(uint8_t* out, size_t out_stride, uint32_t* sizes)
     sizes[3] = 0;
   }
 
-struct Plan { uint32_t L, S, segcap, nch; size_t rows, slot_stride, off_summ, off_inc, off_chmax, off_segbytes, off_segoff, off_flags, off_slots, total; };
+struct Plan { uint32_t L, S, segcap, nch; size_t rows, slot_stride, off_summ, off_inc, off_chmax, off_chhas, off_seen, off_nrec, off_recs, off_segbytes, off_segoff, off_flags, off_slots, total; };
 
 // Before resolve_xchg is trusted on a device, the device shows that its LDS unit applies the active lanes of one ds_wrxchg_rtn_b32
 // in increasing lane order (the property the kernel rests on; see resolve_xchg): 1024 waves x 96 exchanges with random keys (1 to
@@ -1377,6 +1927,10 @@ Plan make_plan(uint32_t n, int arity)
   p.off_summ = o;      o += align_up(p.rows * ROW * 4, 256);
   p.off_inc = o;       o += align_up(p.rows * ROW * 4, 256);
   p.off_chmax = o;     o += align_up((size_t)p.nch * arity * TAB * 4, 256);
+  p.off_chhas = o;     o += align_up((size_t)p.nch * arity * TAB * 4, 256);
+  p.off_seen = o;      o += align_up(p.rows * SEENW * 4, 256);
+  p.off_nrec = o;      o += align_up(p.rows * 4, 256);
+  p.off_recs = o;      o += align_up(p.rows * RCAP * 16, 256);
   p.off_segbytes = o;  o += align_up(p.rows * 4, 256);
   p.off_segoff = o;    o += align_up(p.rows * 4, 256);
   p.off_flags = o;     o += 256;
@@ -1419,9 +1973,27 @@ int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
   uint8_t* slots = d_ws + p.off_slots;
   const uint32_t* src = (const uint32_t*)d_src;
   const unsigned threads = 64u * (unsigned)arity;
-  static const int tile = [] { const char* e = getenv("TRICO_FPC32_TILE"); return e ? atoi(e) : 0; }();
-  const int mode = allow_atomic ? fpc32_code_sweep_mode() : M_BALLOT;
+  uint32_t* nrec = (uint32_t*)(d_ws + p.off_nrec);
   uint32_t* flags = (uint32_t*)(d_ws + p.off_flags);
+  static const int tile = [] { const char* e = getenv("TRICO_FPC32_TILE"); return e ? atoi(e) : 0; }();
+  static const int sweeps = [] { const char* e = getenv("TRICO_FPC32_SWEEPS"); return e ? atoi(e) : 2; }();
+  static const uint32_t prio_mode = [] { const char* e = getenv("TRICO_FPC32_PRIO"); return e ? (uint32_t)atoi(e) : 8u; }();
+  const int mode = allow_atomic ? fpc32_code_sweep_mode() : M_BALLOT;
+  if (sweeps == 1 && mode == M_XCHG && !tile)
+    {
+    // one sweep (see k_fpc32_sweep1): the input is read once, the values that depend on what a segment comes in with are coded afterwards
+    uint32_t* outSeen = (uint32_t*)(d_ws + p.off_seen);
+    uint32_t* chhas = (uint32_t*)(d_ws + p.off_chhas);
+    uint32_t* recs = (uint32_t*)(d_ws + p.off_recs);
+    hipLaunchKernelGGL(k_fpc32_sweep1, dim3(p.S), dim3(threads), (size_t)arity * LDSW_1 * 4 + 16, st, src, n, arity, p.L, p.S, summ, outSeen,
+                       slots, p.slot_stride, p.segcap, segbytes, nrec, recs, prio_mode);
+    const unsigned colblocks = ((unsigned)arity * TAB + 255u) / 256u;
+    hipLaunchKernelGGL(k_fpc32_pscan_a, dim3(colblocks, p.nch), dim3(256), 0, st, summ, outSeen, p.S, arity, chmax, chhas, flags);
+    hipLaunchKernelGGL(k_fpc32_pscan_b, dim3(colblocks, p.nch), dim3(256), 0, st, summ, outSeen, p.S, arity, chmax, chhas, inc);
+    hipLaunchKernelGGL(k_fpc32_fixup, dim3(p.S, arity), dim3(256), 0, st, src, arity, p.S, inc, segbytes, nrec, recs);
+    hipLaunchKernelGGL(k_fpc32_offsets, dim3(arity), dim3(1024), 0, st, segbytes, p.S, segoff, d_sizes, flags);
+    return hip_ok(hipGetLastError(), "fpc32 encode kernels (one sweep)") ? 1 : 0;
+    }
   if (tile && arity == 3)
     {
     // tile variants (bit 0: sweep A, bit 1: sweep C): one wave per segment walks all components (the interleaved array is read
@@ -1435,7 +2007,7 @@ int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
       hipLaunchKernelGGL(k_fpc32_index<false>, dim3(p.S, ISPLIT), dim3(192), ((size_t)BLOCK_V * 3 + (size_t)3 * LDSW_A) * 4, st, src, n, arity, p.L, summ);
       }
     const unsigned colblocks = (3u * TAB + 255u) / 256u;
-    hipLaunchKernelGGL(k_fpc32_scan_a, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax, flags);
+    hipLaunchKernelGGL(k_fpc32_scan_a, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax, flags, nrec);
     hipLaunchKernelGGL(k_fpc32_scan_b, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax, inc);
     if (!(tile & 2))
       hipLaunchKernelGGL(k_fpc32_code<M_BALLOT>, dim3(p.S), dim3(192), (size_t)3 * LDSW_C * 4 + 16, st,
@@ -1460,9 +2032,8 @@ int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
   else
     hipLaunchKernelGGL(k_fpc32_index<false>, dim3(p.S, ISPLIT), dim3(threads), lds_a, st, src, n, arity, p.L, summ);
   const unsigned colblocks = ((unsigned)arity * TAB + 255u) / 256u;
-  hipLaunchKernelGGL(k_fpc32_scan_a, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax, flags);
+  hipLaunchKernelGGL(k_fpc32_scan_a, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax, flags, nrec);
   hipLaunchKernelGGL(k_fpc32_scan_b, dim3(colblocks, p.nch), dim3(256), 0, st, summ, p.S, arity, chmax, inc);
-  static const uint32_t prio_mode = [] { const char* e = getenv("TRICO_FPC32_PRIO"); return e ? (uint32_t)atoi(e) : 8u; }();
   if (mode == M_TAGGED)
     hipLaunchKernelGGL(k_fpc32_code<M_TAGGED>, dim3(p.S), dim3(threads), (size_t)arity * LDSW_CA * 4 + 16, st,
                        src, n, arity, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes, flags, prio_mode);
@@ -1488,7 +2059,8 @@ int launch_fpc32_gather(uint32_t n, int arity, int c, const uint8_t* d_ws, uint8
   const uint8_t* slots = d_ws + p.off_slots;
   GatherDst dst = { { d_dst, nullptr, nullptr } };
   hipLaunchKernelGGL(k_fpc32_gather, dim3(p.S, 1), dim3(256), 0, current_stream(), slots + (size_t)c * p.slot_stride, (size_t)0,
-                     p.segcap, p.S, segbytes + (size_t)c * p.S, segoff + (size_t)c * p.S, dst);
+                     p.segcap, p.S, segbytes + (size_t)c * p.S, segoff + (size_t)c * p.S, dst, (const uint32_t*)(d_ws + p.off_nrec),
+                     (const uint32_t*)(d_ws + p.off_recs), arity, c);
   return hip_ok(hipGetLastError(), "k_fpc32_gather") ? 1 : 0;
   }
 
@@ -1523,7 +2095,7 @@ int launch_fpc32_gather_all(uint32_t n, int arity, const uint8_t* d_ws, uint8_t*
   const uint32_t* segoff = (const uint32_t*)(d_ws + p.off_segoff);
   GatherDst dst = { { d_dst[0], arity > 1 ? d_dst[1] : nullptr, arity > 2 ? d_dst[2] : nullptr } };
   hipLaunchKernelGGL(k_fpc32_gather, dim3(p.S, arity), dim3(256), 0, current_stream(), d_ws + p.off_slots, p.slot_stride,
-                     p.segcap, p.S, segbytes, segoff, dst);
+                     p.segcap, p.S, segbytes, segoff, dst, (const uint32_t*)(d_ws + p.off_nrec), (const uint32_t*)(d_ws + p.off_recs), arity, 0);
   return hip_ok(hipGetLastError(), "k_fpc32_gather") ? 1 : 0;
   }
 
