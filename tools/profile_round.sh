@@ -20,7 +20,7 @@ python $R/tools/prof_summary.py $O/bench > $O/${TAG}_bench_config2_kernel_stats.
 echo "== encoder alone: kernel trace"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/enc -- python $R/tools/perf_fpc32.py grid > $O/enc.log 2>&1
 { echo "# rocprofv3 --kernel-trace --stats -- python tools/perf_fpc32.py grid: the float-vertex encoder alone on the 50 M config-2 vertices (6 encodes,"
-  echo "# payloads gathered to a device buffer with one launch per component; no decoder, no self-check traffic beside it)"
+  echo "# payloads gathered to a device buffer with ONE launch for the three components, as the archive writer does; no decoder, no self-check traffic beside it)"
   grep "kernel span" $O/enc.log
   python $R/tools/prof_summary.py $O/enc; } > $O/${TAG}_fpc32_encode_kernel_stats.txt
 echo "== PMC: HBM traffic of the float encoder (separate passes)"

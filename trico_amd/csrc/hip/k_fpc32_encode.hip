@@ -1826,8 +1826,10 @@ __global__ void __launch_bounds__(256) k_fpc32_xchg_selftest(uint32_t rounds, ui
   {
   __shared__ uint32_t T[4][1024];
   __shared__ uint32_t shadow[4][1024];
+  __shared__ uint32_t bits[4][32], sbits[4][32];       // the one-sweep encoder's "class written" bitmap: ds_or_rtn_b32, same question
   const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
   for (uint32_t i = lane; i < 1024u; i += 64u) { T[w][i] = 0u; shadow[w][i] = 0u; }
+  if (lane < 32u) { bits[w][lane] = 0u; sbits[w][lane] = 0u; }
   __syncthreads();
   const uint32_t nkeys = 1u << (blockIdx.x % 11u);
   uint32_t x = (blockIdx.x * 0x9E3779B9u) ^ (threadIdx.x * 0x85EBCA6Bu) ^ 0x2545F491u;
@@ -1839,19 +1841,25 @@ __global__ void __launch_bounds__(256) k_fpc32_xchg_selftest(uint32_t rounds, ui
     const bool active = ((x >> 3) & 7u) != 0u || (r & 15u) == 0u;
     const uint32_t val = ((r + 1u) << 6) | lane;
     uint32_t expect = shadow[w][k];
-    bool last = true;
+    bool last = true, lower = false;
     for (uint32_t j = 0; j < 64u; ++j)
       {
       const uint32_t kj = (uint32_t)__shfl((int)k, (int)j, 64), vj = (uint32_t)__shfl((int)val, (int)j, 64);
       const bool aj = __shfl((int)active, (int)j, 64) != 0;
-      if (aj && kj == k) { if (j < lane) expect = vj; if (j > lane) last = false; }
+      if (aj && kj == k) { if (j < lane) { expect = vj; lower = true; } if (j > lane) last = false; }
       }
-    uint32_t old = 0;
+    const uint32_t bit = 1u << (k & 31u);
+    const bool expect_bit = lower || (sbits[w][k >> 5] & bit) != 0u;
+    uint32_t old = 0, oldbits = 0;
     if (active)
+      {
       old = __hip_atomic_exchange(&T[w][k], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    if (active && old != expect) ++wrong;
+      oldbits = __hip_atomic_fetch_or(&bits[w][k >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+    if (active && (old != expect || ((oldbits & bit) != 0u) != expect_bit)) ++wrong;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (active && last) shadow[w][k] = val;
+    if (active) atomicOr(&sbits[w][k >> 5], bit);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (active && last && T[w][k] != val) ++wrong;
     }
