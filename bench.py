@@ -131,6 +131,33 @@ def pmc_traffic(mesh, live=True):
     return _pmc_file_traffic(files[-1]), os.path.relpath(files[-1], ROOT) + " (committed summary, not this run)"
 
 
+def encoder_variants(W, H):
+    """The float-vertex encoder alone (tools/perf_fpc32.py: hipEvent span of its launch sequence over the 50 M vertices, 5 timed
+    encodes) as child processes: the default against the opt-in one-sweep encoder (TRICO_FPC32_SWEEPS=1), on both meshes.  Same
+    bytes in every case (tests/test_gpu_onesweep.py); `frac` is algorithmic bytes / span / 8 TB/s like the roofline block."""
+    import re
+    rows = []
+    for mesh in ("grid", "walk"):
+        for sweeps in ("2", "1"):
+            env = dict(os.environ, TRICO_FPC32_SWEEPS=sweeps)
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "perf_fpc32.py"), mesh, str(W), str(H)], env=env, timeout=240,
+                                   capture_output=True, text=True)
+                m = re.search(r"kernel span avg ([0-9.]+) ms; raw ([0-9.]+) MB comp ([0-9.]+) MB", r.stdout)
+                if r.returncode != 0 or not m:
+                    rows.append({"mesh": mesh, "sweeps": int(sweeps), "error": (r.stdout + r.stderr)[-200:]})
+                    continue
+                ms, raw, comp = float(m.group(1)), float(m.group(2)), float(m.group(3))
+                gb = (raw + comp) / 1e3 / (ms * 1e-3)
+                rows.append({"mesh": mesh, "sweeps": int(sweeps), "avg_launch_ms": ms, "achieved": round(gb, 1), "unit": "GB/s",
+                             "frac": round(gb / HBM_PEAK_GBPS, 5)})
+            except Exception as e:      # noqa: BLE001
+                rows.append({"mesh": mesh, "sweeps": int(sweeps), "error": repr(e)[:200]})
+    return {"what": "float-vertex encoder alone, default (two sweeps) vs TRICO_FPC32_SWEEPS=1 (one sweep, opt-in); measured traffic of the "
+                    "one-sweep encoder: profiles/r03c_fpc32_onesweep.txt (2.8 x algorithmic on the grid mesh, 2.1 x on the walk mesh)",
+            "rows": rows}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -786,6 +813,7 @@ def main():
                 torch.cuda.empty_cache()
                 out["config3"] = config3_block(api, meshgen, dev, W, H, grid_dev=[("vertices", d_v, nv), ("triangles", d_t, nt)])
                 out["config5_mixed"] = out["config3"].pop("config5_mixed")
+                out["encoder_variants"] = encoder_variants(W, H)
         if world == 1 and not args.no_cpu_baseline:
             allK = tuple(k for k in Ks if k in (8, 32)) if not (args.no_extras or args.quick) else ()
             if args.cpu_sample == "full":
