@@ -113,6 +113,7 @@ size_t fpc32_encode_workspace(uint32_t n, int arity);
 int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
                         uint8_t* d_ws, size_t ws_bytes, bool allow_atomic = true);
 void fpc32_distrust_atomic();
+bool lds_lane_order_ok();            // the device applies the lanes of one LDS exchange / or-rtn in lane order (tested once per device)
 int fpc32_code_sweep_mode();          // 0 ballots, 1 tagged entries, 2 lane-ordered exchange (runs the device's order test once)
 int launch_fpc32_gather(uint32_t n, int arity, int c, const uint8_t* d_ws, uint8_t* d_dst);
 int launch_fpc32_gather_all(uint32_t n, int arity, const uint8_t* d_ws, uint8_t* const d_dst[3]);

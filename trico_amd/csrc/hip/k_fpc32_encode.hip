@@ -1878,11 +1878,8 @@ bool fpc32_use_atomic()
   return env_atomic && !g_atomic_distrusted;
   }
 
-bool fpc32_xchg_usable()
+bool lane_order_tested()
   {
-  static const bool env_off = [] { const char* e = getenv("TRICO_FPC32_XCHG"); return e && e[0] == '0'; }();
-  if (env_off)
-    return false;
   static std::mutex mu;
   static int state[32] = { 0 };                  // per device: 0 not tested, 1 passed, 2 failed
   int dev = 0;
@@ -1908,6 +1905,12 @@ bool fpc32_xchg_usable()
       }
     }
   return state[dev] == 1;
+  }
+
+bool fpc32_xchg_usable()
+  {
+  static const bool env_off = [] { const char* e = getenv("TRICO_FPC32_XCHG"); return e && e[0] == '0'; }();
+  return !env_off && lane_order_tested();
   }
 
 Plan make_plan(uint32_t n, int arity)
@@ -1955,6 +1958,8 @@ size_t fpc32_encode_workspace(uint32_t n, int arity)
   }
 
 void fpc32_distrust_atomic() { g_atomic_distrusted = true; }
+
+bool lds_lane_order_ok() { return lane_order_tested(); }
 
 int fpc32_code_sweep_mode() { return fpc32_use_atomic() ? M_TAGGED : (fpc32_xchg_usable() ? M_XCHG : M_BALLOT); }
 

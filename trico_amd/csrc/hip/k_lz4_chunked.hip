@@ -291,12 +291,24 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
           w = ld64(src + pos);
         const uint32_t h = (uint32_t)(((w << 24) * 889523592379ull) >> 52);        // hash5 (lz4.c:643-648)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint32_t cnd = 0;
+        uint64_t later_same = 0;                                                   // higher lanes of this round with my hash
+        if (!dup)
+          {
+          // Attempt l reads the table entry of its hash and writes its position there, and sees what the attempts before it wrote
+          // (lz4.c:917-922): that is ONE exchange, because the LDS unit applies the active lanes of a ds_wrxchg_rtn_b32 in lane
+          // order (tested on the device before this path is taken, lds_lane_order_ok()).  No scoreboard, no ballots per hash bit;
+          // what the attempts behind the deciding one wrote is taken back below.
+          if (active)
+            cnd = __hip_atomic_exchange(&tab[h], pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          }
+        else
+          {
         if (active)
           dup[h] = (uint8_t)lane;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const bool clash = active && dup[h] != (uint8_t)lane;
-        uint32_t cnd = active ? tab[h] : 0u;
-        uint64_t later_same = 0;                                                   // higher lanes of this round with my hash
+        cnd = active ? tab[h] : 0u;
         if (__ballot(clash))
           {
           // Attempts of this round share a hash.  In the reference attempt l sees what the attempts before it wrote: its
@@ -321,6 +333,8 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
             cnd = ppos;
           later_same = same & ~((2ull << lane) - 1ull);
           }
+          }
+        const uint32_t found = cnd;                                                // what the table held when my turn came
         bool hit = false, pre = false;
         uint64_t cw = 0, pw = 0, pcw = 0;
         if (active && !fin && cnd + MAXD >= pos)
@@ -339,12 +353,20 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
         const bool first_fin = stop && ((__ballot(fin) >> first) & 1ull);
         // table writes: every attempt before the deciding one, and the deciding one too unless it is the final one
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        {
-        const int lastw = !stop ? 63 : (first_fin ? first - 1 : first);            // highest lane that writes
-        const uint64_t writers = lastw >= 63 ? ~0ull : (lastw < 0 ? 0ull : (2ull << lastw) - 1ull);
-        if (active && (lane < first || (lane == first && !first_fin)) && (later_same & writers) == 0ull)
-          tab[h] = pos;
-        }
+        if (!dup)
+          {
+          // exchange mode: all attempts have written.  The positions in an entry only grow (the parse moves forward), so the minimum
+          // with what each attempt behind the deciding one found restores the entry as the last attempt that counts left it.
+          if (active && stop && (lane > first || (lane == first && first_fin)))
+            atomicMin(&tab[h], found);
+          }
+        else
+          {
+          const int lastw = !stop ? 63 : (first_fin ? first - 1 : first);          // highest lane that writes
+          const uint64_t writers = lastw >= 63 ? ~0ull : (lastw < 0 ? 0ull : (2ull << lastw) - 1ull);
+          if (active && (lane < first || (lane == first && !first_fin)) && (later_same & writers) == 0ull)
+            tab[h] = pos;
+          }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (stop)
           {
@@ -440,7 +462,7 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
     }
   }
 
-struct Geom { uint32_t n, chunk, warm, K, dcap; size_t plane_stride; uint32_t alt_rounds, alt_dcap; };
+struct Geom { uint32_t n, chunk, warm, K, dcap; size_t plane_stride; uint32_t alt_rounds, alt_dcap, xchg; };   // xchg: search rounds through one LDS exchange (lz4_parse)
 constexpr uint32_t ALT_R = 4;             // alternative parses kept per chunk (k_lz4_alt)
 
 __global__ void __launch_bounds__(64) k_lz4_parse(const uint8_t* __restrict__ planes, Geom g, Desc* __restrict__ descs, Meta* __restrict__ metas,
@@ -463,7 +485,7 @@ __global__ void __launch_bounds__(64) k_lz4_parse(const uint8_t* __restrict__ pl
   const uint8_t* src = planes + (size_t)p * g.plane_stride;
   const uint32_t c_lo = k * g.chunk;
   const uint32_t c_hi = (k + 1u == g.K) ? 0xffffffffu : c_lo + g.chunk;
-  lz4_parse<1>(src, g.n, tab, dup, k == 0 ? 0u : c_lo - g.warm, false, k == 0, k == 0, c_lo, c_hi, descs + ck * g.dcap, g.dcap, meta,
+  lz4_parse<1>(src, g.n, tab, g.xchg ? nullptr : dup, k == 0 ? 0u : c_lo - g.warm, false, k == 0, k == 0, c_lo, c_hi, descs + ck * g.dcap, g.dcap, meta,
             snapTs + ck * 4096, endTs + ck * 4096, lane);
   }
 
@@ -480,7 +502,7 @@ __global__ void __launch_bounds__(64) k_lz4_parse(const uint8_t* __restrict__ pl
 constexpr uint32_t PROBE_S = 8, PROBE_W = 4096, PROBE_DCAP = PROBE_W / 4 + 16;
 
 __global__ void __launch_bounds__(64) k_lz4_probe(const uint8_t* __restrict__ planes, uint32_t n, size_t plane_stride, Desc* __restrict__ descs,
-                                                  Meta* __restrict__ metas)
+                                                  Meta* __restrict__ metas, uint32_t xchg)
   {
   __shared__ uint32_t tab[4096];
   __shared__ uint8_t dup[4096];
@@ -498,7 +520,7 @@ __global__ void __launch_bounds__(64) k_lz4_probe(const uint8_t* __restrict__ pl
     }
   const uint32_t section = n / PROBE_S;                                     // n >= the chunked threshold (MiB)
   const uint32_t w0 = s * section + (section - PROBE_W) / 2u;
-  lz4_parse<1>(planes + (size_t)p * plane_stride + w0, PROBE_W, tab, dup, 0u, false, true, true, 0u, 0xffffffffu, descs + pw * PROBE_DCAP,
+  lz4_parse<1>(planes + (size_t)p * plane_stride + w0, PROBE_W, tab, xchg ? nullptr : dup, 0u, false, true, true, 0u, 0xffffffffu, descs + pw * PROBE_DCAP,
             PROBE_DCAP, meta, nullptr, nullptr, lane);
   }
 
@@ -575,7 +597,7 @@ __global__ void __launch_bounds__(64) k_lz4_alt(const uint8_t* __restrict__ plan
   const size_t slot = cj * ALT_R + (r - 1);
   Meta* am = altMetas + slot;
   const uint32_t c_hi = (j + 1u == g.K) ? 0xffffffffu : (j + 1u) * g.chunk;
-  lz4_parse<1>(planes + (size_t)p * g.plane_stride, g.n, tab, dup, ip, true, false, true, j * g.chunk, c_hi, altDescs + slot * g.alt_dcap,
+  lz4_parse<1>(planes + (size_t)p * g.plane_stride, g.n, tab, g.xchg ? nullptr : dup, ip, true, false, true, j * g.chunk, c_hi, altDescs + slot * g.alt_dcap,
             g.alt_dcap, am, nullptr, altEndTs + slot * 4096, lane);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (lane == 0 && am->end_kind != END_NONE)
@@ -673,7 +695,7 @@ __global__ void __launch_bounds__(64 * STITCH_W) k_lz4_stitch(const uint8_t* __r
         tab[i] = curT[i];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       const uint32_t c_hi = (j + 1u == g.K) ? 0xffffffffu : (j + 1u) * g.chunk;
-      lz4_parse<STITCH_W>(src, g.n, tab, dups[wave], ip, true, false, true, j * g.chunk, c_hi, descs + cj * g.dcap, g.dcap, pm + j,
+      lz4_parse<STITCH_W>(src, g.n, tab, g.xchg ? nullptr : dups[wave], ip, true, false, true, j * g.chunk, c_hi, descs + cj * g.dcap, g.dcap, pm + j,
                           snapTs + cj * 4096, endTs + cj * 4096, lane, wave, xch);
       if (threadIdx.x == 0) pm[j].reparsed = 1u;
       }
@@ -959,6 +981,14 @@ __global__ void __launch_bounds__(EMIT_T) k_lz4_bigcopy(const uint8_t* __restric
     }
   }
 
+// the search rounds of lz4_parse through ds_wrxchg_rtn_b32: only where the device has shown that it applies the lanes of one such
+// instruction in lane order (the float encoder's test, k_fpc32_encode.hip); TRICO_LZ4_XCHG=0 keeps the scoreboard + ballot rounds
+static bool lz4_use_xchg()
+  {
+  static const bool off = [] { const char* e = getenv("TRICO_LZ4_XCHG"); return e && e[0] == '0'; }();
+  return !off && lds_lane_order_ok();
+  }
+
 struct Plan { Geom g; size_t off_desc, off_meta, off_snap, off_end, off_cbytes, off_coff, off_altdesc, off_altmeta, off_altend, total; };
 
 // mode 0: long matches (1 MiB chunks, 384 KiB warm-up), mode 1: short sequences (384 KiB / 96 KiB); TRICO_LZ4_CHUNK / TRICO_LZ4_WARM
@@ -1002,6 +1032,7 @@ Plan make_plan(uint32_t n, int nplanes, size_t plane_stride, int mode)
   p.off_coff = o;   o += align_up(cells * 4, 256);
   // alternative parses (k_lz4_alt): only for the long-match geometry; 4096 descriptors per slot (such chunks have dozens)
   p.g.alt_rounds = mode == 0 ? ALT_R : 0u;
+  p.g.xchg = lz4_use_xchg() ? 1u : 0u;
   p.g.alt_dcap = 4096;
   p.off_altmeta = o; o += align_up(cells * ALT_R * sizeof(Meta), 256);
   p.off_altdesc = o; o += p.g.alt_rounds ? align_up(cells * ALT_R * p.g.alt_dcap * sizeof(Desc), 256) : 0;
@@ -1058,7 +1089,7 @@ int launch_lz4_encode_chunked(const uint8_t* d_planes, size_t plane_stride, uint
     uint8_t* pa = d_ws + plans_bytes(n, nplanes, plane_stride);
     Meta* pm = (Meta*)pa;
     Desc* pd = (Desc*)(pa + align_up((size_t)nplanes * PROBE_S * sizeof(Meta), 256));
-    hipLaunchKernelGGL(k_lz4_probe, dim3(PROBE_S, nplanes), dim3(64), 0, st, d_planes, n, plane_stride, pd, pm);
+    hipLaunchKernelGGL(k_lz4_probe, dim3(PROBE_S, nplanes), dim3(64), 0, st, d_planes, n, plane_stride, pd, pm, lz4_use_xchg() ? 1u : 0u);
     Meta h[8 * PROBE_S];
     if (!hip_ok(hipMemcpyAsync(h, pm, (size_t)nplanes * PROBE_S * sizeof(Meta), hipMemcpyDeviceToHost, st), "lz4 probe readback") ||
         !hip_ok(hipStreamSynchronize(st), "lz4 probe"))
