@@ -33,6 +33,31 @@ cases.append(("vertices", bits(v), 120000))
 # constant stream, and a ramp (one class, stride hits)
 cases.append(("vertices", bits(np.full(90000 * 3, 0x3f800000, dtype=np.int64)), 90000))
 cases.append(("vertex_normals", (np.arange(200001 * 3, dtype=np.float32) * 0.25), 200001))
+# the sweep's "unknown" sentinel (0x7fc0dead, k_fpc32_encode.hip: SENT) as a payload: as a value (FCM entries), as a stride (DFCM entries),
+# alone and mixed with values of other classes, so that a class whose entry legitimately holds the sentinel is looked up again
+SENT = 0x7fc0dead
+m = 150000 * 3
+cases.append(("vertices", bits(np.full(m, SENT, dtype=np.int64)), 150000))
+cases.append(("vertex_normals", bits((np.arange(m, dtype=np.int64) * SENT) & 0xffffffff), 150000))
+mix = rng.integers(0, 1 << 32, m, dtype=np.int64)
+mix[::2] = SENT
+cases.append(("vertices", bits(mix), 150000))
+mix2 = np.cumsum(np.where(rng.integers(0, 3, m) == 0, SENT, rng.integers(0, 1 << 20, m))) & 0xffffffff
+cases.append(("vertex_normals", bits(mix2), 150000))
+# random streams of many shapes: few distinct values, random walks with rare jumps, pure noise
+for seed in range(12):
+    r2 = np.random.default_rng(100 + seed)
+    nn = int(r2.integers(1, 400000))
+    kind = seed %% 4
+    if kind == 0:
+        u = r2.integers(0, 1 << 32, nn * 3, dtype=np.int64)
+    elif kind == 1:
+        u = r2.choice(r2.integers(0, 1 << 32, 5, dtype=np.int64), nn * 3)
+    elif kind == 2:
+        u = np.cumsum(r2.integers(-1000, 1000, nn * 3)) & 0xffffffff
+    else:
+        u = (np.cumsum(r2.integers(0, 50, nn * 3)) + (r2.integers(0, 2000, nn * 3) == 0) * r2.integers(0, 1 << 31, nn * 3)) & 0xffffffff
+    cases.append(("vertices" if seed %% 2 else "vertex_normals", bits(u), nn))
 # two components and one component, lengths around the step and segment sizes
 for nn in (1, 7, 63, 64, 65, 1023, 1024, 1025, 70001):
     cases.append(("uv_per_vertex", rng.standard_normal(nn * 2).astype(np.float32), nn))
@@ -59,9 +84,11 @@ print("ONESWEEP OK", len(x))
 """
 
 
-def test_one_sweep_encoder_writes_the_reference_bytes():
+@pytest.mark.parametrize("sweeps", ["1", "2"])
+def test_one_sweep_encoder_writes_the_reference_bytes(sweeps):
+    """sweeps = 2: the same streams through the default encoder (exchange code sweep with index sweep)."""
     env = dict(os.environ)
-    env["TRICO_FPC32_SWEEPS"] = "1"
+    env["TRICO_FPC32_SWEEPS"] = sweeps
     out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ONESWEEP OK" in out.stdout, out.stdout + out.stderr
 
