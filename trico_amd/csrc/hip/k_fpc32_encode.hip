@@ -1082,8 +1082,12 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
   sw.cy = load_carry(src, i_begin, arity, c);
   uint32_t cur[PF], nxt[PF];
   load_block(cur, src, i_begin, i_end, arity, c, lane);
+  const uint32_t lag = prio_mode >> 8;                 // TRICO_FPC32_LAG: blocks a component wave may run ahead of the slowest (0 = any)
+  prio_mode &= 255u;
   if (prio_mode == 8u && lane == 0)
     prog[c] = i_begin;
+  if (lag)
+    __syncthreads();                                   // everybody's progress word is this workgroup's before anybody compares
   for (uint32_t ib = i_begin; ib < i_end; ib += 64u * PF)
     {
     load_block(nxt, src, ib + 64u * PF, i_end, arity, c, lane);
@@ -1095,11 +1099,22 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
         prog[c] = ib;
       uint32_t ahead = 0;
       for (int o = 0; o < arity; ++o)
-        ahead = max(ahead, (uint32_t)__builtin_amdgcn_readfirstlane((int)prog[o]) + 1u);
+        ahead = max(ahead, (uint32_t)__builtin_amdgcn_readfirstlane((int)prog[o]) + 1u);      // (a finished wave's 0xffffffff counts as 0)
       if (ib + 1u + 64u * PF <= ahead)
         __builtin_amdgcn_s_setprio(3);
       else
         __builtin_amdgcn_s_setprio(0);
+      // ... and with a lag the ones in front wait for it (bounded), so that the three waves read the same cache lines at about the
+      // same time and the interleaved array comes over HBM once
+      for (uint32_t spin = 0; lag && spin < 4096u; ++spin)
+        {
+        uint32_t lo = 0xffffffffu;
+        for (int o = 0; o < arity; ++o)
+          lo = min(lo, (uint32_t)__builtin_amdgcn_readfirstlane((int)prog[o]));
+        if (lo == 0xffffffffu || ib <= lo + lag * 64u * PF)
+          break;
+        __builtin_amdgcn_s_sleep(2);
+        }
       }
 #pragma unroll
     for (int pu = 0; pu < PF; ++pu)
@@ -1122,7 +1137,7 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
     store_span(gbase + sw.flushed, off, ((const uint32_t*)stage)[lane], sw.posl);
   }
   if (prio_mode == 8u && lane == 0)
-    prog[c] = 0u;                                      // done: nobody is behind me any more
+    prog[c] = 0xffffffffu;                             // done: nobody is behind me any more, nobody waits for me
   if (lane == 0)
     segbytes[(size_t)c * S + g] = sw.flushed + sw.posl;
   if (ATOMIC && sw.viol && lane == 0)
@@ -1153,6 +1168,7 @@ k_fpc32_sweep1(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t g = blockIdx.x;
+  prio_mode &= 255u;                                   // (the upper bits carry the two-sweep code sweep's lag)
   volatile uint32_t* prog = lds + arity * LDSW_1;
   uint32_t* T = lds + c * LDSW_1;
   uint8_t* stage = (uint8_t*)(T + TAB);
@@ -1990,7 +2006,10 @@ int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
   uint32_t* flags = (uint32_t*)(d_ws + p.off_flags);
   static const int tile = [] { const char* e = getenv("TRICO_FPC32_TILE"); return e ? atoi(e) : 0; }();
   static const int sweeps = [] { const char* e = getenv("TRICO_FPC32_SWEEPS"); return e ? atoi(e) : 2; }();
-  static const uint32_t prio_mode = [] { const char* e = getenv("TRICO_FPC32_PRIO"); return e ? (uint32_t)atoi(e) : 8u; }();
+  static const uint32_t prio_mode = [] {
+    const char* e = getenv("TRICO_FPC32_PRIO"), * l = getenv("TRICO_FPC32_LAG");
+    return (e ? (uint32_t)atoi(e) & 255u : 8u) | ((l ? (uint32_t)atoi(l) & 255u : 1u) << 8);
+  }();
   const int mode = allow_atomic ? fpc32_code_sweep_mode() : M_BALLOT;
   if (sweeps == 1 && mode == M_XCHG && !tile)
     {
