@@ -48,6 +48,10 @@ constexpr int ROW = 1040;      // words per (segment, component) row in the glob
 constexpr int CH = 32;         // segments per chunk in the cross-segment scan
 constexpr int LDSW_A = TAB;                        // per-wave LDS words, sweep A
 constexpr int PF = 8;          // steps (of 64 values) whose loads are kept in flight per wave
+#ifndef TRICO_PFC
+#define TRICO_PFC 8
+#endif
+constexpr int PFC = TRICO_PFC; // ... in the two-sweep code sweep
 
 __device__ __forceinline__ uint32_t dpp_shr1(uint32_t carry, uint32_t v)
   {
@@ -84,11 +88,12 @@ __device__ __forceinline__ uint32_t pick(uint32_t x1, uint32_t x2, uint32_t& len
 struct Carry { uint32_t m1, m2, m3; };
 
 // loads PF steps of this wave's component starting at value index i0 (0 beyond i_end)
-__device__ __forceinline__ void load_block(uint32_t (&r)[PF], const uint32_t* __restrict__ src, uint32_t i0, uint32_t i_end,
+template <int P>
+__device__ __forceinline__ void load_block(uint32_t (&r)[P], const uint32_t* __restrict__ src, uint32_t i0, uint32_t i_end,
                                            int arity, int c, int lane)
   {
 #pragma unroll
-  for (int pu = 0; pu < PF; ++pu)
+  for (int pu = 0; pu < P; ++pu)
     {
     const uint32_t i = i0 + 64u * pu + lane;
     r[pu] = (i0 < i_end && i < i_end) ? src[(size_t)i * arity + c] : 0u;
@@ -1080,7 +1085,7 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
     }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   sw.cy = load_carry(src, i_begin, arity, c);
-  uint32_t cur[PF], nxt[PF];
+  uint32_t cur[PFC], nxt[PFC];
   load_block(cur, src, i_begin, i_end, arity, c, lane);
   const uint32_t lag = prio_mode >> 8;                 // TRICO_FPC32_LAG: blocks a component wave may run ahead of the slowest (0 = any)
   prio_mode &= 255u;
@@ -1088,9 +1093,9 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
     prog[c] = i_begin;
   if (lag)
     __syncthreads();                                   // everybody's progress word is this workgroup's before anybody compares
-  for (uint32_t ib = i_begin; ib < i_end; ib += 64u * PF)
+  for (uint32_t ib = i_begin; ib < i_end; ib += 64u * PFC)
     {
-    load_block(nxt, src, ib + 64u * PF, i_end, arity, c, lane);
+    load_block(nxt, src, ib + 64u * PFC, i_end, arity, c, lane);
     if (prio_mode == 8u)
       {
       // the component that is behind gets the issue slots first: the waves of a workgroup hold their LDS until the last of them
@@ -1100,7 +1105,7 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
       uint32_t ahead = 0;
       for (int o = 0; o < arity; ++o)
         ahead = max(ahead, (uint32_t)__builtin_amdgcn_readfirstlane((int)prog[o]) + 1u);      // (a finished wave's 0xffffffff counts as 0)
-      if (ib + 1u + 64u * PF <= ahead)
+      if (ib + 1u + 64u * PFC <= ahead)
         __builtin_amdgcn_s_setprio(3);
       else
         __builtin_amdgcn_s_setprio(0);
@@ -1111,13 +1116,13 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
         uint32_t lo = 0xffffffffu;
         for (int o = 0; o < arity; ++o)
           lo = min(lo, (uint32_t)__builtin_amdgcn_readfirstlane((int)prog[o]));
-        if (lo == 0xffffffffu || ib <= lo + lag * 64u * PF)
+        if (lo == 0xffffffffu || ib <= lo + lag * 64u * PFC)
           break;
         __builtin_amdgcn_s_sleep(2);
         }
       }
 #pragma unroll
-    for (int pu = 0; pu < PF; ++pu)
+    for (int pu = 0; pu < PFC; ++pu)
       {
       const uint32_t i0 = ib + 64u * pu;
       if (i0 + 64u <= i_end)
@@ -1126,7 +1131,7 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
         code_step<false, MODE>(cur[pu], i0, i_end, n, T, stage, gbase, sw, lk);
       }
 #pragma unroll
-    for (int pu = 0; pu < PF; ++pu)
+    for (int pu = 0; pu < PFC; ++pu)
       cur[pu] = nxt[pu];
     }
   // what is left in the staging area (< 256 bytes)
