@@ -1085,7 +1085,7 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
     }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   sw.cy = load_carry(src, i_begin, arity, c);
-  uint32_t cur[PFC], nxt[PFC];
+  uint32_t cur[PFC];                                   // the next PFC steps' values: a slot is loaded again as soon as its step begins
   load_block(cur, src, i_begin, i_end, arity, c, lane);
   const uint32_t lag = prio_mode >> 8;                 // TRICO_FPC32_LAG: blocks a component wave may run ahead of the slowest (0 = any)
   prio_mode &= 255u;
@@ -1095,7 +1095,6 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
     __syncthreads();                                   // everybody's progress word is this workgroup's before anybody compares
   for (uint32_t ib = i_begin; ib < i_end; ib += 64u * PFC)
     {
-    load_block(nxt, src, ib + 64u * PFC, i_end, arity, c, lane);
     if (prio_mode == 8u)
       {
       // the component that is behind gets the issue slots first: the waves of a workgroup hold their LDS until the last of them
@@ -1125,14 +1124,18 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
     for (int pu = 0; pu < PFC; ++pu)
       {
       const uint32_t i0 = ib + 64u * pu;
-      if (i0 + 64u <= i_end)
-        code_step<true, MODE>(cur[pu], i0, i_end, n, T, stage, gbase, sw, lk);
-      else if (i0 < i_end)
-        code_step<false, MODE>(cur[pu], i0, i_end, n, T, stage, gbase, sw, lk);
+      const uint32_t v = cur[pu];
+      {
+      // the value this slot holds PFC steps from now: always PFC steps in flight, never more (a whole block fetched ahead doubled what
+      // a workgroup keeps in the L2, and 320 workgroups per XCD share 4 MB)
+      const uint32_t in = i0 + 64u * PFC + (uint32_t)lane;
+      cur[pu] = in < i_end ? src[(size_t)in * arity + c] : 0u;
       }
-#pragma unroll
-    for (int pu = 0; pu < PFC; ++pu)
-      cur[pu] = nxt[pu];
+      if (i0 + 64u <= i_end)
+        code_step<true, MODE>(v, i0, i_end, n, T, stage, gbase, sw, lk);
+      else if (i0 < i_end)
+        code_step<false, MODE>(v, i0, i_end, n, T, stage, gbase, sw, lk);
+      }
     }
   // what is left in the staging area (< 256 bytes)
   flush_end(sw, stage, gbase, lk);
