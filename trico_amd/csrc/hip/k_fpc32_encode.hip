@@ -1217,14 +1217,13 @@ k_fpc32_sweep1(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t
     sw.posl = 5u;
     }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  uint32_t cur[PF], nxt[PF];
+  uint32_t cur[PF];                                    // rolling prefetch as in k_fpc32_code
   sw.cy = load_carry(src, i_begin, arity, c);
   load_block(cur, src, i_begin, i_end, arity, c, lane);
   if (prio_mode == 8u && lane == 0)
     prog[c] = i_begin;
   for (uint32_t ib = i_begin; ib < i_end; ib += 64u * PF)
     {
-    load_block(nxt, src, ib + 64u * PF, i_end, arity, c, lane);
     if (prio_mode == 8u)
       {
       if (lane == 0)
@@ -1244,10 +1243,15 @@ k_fpc32_sweep1(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t
       if (i0 >= i_end)
         break;
       const uint32_t i = i0 + (uint32_t)lane;
+      const uint32_t vcur = cur[pu];
+      {
+      const uint32_t in = i0 + 64u * PF + (uint32_t)lane;
+      cur[pu] = in < i_end ? src[(size_t)in * arity + c] : 0u;
+      }
       StepRegs r;
       if (i0 + 64u <= i_end)
         {
-        step_head<true>(r, cur[pu], i, i_end, sw);
+        step_head<true>(r, vcur, i, i_end, sw);
         if (r.any1 && r.any2)
           resolve_xchg_h<true, true, true>(r.k1, r.k2, r.st1, r.st2, true, r.v, r.s, r.p1, r.p2, r.ft1, r.ft2, T, seen, sw, lk);
         else if (r.any1)
@@ -1267,7 +1271,7 @@ k_fpc32_sweep1(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t
         }
       else
         {
-        step_head<false>(r, cur[pu], i, i_end, sw);
+        step_head<false>(r, vcur, i, i_end, sw);
         if (r.any1 || r.any2)
           resolve_xchg_h<false, true, true>(r.k1, r.k2, r.st1, r.st2, r.act, r.v, r.s, r.p1, r.p2, r.ft1, r.ft2, T, seen, sw, lk);
         else
@@ -1277,11 +1281,8 @@ k_fpc32_sweep1(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t
         }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       flush_begin(sw, stage, lk);
-      next_carry(sw.cy, cur[pu]);
+      next_carry(sw.cy, vcur);
       }
-#pragma unroll
-    for (int pu = 0; pu < PF; ++pu)
-      cur[pu] = nxt[pu];
     }
   flush_end(sw, stage, gbase, lk);
   {
