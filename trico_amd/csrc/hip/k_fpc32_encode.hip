@@ -462,9 +462,10 @@ __device__ __forceinline__ void flush_end(Sweep& sw, uint8_t* __restrict__ stage
   {
   if (sw.fl_nb)
     {
-    *(uint32_t*)(gbase + sw.fl_off + 4u * (uint32_t)lk.lane) = sw.fw0;
+    // (streaming stores: the slot is read again only by the gather, and the lines should not push the input out of the L2)
+    __builtin_nontemporal_store(sw.fw0, (uint32_t*)(gbase + sw.fl_off + 4u * (uint32_t)lk.lane));
     if (sw.fl_nb == 2u)
-      *(uint32_t*)(gbase + sw.fl_off + 256u + 4u * (uint32_t)lk.lane) = sw.fw1;
+      __builtin_nontemporal_store(sw.fw1, (uint32_t*)(gbase + sw.fl_off + 256u + 4u * (uint32_t)lk.lane));
     ((uint32_t*)stage)[lk.lane] = sw.ft;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     sw.fl_nb = 0u;
