@@ -1161,9 +1161,11 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
 //                   would come from the incoming table gets four zero bytes and code 0 and a 16-byte record; at the end the wave
 //                   publishes its table (= what the segment leaves behind, per class) and the bitmap of the classes it wrote.
 //   k_fpc32_pscan_* incoming payload of every (segment, class) = the entry of the nearest earlier segment that wrote the class.
-//   k_fpc32_fixup   one thread per record: residual and code from the incoming entry; residual bytes into the front of the four
-//                   reserved bytes, code ORed into the group header, the unused bytes counted per segment.
-//   k_fpc32_offsets, k_fpc32_gather (which skips the unused bytes of the records of a segment).
+//   k_fpc32_fixup   per record: residual, length and code from the incoming entry, and where the gather will find them in its output
+//                   (nothing is written to the slot: scattered stores on a million fields cost more than the sweep saves); the
+//                   unused bytes of the fields are counted per segment.
+//   k_fpc32_offsets, k_fpc32_gather (which drops the unused bytes of the fields and ORs residuals and codes into the vectors on their
+//                   way through its registers).
 // The input is read once (+ 8 bytes per record), the index sweep and its zeroing are gone.
 constexpr int SEENW = 36;                               // words of the per-wave class bitmap (1040 bits, padded)
 constexpr int LDSW_1 = TAB + STAGE / 4 + SEENW;         // per-wave LDS words of k_fpc32_sweep1 (5,104 B)
