@@ -799,7 +799,7 @@ def main():
                          "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fe["avg_ms"],
-                         "code_sweep": {0: "ballots", 1: "tagged 64-bit table entries", 2: "lane-ordered LDS exchange"}.get(
+                         "code_sweep": {0: "two sweeps, ballots", 2: "two sweeps, lane-ordered LDS exchange", 3: "one sweep, lane-ordered LDS exchange"}.get(
                              L.trico_hip_fpc32_code_sweep(), "?")},
             "roofline_all": roofline_all,
             "kernels": kms,

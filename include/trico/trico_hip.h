@@ -216,10 +216,16 @@ enum trico_hip_kernel_id
  * out[3] (process-wide) = streams whose values, decoded in reference order at the end of the repeat ladder, still do not code back to their
  * payload: payloads the reference's encoder would not have written (decoded all the same; counts up, never reset) */
 TRICO_API void trico_hip_last_stats(uint32_t out[4]);
-/* which code sweep the float encoder (k_fpc32_encode.hip) uses on the current device: 0 = run starts resolved with ballots, 1 = tagged
- * 64-bit table entries (TRICO_FPC32_ATOMIC=1), 2 = one lane-ordered LDS exchange per predictor and step (the default once the device
- * has passed the order test, which the first call runs: ~0.3 ms; TRICO_FPC32_XCHG=0 turns it off).  All three write the same bytes. */
+/* which float encoder the library uses on the current device: 3 = ONE sweep, run starts resolved with one lane-ordered LDS exchange
+ * per predictor and step (k_fpc32_sweep.hip; the choice once the device has passed the order test, which the first call runs:
+ * ~0.3 ms), 0 = two sweeps, run starts resolved with ballots (k_fpc32_encode.hip; a device that fails the test, TRICO_FPC32_XCHG=0,
+ * and every stream the one-sweep coder raised a flag on), 2 = two sweeps with the exchange (TRICO_FPC32_SWEEPS=2, measurements).
+ * All write the same bytes. */
 TRICO_API int trico_hip_fpc32_code_sweep(void);
+/* write-side guard of the float encoder, process-wide, counting up: out[0] = streams coded again with the ballot coder because a
+ * sampled step of the one-sweep coder found the LDS exchange out of lane order (the device is not asked again afterwards),
+ * out[1] = because a value or stride equal to the coder's "never written" table mark was stored (2^-32 per value on random bits). */
+TRICO_API void trico_hip_encode_stats(uint32_t out[2]);
 TRICO_API void trico_hip_profile_enable(int on);
 TRICO_API void trico_hip_profile_reset(void);
 /* returns accumulated milliseconds and number of timed spans for kernel id `k` (syncs first) */

@@ -257,36 +257,23 @@ print("ENCODE OK")
 """
 
 
-def test_tagged_table_code_sweep_writes_the_same_bytes():
-    """TRICO_FPC32_ATOMIC=1: the float encoder's code sweep with 64-bit {tag, payload} table entries and one ds_max_rtn_u64 per
-    predictor and step instead of the ballot match (k_fpc32_encode.hip, resolve_atomic): byte-identical archives."""
-    env = dict(os.environ)
-    env["TRICO_FPC32_ATOMIC"] = "1"
-    out = subprocess.run([sys.executable, "-c", ENC_CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "ENCODE OK" in out.stdout, out.stdout + out.stderr
-
-
-def test_the_device_passes_the_lane_order_test_of_the_exchange_sweep(api):
-    """The float encoder's default code sweep resolves run starts with one ds_wrxchg_rtn_b32 per predictor and step, which rests on the
+def test_the_device_passes_the_lane_order_test_of_the_exchange(api):
+    """The float encoder resolves run starts with one ds_wrxchg_rtn_b32 per predictor and step (k_fpc32_sweep.hip), which rests on the
     LDS unit applying the lanes of one instruction in increasing lane order; the library tests that on the device before it uses the
-    kernel (k_fpc32_xchg_selftest) and would silently fall back to ballots otherwise.  On an MI355X the test has to pass."""
-    if os.environ.get("TRICO_FPC32_XCHG") == "0" or os.environ.get("TRICO_FPC32_ATOMIC") == "1":
-        pytest.skip("code sweep chosen by the environment")
-    assert api.lib().trico_hip_fpc32_code_sweep() == 2
+    kernel (k_fpc32_xchg_selftest) and would fall back to the two-sweep coder with ballots otherwise.  On an MI355X the test has to
+    pass, and the library has to choose the one-sweep coder by itself (no environment variable)."""
+    if os.environ.get("TRICO_FPC32_XCHG") == "0" or os.environ.get("TRICO_FPC32_SWEEPS"):
+        pytest.skip("coder chosen by the environment")
+    assert api.lib().trico_hip_fpc32_code_sweep() == 3
 
 
-@pytest.mark.parametrize("env_add", [{"TRICO_FPC32_TILE": "3"}, {"TRICO_FPC32_TILE": "1"}, {"TRICO_FPC32_TILE": "2"},
-                                     {"TRICO_FPC32_TILE": "3", "TRICO_FPC32_ATOMIC": "1"}, {"TRICO_FPC32_PRIO": "0"},
-                                     {"TRICO_FPC32_PRIO": "3"}, {"TRICO_FPC32_XCHG": "0"}, {"TRICO_FPC32_XCHG": "0", "TRICO_FPC32_TILE": "3"},
-                                     {"TRICO_FPC32_SWEEPS": "1"}, {"TRICO_FPC32_SWEEPS": "1", "TRICO_FPC32_PRIO": "0"}])
+@pytest.mark.parametrize("env_add", [{"TRICO_FPC32_SWEEPS": "2"}, {"TRICO_FPC32_XCHG": "0"}, {"TRICO_FPC32_PRIO": "0"},
+                                     {"TRICO_FPC32_LAG": "0"}, {"TRICO_FPC32_SWEEPS": "2", "TRICO_FPC32_PRIO": "0"}])
 def test_encoder_variants_write_the_same_bytes(env_add):
-    """The opt-in shapes of the float encoder (k_fpc32_encode.hip): TRICO_FPC32_TILE bit 0 / bit 1 = the index / code sweep with one
-    wave per segment that walks all three components of whole vertices (the interleaved array is read once per sweep);
-    TRICO_FPC32_PRIO = who gets the issue slots among the component waves of a workgroup (default 8: whoever is behind);
-    TRICO_FPC32_XCHG=0 = run starts resolved with ballots instead of one lane-ordered LDS exchange (the default once the device has
-    passed the order test); TRICO_FPC32_SWEEPS=1 = the one-sweep encoder (k_fpc32_sweep1: segments coded without their incoming
-    tables, the values that depend on them deferred to k_fpc32_fixup and put in place by the gather).  They decide time and traffic,
-    never bytes."""
+    """The other shapes of the float encoder: TRICO_FPC32_SWEEPS=2 = index sweep + code sweep with the exchange (round 3's encoder,
+    kept for measurements); TRICO_FPC32_XCHG=0 = two sweeps with ballots, i.e. what a device that fails the lane-order test runs, what
+    a stream is coded with again when the one-sweep coder raised a flag, and what the decoders' self-check re-encodes with;
+    TRICO_FPC32_PRIO / _LAG = how the component waves of a workgroup are kept together.  They decide time and traffic, never bytes."""
     env = dict(os.environ)
     env.update(env_add)
     out = subprocess.run([sys.executable, "-c", ENC_CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)

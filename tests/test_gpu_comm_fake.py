@@ -57,6 +57,6 @@ print("FAKE GATHER OK")
 @pytest.mark.gpu
 def test_comm_gather_offsets_with_four_ranks():
     env = dict(os.environ)
-    env["TRICO_AMD_LIB"] = os.path.join(ROOT, "trico_amd", "lib", "libtrico_testhooks.so")
+    env["TRICO_AMD_LIB"] = os.path.join(ROOT, "tests", "_build", "libtrico_testhooks.so")
     out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "FAKE GATHER OK" in out.stdout, out.stdout + out.stderr

@@ -1,8 +1,9 @@
-"""The one-sweep float encoder (TRICO_FPC32_SWEEPS=1; k_fpc32_sweep1 / k_fpc32_pscan_* / k_fpc32_fixup and the record path of
-k_fpc32_gather in k_fpc32_encode.hip) against the oracle: the archives have to be the reference's bytes, through the whole
-parity suite and on streams built to stress the deferred values - a stream whose every DFCM class is new (a record per value at
-the start of every segment), exact hits that are deferred (residual length 0: four unused bytes in a row), one- and two-component
-streams, and streams shorter than a segment.  The switch is read once per process, hence the child process."""
+"""The one-sweep float encoder (k_fpc32_sweep.hip: k_fpc32_sweep / k_fpc32_pscan_* / k_fpc32_fixup / k_fpc32_gather; the library's
+choice on a device that passes the lane-order test) against the oracle: the archives have to be the reference's bytes on streams built
+to stress the deferred values - a stream whose every DFCM class is new (a record per value at the start of every segment), exact hits
+that are deferred (residual length 0: four unused bytes in a row), the coder's "never written" mark as a value and as a stride (the
+stream is then coded again by the ballot coder: trico_hip_encode_stats), one- and two-component streams, streams shorter than a
+segment - and, in the second half of the file, with its write-side guard provoked (tests/_build/libtrico_testhooks.so)."""
 import os
 import subprocess
 import sys
@@ -19,7 +20,7 @@ sys.path.insert(0, %(root)r)
 sys.path.insert(0, %(root)r + "/tests")
 from trico_amd import api
 from oracle import oracle as O
-assert api.lib().trico_hip_fpc32_code_sweep() == 2
+assert api.lib().trico_hip_fpc32_code_sweep() == %(mode)d
 rng = np.random.default_rng(7)
 def bits(u):
     return np.ascontiguousarray(u.astype(np.uint32)).view(np.float32)
@@ -33,7 +34,7 @@ cases.append(("vertices", bits(v), 120000))
 # constant stream, and a ramp (one class, stride hits)
 cases.append(("vertices", bits(np.full(90000 * 3, 0x3f800000, dtype=np.int64)), 90000))
 cases.append(("vertex_normals", (np.arange(200001 * 3, dtype=np.float32) * 0.25), 200001))
-# the sweep's "unknown" sentinel (0x7fc0dead, k_fpc32_encode.hip: SENT) as a payload: as a value (FCM entries), as a stride (DFCM entries),
+# the sweep's "never written" mark (0x7fc0dead, fpc32_common.hpp: SENT) as a payload: as a value (FCM entries), as a stride (DFCM entries),
 # alone and mixed with values of other classes, so that a class whose entry legitimately holds the sentinel is looked up again
 SENT = 0x7fc0dead
 m = 150000 * 3
@@ -86,17 +87,95 @@ print("ONESWEEP OK", len(x))
 
 @pytest.mark.parametrize("sweeps", ["1", "2"])
 def test_one_sweep_encoder_writes_the_reference_bytes(sweeps):
-    """sweeps = 2: the same streams through the default encoder (exchange code sweep with index sweep)."""
+    """sweeps = 2: the same streams through round 3's encoder (index sweep + code sweep with the exchange)."""
     env = dict(os.environ)
     env["TRICO_FPC32_SWEEPS"] = sweeps
-    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "mode": 3 if sweeps == "1" else 2}], env=env, capture_output=True,
+                         text=True, timeout=600)
     assert out.returncode == 0 and "ONESWEEP OK" in out.stdout, out.stdout + out.stderr
 
 
-def test_one_sweep_encoder_through_the_parity_suite():
-    """tests/test_gpu_parity.py in a child process with the one-sweep encoder switched on."""
+GUARD_CHILD = r"""
+import ctypes
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r + "/tests")
+from trico_amd import api
+from oracle import oracle as O
+from streams import mesh_streams
+L = api.lib()
+L.trico_hip_encode_stats.argtypes = [ctypes.POINTER(ctypes.c_uint32)]
+def stats():
+    out = (ctypes.c_uint32 * 2)()
+    L.trico_hip_encode_stats(out)
+    return list(out)
+assert L.trico_hip_fpc32_code_sweep() == 3
+before = stats()
+for kind, W, H in (("walk", 300, 77), ("grid", 256, 128), ("walk", 1000, 1000)):
+    s = mesh_streams(kind, W, H)
+    a = api.Archive.open_for_writing(1 << 16)
+    o = O.OracleArchive()
+    for name, data, count in s:
+        assert a.write(name, data, count) == 1, api.last_error()
+        o.write(name, data, count)
+    assert a.tobytes() == o.tobytes(), (kind, W, H)
+    a.close(); o.close()
+after = stats()
+print("GUARD", after[0] - before[0], after[1] - before[1], L.trico_hip_fpc32_code_sweep())
+"""
+
+
+def _guard_child(env_add):
     env = dict(os.environ)
-    env["TRICO_FPC32_SWEEPS"] = "1"
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q"], env=env,
-                         capture_output=True, text=True, timeout=900, cwd=ROOT)
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    env["TRICO_AMD_LIB"] = os.path.join(ROOT, "tests", "_build", "libtrico_testhooks.so")
+    env.update(env_add)
+    out = subprocess.run([sys.executable, "-c", GUARD_CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "GUARD" in out.stdout, out.stdout + out.stderr
+    return [int(x) for x in out.stdout.split("GUARD")[1].split()[:3]]
+
+
+def test_write_side_guard_catches_an_exchange_out_of_lane_order():
+    """TRICO_HIP_ENCODE_SABOTAGE=1 (test-hooks library only) hands every run start in the upper half of a wave something else than
+    its predecessor left, as an LDS unit that does not apply an exchange in lane order would.  The sampled steps of the one-sweep
+    coder notice (k_fpc32_sweep.hip: resolve_guarded), the stream is coded again by the ballot coder, the device is not asked again
+    in this process - and every archive is still the reference's."""
+    order, sentinel, mode = _guard_child({"TRICO_HIP_ENCODE_SABOTAGE": "1"})
+    assert order >= 1 and mode == 0, (order, sentinel, mode)
+
+
+def test_write_side_guard_is_quiet_without_sabotage():
+    order, sentinel, mode = _guard_child({})
+    assert order == 0 and sentinel == 0 and mode == 3, (order, sentinel, mode)
+
+
+def test_product_library_has_no_encode_sabotage_switch():
+    env = dict(os.environ)
+    env["TRICO_HIP_ENCODE_SABOTAGE"] = "1"
+    out = subprocess.run([sys.executable, "-c", GUARD_CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "GUARD 0 0 3" in out.stdout, out.stdout + out.stderr
+
+
+def test_sentinel_payloads_are_coded_again_and_counted():
+    """A stream that stores the coder's "never written" mark (as a value: FCM table; as a stride: DFCM table) raises FLAG_SENTINEL;
+    the ballot coder takes over for that stream only and the bytes are the reference's (the CHILD's archive compare covers it; here:
+    the counter moves and the device stays trusted)."""
+    child = r"""
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from trico_amd import api
+from oracle import oracle as O
+L = api.lib()
+L.trico_hip_encode_stats.argtypes = [ctypes.POINTER(ctypes.c_uint32)]
+out = (ctypes.c_uint32 * 2)()
+v = np.full(150000 * 3, 0x7fc0dead, dtype=np.uint32).view(np.float32)
+a = api.Archive.open_for_writing(1 << 16); o = O.OracleArchive()
+assert a.write("vertices", v, 150000) == 1, api.last_error()
+o.write("vertices", v, 150000)
+assert a.tobytes() == o.tobytes()
+L.trico_hip_encode_stats(out)
+print("SENT", out[0], out[1], L.trico_hip_fpc32_code_sweep())
+"""
+    out = subprocess.run([sys.executable, "-c", child % {"root": ROOT}], env=dict(os.environ), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "SENT 0 1 3" in out.stdout, out.stdout + out.stderr

@@ -43,7 +43,7 @@ def run_child(sabotage):
     env = dict(os.environ)
     env["TRICO_HIP_DECODE_SABOTAGE"] = str(sabotage)
     # the switch exists only in the test build of the library (trico_amd/build.py); the product library ignores the variable
-    env["TRICO_AMD_LIB"] = os.path.join(ROOT, "trico_amd", "lib", "libtrico_testhooks.so")
+    env["TRICO_AMD_LIB"] = os.path.join(ROOT, "tests", "_build", "libtrico_testhooks.so")
     out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     line = [l for l in out.stdout.splitlines() if l.startswith("REPEATS")][0]

@@ -57,7 +57,7 @@ HIP_SYMBOLS = [
     "trico_hip_device_free", "trico_hip_copy", "trico_hip_fpc_encode", "trico_hip_fpc_decode",
     "trico_hip_int_encode", "trico_hip_int_decode", "trico_hip_fetch_payload", "trico_hip_fetch_payloads", "trico_hip_payload_device_pointer",
     "trico_hip_open_archive_for_writing_device", "trico_hip_profile_enable", "trico_hip_profile_reset",
-    "trico_hip_profile_ms", "trico_hip_last_stats", "trico_hip_fpc32_code_sweep",
+    "trico_hip_profile_ms", "trico_hip_last_stats", "trico_hip_encode_stats", "trico_hip_fpc32_code_sweep",
     "trico_hip_decode_jobs", "trico_hip_decode_jobs_reserve", "trico_hip_list_streams", "trico_hip_read_archives",
     "trico_hip_walk_frames", "trico_hip_release_workspaces",
 ]
@@ -163,6 +163,8 @@ def lib():
     L.trico_hip_payload_device_pointer.restype = vp
     L.trico_hip_last_stats.argtypes = [ctypes.POINTER(u32)]
     L.trico_hip_last_stats.restype = None
+    L.trico_hip_encode_stats.argtypes = [ctypes.POINTER(u32)]
+    L.trico_hip_encode_stats.restype = None
     L.trico_hip_fpc32_code_sweep.argtypes = []
     L.trico_hip_fpc32_code_sweep.restype = ctypes.c_int
     L.trico_hip_profile_enable.argtypes = [ci]

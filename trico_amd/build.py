@@ -5,7 +5,10 @@
 
 Outputs (git-ignored, but they travel to the GPU box with the gpurun snapshot):
     trico_amd/lib/libtrico.so            host C container + HIP kernels + C-ABI shim
+    trico_amd/lib/libtrico.a             the same objects as a static library (the reference's default flavour, TRICO_SHARED=no)
     trico_amd/lib/libtrico_meshgen.so    synthetic mesh generators (tests / bench only)
+Only on request (build(test_hooks=True), what the test suite and __graft_entry__.build() ask for), outside the package:
+    tests/_build/libtrico_testhooks.so   the same library + the sabotage switches and the fake RCCL transport of the tests
 """
 import os
 import subprocess
@@ -27,8 +30,10 @@ HIP_SRC = sorted(f for f in os.listdir(os.path.join(CSRC, "hip")) if f.endswith(
 HIP_HDR = sorted(f for f in os.listdir(os.path.join(CSRC, "hip")) if f.endswith(".hpp"))
 
 LIBTRICO = os.path.join(LIBDIR, "libtrico.so")
-LIBTRICO_HOOKS = os.path.join(LIBDIR, "libtrico_testhooks.so")    # same library + the decode sabotage switch (tests only)
-HOOKED = ("shim.hip", "dist.hip")                                             # sources that look at TRICO_HIP_TEST_HOOKS
+LIBTRICO_A = os.path.join(LIBDIR, "libtrico.a")
+HOOKDIR = os.path.join(ROOT, "tests", "_build")
+LIBTRICO_HOOKS = os.path.join(HOOKDIR, "libtrico_testhooks.so")   # same library + the sabotage switches (tests only; never in lib/)
+HOOKED = ("shim.hip", "dist.hip", "k_fpc32_sweep.hip")                        # sources that look at TRICO_HIP_TEST_HOOKS
 LIBMESHGEN = os.path.join(LIBDIR, "libtrico_meshgen.so")
 LIBIO = os.path.join(LIBDIR, "libtrico_io.so")
 BINDIR = os.path.join(HERE, "bin")
@@ -47,7 +52,7 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, test_hooks=False):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     headers = [os.path.join(INCLUDE, "trico", h) for h in ("trico.h", "trico_hip.h")]
@@ -69,7 +74,7 @@ def build(force=False, verbose=True):
                   "-Wall", "-Wno-unused-function", "-I" + INCLUDE, "-I" + os.path.join(CSRC, "hip"),
                   "-c", src, "-o", obj])
         objs.append(obj)
-        if f in HOOKED:
+        if test_hooks and f in HOOKED:
             hobj = os.path.join(OBJDIR, f + ".hooks.o")
             if force or _stale(hobj, [src] + headers):
                 _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DTRICO_HIP_TEST_HOOKS",
@@ -78,9 +83,18 @@ def build(force=False, verbose=True):
             hook_objs[obj] = hobj
     if force or _stale(LIBTRICO, objs):
         _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIBTRICO] + objs + ["-ldl"])
-    hobjs = [hook_objs.get(o, o) for o in objs]
-    if force or _stale(LIBTRICO_HOOKS, hobjs):
-        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIBTRICO_HOOKS] + hobjs + ["-ldl"])
+    if force or _stale(LIBTRICO_A, objs):
+        if os.path.exists(LIBTRICO_A):
+            os.remove(LIBTRICO_A)
+        _run(["ar", "rcs", LIBTRICO_A] + objs)
+    if test_hooks:
+        os.makedirs(HOOKDIR, exist_ok=True)
+        hobjs = [hook_objs.get(o, o) for o in objs]
+        if force or _stale(LIBTRICO_HOOKS, hobjs):
+            _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIBTRICO_HOOKS] + hobjs + ["-ldl"])
+    stale_hooks = os.path.join(LIBDIR, "libtrico_testhooks.so")       # where rounds 2 and 3 put it
+    if os.path.exists(stale_hooks):
+        os.remove(stale_hooks)
     mg = os.path.join(CSRC, "tools", "meshgen.c")
     if force or _stale(LIBMESHGEN, [mg]):
         _run([CC, "-O2", "-std=c11", "-fPIC", "-fvisibility=hidden", "-shared", mg, "-o", LIBMESHGEN])
@@ -103,4 +117,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, test_hooks="--test-hooks" in sys.argv)

@@ -105,16 +105,19 @@ int launch_lz4_encode_serial(const uint8_t* d_planes, size_t plane_stride, uint3
 int launch_lz4_decode_serial(const uint8_t* const d_payloads[8], const uint32_t sizes[8], int nplanes,
                              uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, uint32_t* d_status);
 
-// throughput float encoder (k_fpc32_encode.hip): segmented 2-sweep scheme, see the file header
+// throughput float encoder: the one-sweep coder (k_fpc32_sweep.hip) and the two-sweep coder with ballots (k_fpc32_encode.hip)
 size_t fpc32_encode_workspace(uint32_t n, int arity);
-// d_sizes: 4 words - payload bytes of components 0..2, then a flag: non-zero if the tagged-table code sweep found the LDS unit
-// applying an atomic out of lane order (the result is then not to be used: fpc32_distrust_atomic() and encode again).
-// allow_atomic = false: always the ballot kernel (what the decoders' self-check uses).
+// d_sizes: 6 words - payload bytes of components 0..2, then the flags their waves raised (FPC32_FLAG_*): a non-zero flag means
+// the payloads are not to be used - code the stream again with FPC32_CODER_BALLOT, which raises none.
+// FPC32_CODER_BALLOT: always the two-sweep coder with ballots (what the decoders' self-check uses).
+constexpr int FPC32_CODER_AUTO = 0, FPC32_CODER_BALLOT = 1;
+constexpr uint32_t FPC32_FLAG_ORDER = 1u;      // a sampled step found the LDS exchange out of lane order (-> fpc32_distrust_lane_order())
+constexpr uint32_t FPC32_FLAG_SENTINEL = 2u;   // a payload equal to the one-sweep coder's "never written" mark was written to a table
 int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
-                        uint8_t* d_ws, size_t ws_bytes, bool allow_atomic = true);
-void fpc32_distrust_atomic();
-bool lds_lane_order_ok();            // the device applies the lanes of one LDS exchange / or-rtn in lane order (tested once per device)
-int fpc32_code_sweep_mode();          // 0 ballots, 1 tagged entries, 2 lane-ordered exchange (runs the device's order test once)
+                        uint8_t* d_ws, size_t ws_bytes, int coder = FPC32_CODER_AUTO);
+void fpc32_distrust_lane_order();    // this device's exchange is not used again in this process
+bool lds_lane_order_ok();            // the device applies the lanes of one LDS exchange in lane order (tested once per device)
+int fpc32_code_sweep_mode();          // what FPC32_CODER_AUTO runs: 0 two sweeps + ballots, 2 two sweeps + exchange, 3 one sweep + exchange
 int launch_fpc32_gather(uint32_t n, int arity, int c, const uint8_t* d_ws, uint8_t* d_dst);
 int launch_fpc32_gather_all(uint32_t n, int arity, const uint8_t* d_ws, uint8_t* const d_dst[3]);
 int launch_fpc32_compare(uint32_t n, int arity, const uint8_t* d_ws, const uint32_t* d_sizes, const uint8_t* const d_pay[3],

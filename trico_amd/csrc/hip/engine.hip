@@ -44,7 +44,7 @@ struct Engine
 
 Engine E;
 
-constexpr uint32_t STATUS_WORDS = 16;          // per job: [0] status, [4..6] payload sizes of the self-check's re-encode
+constexpr uint32_t STATUS_WORDS = 16;          // per job: [0] status, [4..9] payload sizes + flags of the self-check's re-encode
 
 bool dedicated_reserve(uint8_t*& p, size_t& cap, size_t bytes)
   {

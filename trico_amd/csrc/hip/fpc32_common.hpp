@@ -1,0 +1,130 @@
+// fpc32_common.hpp — what the translation units of the 32-bit float encoder share (gfx950, wave64): table geometry, the workspace
+// plan, the record of a deferred value, a few wave primitives.  Internal; nothing here crosses the C-ABI.
+#pragma once
+
+#include "common.hpp"
+#include <stdlib.h>
+
+namespace trico {
+namespace fpc32 {
+
+constexpr int TAB = 1040;      // 16 FCM entries followed by 1024 DFCM entries (fpsc.c:96-97 with the API's exponents 4 and 10)
+constexpr int ROW = 1040;      // words per (segment, component) row in the global tables
+constexpr int CH = 32;         // segments per chunk in the cross-segment scans
+constexpr uint32_t RCAP = 1040;   // deferred values per (segment, component): a class is met for the first time at most once
+constexpr uint32_t RECW = 8;      // words per record (two 16-byte stores)
+constexpr uint32_t GUARD_WGS = 16;          // workgroups of the sweep that code the beginning of a sampled segment again (write-side guard)
+constexpr uint32_t GUARD_SLOT = 64 * 280 + 512;   // bytes such a workgroup can produce per component (k_fpc32_sweep.hip: GUARD_CAP)
+
+// A table entry nobody has written in this segment.  A payload that equals it cannot be told from "never written", so a wave that
+// WRITES this value raises the collision flag and the host codes the stream again with the two-sweep coder (k_fpc32_encode.hip),
+// which has no sentinel: 2^-32 per DFCM write on random bits, a quiet NaN nobody stores for the FCM table.
+constexpr uint32_t SENT = 0x7fc0dead;
+
+// what a wave of the one-sweep coder can raise; the flags travel in the upper half of its record count (Plan::off_nrec) and reach
+// the host with the sizes (k_fpc32_offsets)
+constexpr uint32_t FLAG_ORDER = FPC32_FLAG_ORDER, FLAG_SENTINEL = FPC32_FLAG_SENTINEL;
+
+// Record of a deferred value (k_fpc32_sweep -> k_fpc32_fixup -> k_fpc32_gather):
+//   w0 slot offset of the value's four reserved bytes      w1 dh | gi << 8 | ft1 << 12 | ft2 << 13 | k1 << 16 | k2 << 20
+//   w2 the value   w3 its predecessor   w4 the prediction that IS known (one open class), else 0
+//   w6 residual, w7 length | code << 4  (written by the fix-up)
+// dh = distance from the group's header to the four bytes (3..31), gi = index in the group, k1 / k2 = FCM / DFCM class.
+
+struct Plan
+  {
+  uint32_t L, S, segcap, nch;
+  size_t rows, slot_stride;
+  size_t off_summ, off_inc, off_chmax, off_nrec, off_recs, off_segbytes, off_rawbytes, off_segoff, off_gslots, off_grecs, off_gmeta, off_slots, total;
+  };
+
+inline Plan make_plan(uint32_t n, int arity)
+  {
+  static int waves = 0;
+  if (!waves)
+    {
+    const char* e = getenv("TRICO_FPC32_WAVES");      // tuning knob: waves per sweep (30 per CU x 256 CUs)
+    waves = e ? atoi(e) : 7680;
+    if (waves < 3) waves = 3;
+    }
+  Plan p;
+  // (the guard's workgroups take part in the sweep's launch: leave them room, so that the whole grid is resident at once)
+  uint32_t target = (uint32_t)waves / (uint32_t)arity;
+  if (target > 8u * GUARD_WGS)
+    target -= GUARD_WGS;
+  uint64_t L = ((uint64_t)n + target - 1) / target;
+  L = (L + 127) / 128 * 128;                    // multiple of 128: two sub-ranges of whole steps in the index sweep
+  if (L < 1024) L = 1024;
+  p.L = (uint32_t)L;
+  p.S = (uint32_t)(((uint64_t)n + L - 1) / L);
+  if (p.S == 0) p.S = 1;
+  p.segcap = (uint32_t)align_up(5 + 4 * (size_t)L + 3 * ((size_t)L / 8) + 16 + 280, 256);
+  p.nch = (p.S + CH - 1) / CH;
+  p.rows = (size_t)p.S * arity;
+  p.slot_stride = (size_t)p.S * p.segcap;
+  size_t o = 0;
+  p.off_summ = o;      o += align_up(p.rows * ROW * 4, 256);
+  p.off_inc = o;       o += align_up(p.rows * ROW * 4, 256);
+  p.off_chmax = o;     o += align_up((size_t)p.nch * arity * TAB * 4, 256);
+  p.off_nrec = o;      o += align_up(p.rows * 4, 256);
+  p.off_recs = o;      o += align_up(p.rows * RCAP * RECW * 4, 256);
+  p.off_segbytes = o;  o += align_up(p.rows * 4, 256);
+  p.off_rawbytes = o;  o += align_up(p.rows * 4, 256);
+  p.off_segoff = o;    o += align_up(p.rows * 4, 256);
+  p.off_gslots = o;    o += align_up((size_t)GUARD_WGS * arity * GUARD_SLOT, 256);
+  p.off_grecs = o;     o += align_up((size_t)GUARD_WGS * arity * RCAP * RECW * 4, 256);
+  p.off_gmeta = o;     o += align_up((size_t)GUARD_WGS * arity * 16, 256);
+  p.off_slots = o;     o += p.slot_stride * arity;
+  p.total = o + 256;
+  return p;
+  }
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+__device__ __forceinline__ uint32_t dpp_shr1(uint32_t carry, uint32_t v)
+  {
+  // lane l <- lane l-1, lane 0 <- carry   (DPP wave_shr:1)
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)v, 0x138, 0xf, 0xf, false);
+  }
+
+__device__ __forceinline__ uint32_t dpp_shl1(uint32_t carry, uint32_t v)
+  {
+  // lane l <- lane l+1, lane 63 <- carry   (DPP wave_shl:1)
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)v, 0x130, 0xf, 0xf, false);
+  }
+
+// lane l <- lane l-1 of `cur`, lane 0 <- lane 63 of `prev` (the register the previous step kept): a shift across steps without
+// a trip through the scalar registers (wave_ror:1 of prev, then wave_shr:1 of cur on top; lane 0 has no source and keeps it)
+__device__ __forceinline__ uint32_t shr1_across(uint32_t prev, uint32_t cur)
+  {
+  const int r = __builtin_amdgcn_mov_dpp((int)prev, 0x13C, 0xf, 0xf, false);        // (every lane has a source: no old value)
+  return (uint32_t)__builtin_amdgcn_update_dpp(r, (int)cur, 0x138, 0xf, 0xf, false);
+  }
+
+// inclusive prefix sum over the wave (DPP: four steps inside the rows of 16 lanes, two row broadcasts)
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x)
+  {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);     // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);     // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);     // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);     // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, true);     // row_bcast:15 into rows 1 and 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, true);     // row_bcast:31 into rows 2 and 3
+  return x;
+  }
+
+__device__ __forceinline__ uint32_t popc_below(uint64_t mask)
+  {
+  // number of set bits of `mask` strictly below this lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+  }
+#endif
+
+// k_fpc32_sweep.hip: the one-sweep coder.  launch_fpc32_sweep queues sweep, cross-segment scan and fix-up (sizes of the segments are
+// final afterwards: Plan::off_segbytes); launch_fpc32_gather_rec moves the slots of components [c0, c0 + count) to dst[0..count).
+int launch_fpc32_sweep(const uint32_t* d_src, uint32_t n, int arity, const Plan& p, uint8_t* d_ws);
+int launch_fpc32_gather_rec(const Plan& p, int arity, int c0, int count, const uint8_t* d_ws, uint8_t* const d_dst[3]);
+
+} // namespace fpc32
+} // namespace trico

@@ -1,0 +1,1275 @@
+// k_fpc32_sweep.hip — the throughput encoder for 32-bit floating-point streams: ONE sweep over the input (gfx950, wave64).
+//
+// Replaces, fused: trico_transpose_xyz/uv_aos_to_soa (transpose_aos_to_soa.c:8-16, 48-56) and trico_compress(..., 4, 10)
+// (fpsc.c:86-210) for every component of a vec3 / vec2 / scalar stream.
+//
+// Why this can be parallel and still bit-exact: the FCM hash of value i is a pure function of v[i-1]
+// (top 4 bits) and the DFCM hash a pure function of the strides of v[i-1] and v[i-2], so every value belongs to a *class* known
+// from the input alone, and the reference's table read for value i (fpsc.c:133-143) returns the payload (value / stride) of the
+// latest earlier value of the same class, or 0.
+//
+// Structure: each component stream is cut into S contiguous segments of L values; one wave owns one (segment, component) and walks
+// it 64 values per step; the component waves of a segment share a workgroup (they read the same cache lines).
+//   k_fpc32_sweep   codes every segment WITHOUT knowing the tables it comes in with.  Inside a run of equal classes the
+//                   predecessor is the previous lane (DPP; runs span steps through the registers the previous step left).  The
+//                   lanes where a run starts or ends do ONE ds_wrxchg_rtn_b32 on the wave's payload table per predictor: the LDS
+//                   unit applies the lanes of an instruction in lane order, which is the reference's read-then-write, value after
+//                   value (tested on the device before use and checked again in sampled steps against ballots, see guard_*).
+//                   A run start that gets the sentinel back has met the entry the segment came in with: its value is *deferred* -
+//                   four zero bytes, code 0 and a record - and nothing else depends on it (a prediction only decides its own
+//                   value's residual).  Steps whose 64 values all continue their runs with an exact prediction - the x / y of a
+//                   grid, the flat parts of a scan - leave a constant 24- or 88-byte pattern with one LDS store and skip the
+//                   byte layout altogether.  At its end the wave publishes its tables (= what the segment leaves behind).
+//   k_fpc32_pscan_* incoming payload of every (segment, class) = the entry of the nearest earlier segment that wrote the class.
+//   k_fpc32_fixup   per record: residual, length and code from the incoming entry; the segment's final size.
+//   k_fpc32_offsets (k_fpc32_encode.hip) exclusive scan of the segment sizes.
+//   k_fpc32_gather  slot -> final position: a plain copy for segments without records, else a pass through LDS that drops the
+//                   unused bytes of the reserved fields and ORs residuals and codes in.
+// HBM traffic: the input once (+ what the component waves re-fetch when they drift apart), the payload three times (slot write,
+// gather read + write), tables and records.  No MFMA: integer bit-twiddling; algorithmic bytes per value = 4 + its payload share.
+#include "fpc32_common.hpp"
+#include <atomic>
+
+namespace trico {
+namespace fpc32 {
+
+namespace {
+
+constexpr int PF = 8;                             // steps (of 64 values) whose loads are kept in flight per wave
+constexpr int STAGE_LIVE = 544;                   // < 256 unflushed + <= 280 of the step, rounded
+constexpr int STAGE = STAGE_LIVE + 256;           // + 4 dump bytes per lane
+constexpr int LDSW = 1248;                        // per-wave LDS words: TAB + STAGE / 4 = 1240, rounded so that every wave's table starts
+                                                  // at a multiple of 64 bytes (4,992 B: 10 workgroups of 3 waves per CU)
+static_assert(LDSW >= TAB + STAGE / 4 && (LDSW * 4) % 64 == 0, "LDS layout of a wave");
+
+constexpr uint32_t GUARD_STEPS = 64;              // steps of a sampled segment the guard codes again
+constexpr uint32_t GUARD_CAP = GUARD_SLOT;        // bytes they can produce (a step: 24 header + 256 residual bytes), rounded
+
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) volatile uint8_t lds_vu8;
+
+struct LaneK                                      // per-lane constants
+  {
+  uint32_t lane, lane4;
+  uint32_t sh3, grp3;
+  uint32_t pat5;                                  // this lane's dword of the 88-byte pattern of a step of 64 exact DFCM hits
+  bool lead;
+  };
+
+struct Sweep                                      // running state of a wave
+  {
+  uint32_t vp, sp, s1p, a1p, a2p;                 // per lane, of the previous step: value, stride, stride of the lane below, table addresses
+  uint32_t pend1, pend2;                          // 1: the table writes of the previous step's last value are still pending
+  uint32_t posl, flushed;                         // bytes staged in LDS / bytes already in the slot
+  uint32_t fl_nb, fl_off;                         // flush in flight (1, else 0): a 256-byte block and its offset in the slot
+  uint32_t fw0, ft;                               // ... per lane: its word of the block and of what moves to the front
+  uint32_t nrec;                                  // records written so far
+  uint32_t flags;                                 // FLAG_* raised by this wave
+  };
+
+constexpr uint32_t DUMP = STAGE_LIVE + 1;          // a lane's four dump bytes: stage + DUMP - 1 + 4 * lane
+
+// second half of a flush (see flush_begin): the word read from the staging area a step ago goes to the slot, the unflushed rest
+// moves to the front.  Must run before the next byte is staged.
+__device__ __forceinline__ void flush_end(Sweep& sw, uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase, const LaneK& lk)
+  {
+  if (sw.fl_nb)
+    {
+    // (streaming stores: the slot is read again only by the gather, and the lines should not push the input out of the L2)
+    uint32_t off = lk.lane4;
+    asm volatile("" : "+v"(off));                  // (keeps the 32-bit offset in this block: scalar base + vector offset addressing)
+    __builtin_nontemporal_store(sw.fw0, (uint32_t*)(gbase + sw.fl_off + off));
+    ((uint32_t*)stage)[lk.lane] = sw.ft;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    sw.fl_nb = 0u;
+    }
+  }
+
+// first half of a flush: a full 256-byte block goes to the slot as aligned dwords, the rest moves to the front of the staging area.
+// Only the LDS reads are issued here; their data is used by flush_end() in the next step, right before its first byte is staged
+// (LDS operations of a wave execute in order), so the wave never waits for the round trip.  Two full blocks at once (a step of
+// more than 256 bytes on top of nearly 256) are rare: the first one leaves on the spot.
+__device__ __forceinline__ void flush_begin(Sweep& sw, const uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase, const LaneK& lk)
+  {
+  if (sw.posl >= 256u)
+    {
+    const uint32_t* stw = (const uint32_t*)stage;
+    uint32_t first = 0;
+    if (sw.posl >= 512u)
+      {
+      *(uint32_t*)(gbase + sw.flushed + lk.lane4) = stw[lk.lane];
+      sw.flushed += 256u;
+      first = 64u;
+      }
+    sw.fw0 = stw[first + lk.lane];
+    sw.ft = stw[first + 64u + lk.lane];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    sw.fl_nb = 1u;
+    sw.fl_off = sw.flushed;
+    sw.flushed += 256u;
+    sw.posl &= 255u;
+    }
+  }
+
+// ---- run starts ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ lds_u32* lds_at(uint32_t address) { return (lds_u32*)(uintptr_t)address; }
+
+// What the reference's table read hands a lane of `part` (the lanes where a run starts or ends) for the entry at LDS address `ad`
+// (class k, B bits): the payload of the nearest lower lane of `part` with the same class, else what the table holds.  Also tells
+// the lane whether it is the highest of its class (its payload is the table's afterwards).  The lanes of my class: one ballot per
+// class bit.  This is how the guard workgroups resolve run starts - no LDS exchange, no assumption about the order of anything.
+template <int B>
+__device__ __forceinline__ uint32_t ballot_lookup(uint32_t ad, uint32_t k, bool part, uint32_t pay, uint32_t lane, bool& owner)
+  {
+  const uint32_t tv = part ? *lds_at(ad) : 0u;
+  uint64_t same = __ballot(part);
+#pragma unroll 1
+  for (int b = 0; b < B; ++b)
+    {
+    const bool bit = (k >> b) & 1u;
+    const uint64_t m = __ballot(bit);
+    same &= bit ? m : ~m;
+    }
+  const uint64_t lo = same & ((1ull << lane) - 1ull);
+  const uint32_t q = (uint32_t)__builtin_amdgcn_ds_bpermute((63 - __builtin_clzll(lo | 1ull)) << 2, (int)pay);
+  owner = part && (same >> lane) == 1ull;
+  return lo ? q : tv;
+  }
+
+// The reference codes a value by reading the entry of its class and then writing its own payload there (fpsc.c:133-143), value
+// after value; an exchange is exactly that pair, and the LDS unit of gfx950 applies the active lanes of one ds_wrxchg_rtn_b32 in
+// increasing lane order (tools/ubench/lds_xchg_order.hip: 131 M instructions, 1 to 1024 keys, random exec masks, four waves per
+// workgroup on the same LDS).  Only the lanes where a run of equal classes starts or ends take part: a start takes what comes back;
+// a start that is not an end leaves its payload there for the moment it takes the end lane of its run - a higher lane of the same
+// instruction - to replace it.  The table starts as SENT everywhere: a start that gets SENT back has met what the segment came in
+// with (ft*).  The order is not documented, hence: the device test before first use (k_fpc32_xchg_selftest), and in every encode a
+// few workgroups code the beginning of sampled segments again with BALLOT = true - ballots instead of the exchange - for the
+// fix-up kernel to compare (FLAG_ORDER -> the host codes the stream again with the ballot coder).
+// a1 / a2 are the LDS addresses of the values' table entries.
+template <bool FULL, bool D1, bool D2, bool BALLOT, bool HOOK>
+__device__ __forceinline__ void resolve_h(uint32_t a1, uint32_t a2, bool st1, bool st2, bool act, uint32_t v, uint32_t s,
+                                          uint32_t& p1, uint32_t& p2, bool& ft1, bool& ft2, uint32_t t1abs,
+                                          Sweep& sw, const LaneK& lk, uint32_t sabotage)
+  {
+  // pending writes of the previous step's last value (its lane 63 still holds address and payload)
+  if (lk.lane == 63u)
+    {
+    if (D1 && sw.pend1) *lds_at(sw.a1p) = sw.vp;
+    if (D2 && sw.pend2) *lds_at(sw.a2p) = sw.sp;
+    }
+  uint64_t sent = 0;
+  if (D1 && sw.pend1) sent |= __ballot(lk.lane == 63u && sw.vp == SENT);
+  if (D2 && sw.pend2) sent |= __ballot(lk.lane == 63u && sw.sp == SENT);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const bool en1 = D1 && (FULL || act) && a1 != dpp_shl1(0xffffffffu, a1);     // last lane of a run (lane 63 always)
+  const bool en2 = D2 && (FULL || act) && a2 != dpp_shl1(0xffffffffu, a2);
+  const bool part1 = D1 && (st1 || en1), part2 = D2 && (st2 || en2);
+  uint32_t old1 = 0, old2 = 0;
+  if (BALLOT)
+    {
+    bool own1 = false, own2 = false;
+    if (D1) old1 = ballot_lookup<4>(a1, (a1 >> 2) & 15u, part1, v, lk.lane, own1);
+    if (D2) old2 = ballot_lookup<10>(a2, (a2 - (t1abs + 64u)) >> 2, part2, s, lk.lane, own2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (own1) *lds_at(a1) = v;
+    if (own2) *lds_at(a2) = s;
+    }
+  else
+    {
+    if (part1)
+      old1 = __hip_atomic_exchange(lds_at(a1), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (part2)
+      old2 = __hip_atomic_exchange(lds_at(a2), s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (HOOK && !BALLOT && sabotage)
+    {
+    // test hook (libtrico_testhooks.so only): pretend the LDS unit served the lanes in another order - a start in the upper half
+    // of the wave gets something else than its predecessor left
+    if (D1 && st1 && lk.lane >= 32u) old1 ^= 0x100u;
+    if (D2 && st2 && lk.lane >= 32u) old2 ^= 0x100u;
+    }
+  if (D1) { p1 = st1 ? old1 : p1; ft1 = st1 && old1 == SENT; sent |= __ballot(v == SENT); }
+  if (D2) { p2 = st2 ? old2 : p2; ft2 = st2 && old2 == SENT; sent |= __ballot(s == SENT); }
+  if (sent)
+    sw.flags |= FLAG_SENTINEL;
+  if (D1) sw.pend1 = 0u;
+  if (D2) sw.pend2 = 0u;
+  }
+
+struct RecSink { uint32_t* recs; };               // this wave's record list (RECW words each)
+
+// residual selection, byte layout of the step, bytes into the staging area, records of the deferred values (flush_end must have run)
+template <bool FULL>
+__device__ __forceinline__ void step_tail(uint32_t v, uint32_t a, uint32_t a1, uint32_t a2, uint32_t p1, uint32_t p2, bool ft1, bool ft2,
+                                          bool act, uint32_t i, uint32_t i_end, uint32_t n, uint32_t t1abs, uint32_t sbase, Sweep& sw,
+                                          const LaneK& lk, const RecSink& sink)
+  {
+  // residual selection (fpsc.c:146-189).  With m = leading zero BYTES (m1 in 0..4, m2 in 0..3: a DFCM residual takes at least
+  // one byte): n = 4 - m, the DFCM residual is chosen iff n2 < n1 (n2 >= 1, so this already says n1 > 1), the length is the
+  // smaller n
+  const uint32_t x1 = v ^ p1, x2 = v ^ (a + p2);
+  const uint32_t m1 = (uint32_t)__clz((int)x1) >> 3;
+  const uint32_t m2 = (uint32_t)__clz((int)(x2 | 1u)) >> 3;
+  const bool use2 = m2 > m1;
+  uint32_t len = 4u - max(m1, m2);
+  uint32_t x = use2 ? x2 : x1;
+  uint32_t code = len + (use2 ? 4u : 0u);
+  bool slot = true;
+  if (!FULL)
+    {
+    slot = act || (i_end == n && i < ((n + 7u) & ~7u));      // value or tail padding slot (fpsc.c:196-204)
+    if (!act)
+      {
+      code = slot ? 1u : 0u;
+      len = code;
+      x = 0u;
+      }
+    }
+  const bool hole = ft1 || ft2;
+  const uint64_t hm = __ballot(hole);
+  if (hm)
+    {
+    // four zero bytes and code 0 for now; the fix-up codes the value when the incoming entry is known, the gather drops what the
+    // residual does not need
+    len = hole ? 4u : len;
+    code = hole ? 0u : code;
+    x = hole ? 0u : x;
+    }
+  // byte layout of the step: [hdr g0][residuals 0..7][hdr g1][residuals 8..15]...
+  const uint32_t incl = wave_scan_incl(len);
+  const uint32_t pre = incl - len;
+  uint32_t bc = code << lk.sh3;
+  bc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bc, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+  bc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bc, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+  bc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bc, 0x141, 0xf, 0xf, true);    // row_half_mirror
+  const uint32_t hq = (sbase + sw.posl) + lk.grp3 + pre;     // LDS address of my group's header (if I lead it), my residual starts at hq + 3
+  {
+  // A residual is stored as the 4 big-endian bytes that END at its last byte, most significant first, in this order: the leading
+  // zero bytes of lane l land on bytes owned by lower lanes or on group headers of the same step, all of which are written by a
+  // LATER instruction (proof in DESIGN.md), so there is no per-byte predicate.  volatile keeps four byte stores in program order
+  // (merged into one dword store, lanes would race).
+  const uint32_t re = len ? hq + len : (sbase + DUMP) + lk.lane4;      // residual end - 3
+  lds_vu8* vs = (lds_vu8*)(uintptr_t)re;
+  vs[-1] = (uint8_t)(x >> 24);
+  vs[0] = (uint8_t)(x >> 16);
+  vs[1] = (uint8_t)(x >> 8);
+  vs[2] = (uint8_t)x;
+  }
+  {
+  const bool lead = FULL ? lk.lead : (lk.lead && slot);
+  lds_vu8* hs = (lds_vu8*)(uintptr_t)(lead ? hq : (sbase + DUMP) + lk.lane4);
+  hs[0] = (uint8_t)(bc >> 16);
+  hs[1] = (uint8_t)(bc >> 8);
+  hs[2] = (uint8_t)bc;
+  }
+  if (hm)
+    {
+    // record: where the four bytes are (offset in the slot) and how far behind its group header, the value and its predecessor,
+    // which classes are open, the prediction that is known if only one is open
+    const uint32_t pre_lead = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lk.lane & ~7u) << 2), (int)pre);
+    const uint32_t idx = sw.nrec + popc_below(hm);
+    if (hole)
+      {
+      u32x4 w;
+      w[0] = sw.flushed + (hq - sbase) + 3u;
+      w[1] = (3u + pre - pre_lead) | ((lk.lane & 7u) << 8) | ((uint32_t)ft1 << 12) | ((uint32_t)ft2 << 13) | (((a1 >> 2) & 15u) << 16) |
+             (((a2 - (t1abs + 64u)) >> 2) << 20);
+      w[2] = v;
+      w[3] = a;
+      uint32_t* r = sink.recs + RECW * idx;
+      *(u32x4*)r = w;
+      r[4] = ft1 ? (ft2 ? 0u : p2) : p1;
+      }
+    sw.nrec += (uint32_t)__popcll(hm);
+    }
+  const uint32_t hdr = FULL ? 24u : 3u * ((uint32_t)__popcll(__ballot(slot)) >> 3);
+  sw.posl += hdr + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  }
+
+// resolve + tail, compiled from C++
+template <bool FULL, bool BALLOT, bool HOOK>
+__device__ __forceinline__ void step_general(uint32_t v, uint32_t a, uint32_t s, uint32_t s1, uint32_t a1, uint32_t a2, bool st1, bool st2,
+                                             bool any1, bool any2, bool act, uint32_t i, uint32_t i_end, uint32_t n, uint32_t t1abs,
+                                             uint32_t sbase, Sweep& sw, const LaneK& lk, const RecSink& sink, uint32_t sabotage)
+  {
+  uint32_t p1 = a, p2 = s1;                                  // inside a run: previous value / previous stride
+  bool ft1 = false, ft2 = false;
+  if (any1 && any2)
+    resolve_h<FULL, true, true, BALLOT, HOOK>(a1, a2, st1, st2, act, v, s, p1, p2, ft1, ft2, t1abs, sw, lk, sabotage);
+  else if (any1)
+    {
+    resolve_h<FULL, true, false, BALLOT, HOOK>(a1, a2, st1, st2, act, v, s, p1, p2, ft1, ft2, t1abs, sw, lk, sabotage);
+    sw.pend2 = 1u;
+    }
+  else if (any2)
+    {
+    resolve_h<FULL, false, true, BALLOT, HOOK>(a1, a2, st1, st2, act, v, s, p1, p2, ft1, ft2, t1abs, sw, lk, sabotage);
+    sw.pend1 = 1u;
+    }
+  else
+    sw.pend1 = sw.pend2 = 1u;
+  step_tail<FULL>(v, a, a1, a2, p1, p2, ft1, ft2, act, i, i_end, n, t1abs, sbase, sw, lk, sink);
+  }
+
+// one step of one component, compiled from C++ throughout: 64 values starting at index i0 (FULL: all of them inside the segment
+// and the stream).  The last step of a stream takes this path, the guard workgroups (BALLOT), and every step under TRICO_FPC32_ASM=0.
+template <bool FULL, bool BALLOT, bool HOOK>
+__device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_end, uint32_t n, uint32_t t1abs,
+                                          uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase, Sweep& sw, const LaneK& lk,
+                                          const RecSink& sink, uint32_t sabotage)
+  {
+  const uint32_t i = i0 + lk.lane;
+  const bool act = FULL || i < i_end;
+  // classes (fpsc.c:76-84 with e1 = 4, e2 = 10) as table addresses: FCM from v[i-1], DFCM from the strides of v[i-1] and v[i-2]
+  const uint32_t a = shr1_across(sw.vp, v);                  // v[i-1]
+  const uint32_t s = v - a;                                  // stride of v[i]
+  const uint32_t s1 = shr1_across(sw.sp, s);                 // stride of v[i-1]
+  const uint32_t s2 = shr1_across(sw.s1p, s1);               // stride of v[i-2]
+  uint32_t a1 = ((a >> 26) & 0x3cu) | t1abs;                 // (the table starts at a multiple of 64 bytes)
+  uint32_t a2 = (((((s2 >> 22) & 31u) << 5) ^ (s1 >> 22)) << 2) + (t1abs + 64u);
+  if (!FULL && !act)
+    a1 = a2 = 0xffffffffu;
+  // run starts: my class differs from the class of the value before me (lane 0: the previous step's lane 63)
+  bool st1 = a1 != shr1_across(sw.a1p, a1);
+  bool st2 = a2 != shr1_across(sw.a2p, a2);
+  if (!FULL) { st1 = st1 && act; st2 = st2 && act; }
+  const bool any1 = __ballot(st1) != 0ull, any2 = __ballot(st2) != 0ull;
+  const uint32_t sbase = (uint32_t)(uintptr_t)(lds_u8*)stage;        // LDS address of the staging area (uniform)
+  flush_end(sw, stage, gbase, lk);
+  // Every value continues its runs and every prediction is exact: the 64 values are a constant - eight groups of a zero header
+  // (FCM hit: code 0, no byte), or of header b6 db 6d and eight zero bytes (DFCM hit: code 5, residual byte 0x00; it is the choice
+  // only if the FCM residual needs more than one byte, fpsc.c:146-189).  One LDS store, no byte layout.
+  bool u0 = false, u5 = false;
+  if (FULL && !any1 && !any2)
+    {
+    const uint32_t x1 = v ^ a, x2 = v ^ (a + s1);
+    u0 = __ballot(x1 != 0u) == 0ull;
+    u5 = !u0 && (__ballot(x2 != 0u) | __ballot(x1 < 256u)) == 0ull;
+    }
+  if (u0 || u5)
+    {
+    const uint32_t ad = (sbase + sw.posl) + lk.lane4;
+    if (lk.lane < (u5 ? 22u : 6u))
+      asm volatile("ds_write_b32 %0, %1" :: "v"(ad), "v"(u5 ? lk.pat5 : 0u) : "memory");         // (not dword aligned: gfx950 executes it)
+    sw.posl += u5 ? 88u : 24u;
+    sw.pend1 = sw.pend2 = 1u;
+    }
+  else
+    step_general<FULL, BALLOT, HOOK>(v, a, s, s1, a1, a2, st1, st2, any1, any2, act, i, i_end, n, t1abs, sbase, sw, lk, sink, sabotage);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  flush_begin(sw, stage, gbase, lk);
+  sw.vp = v; sw.sp = s; sw.s1p = s1; sw.a1p = a1; sw.a2p = a2;
+  }
+
+__device__ __forceinline__ LaneK lane_constants(uint32_t lane)
+  {
+  LaneK lk;
+  lk.lane = lane;
+  lk.lane4 = 4u * lane;
+  lk.sh3 = 3u * (lane & 7u);
+  lk.grp3 = 3u * (lane >> 3);
+  lk.lead = (lane & 7u) == 0u;
+  uint32_t w = 0;
+  for (uint32_t b = 0; b < 4u; ++b)
+    {
+    const uint32_t q = (4u * lane + b) % 11u;
+    const uint32_t by = q == 0u ? 0xb6u : q == 1u ? 0xdbu : q == 2u ? 0x6du : 0u;      // eight codes 5 = 0xb6db6d, then eight zero bytes
+    w |= by << (8u * b);
+    }
+  lk.pat5 = w;
+  return lk;
+  }
+
+// ---- the same step, written out ---------------------------------------------------------------------------------------------
+// The sweep is bound by instruction issue - a SIMD takes one vector and one scalar instruction per four cycles, and the step the
+// compiler makes of the C++ above costs ~67 of each per 64 values on the benchmark mesh (SQ counters, profiles/r04_*) - so the
+// full steps run hand-scheduled code: 25 vector instructions up to the
+// verdict "constant step" (+2 for its store), 4 per resolved predictor (the run-end mask is the run-start mask shifted by one lane:
+// scalar), 33 for selection, scan, headers and byte stores.  DPP sources are read at the earliest three instructions after they were
+// written (two wait states, which the assembler does not check); EXEC is all ones on entry and on exit.
+
+// (the compiler takes what an asm statement returns for divergent, scalar registers or not: these tell it otherwise)
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uint32_t)(x >> 32)) << 32) | uni((uint32_t)x); }
+
+// head: classes, run starts, and the constant step.  done = 1: the step is coded (24 or 88 bytes staged, posl advanced).
+__device__ __forceinline__ uint32_t step_head_asm(uint32_t v, const Sweep& sw, uint32_t t1abs, uint32_t posl_abs, const LaneK& lk,
+                                                  uint32_t& a, uint32_t& s, uint32_t& s1, uint32_t& a1, uint32_t& a2,
+                                                  uint64_t& st1, uint64_t& st2, uint32_t& no1, uint32_t& no2, uint32_t& adv)
+  {
+  uint32_t s2, q1, q2, t, u, x1, x2, done;
+  uint64_t nz1, nz2;
+  asm volatile(
+    "s_nop 1\n"
+    "v_mov_b32_dpp %[a], %[vp] wave_ror:1 row_mask:0xf bank_mask:0xf\n"
+    "v_mov_b32_dpp %[s1], %[sp] wave_ror:1 row_mask:0xf bank_mask:0xf\n"
+    "v_mov_b32_dpp %[s2], %[s1p] wave_ror:1 row_mask:0xf bank_mask:0xf\n"
+    "v_mov_b32_dpp %[q1], %[a1p] wave_ror:1 row_mask:0xf bank_mask:0xf\n"
+    "v_mov_b32_dpp %[q2], %[a2p] wave_ror:1 row_mask:0xf bank_mask:0xf\n"
+    "v_mov_b32_dpp %[a], %[v] wave_shr:1 row_mask:0xf bank_mask:0xf\n"          // a = v[i-1]
+    "v_sub_u32 %[s], %[v], %[a]\n"                                                 // stride of v[i]
+    "v_lshrrev_b32 %[t], 26, %[a]\n"
+    "v_and_or_b32 %[a1], %[t], 60, %[t1]\n"                                        // FCM entry: table + 4 * (top four bits of v[i-1])
+    "v_mov_b32_dpp %[s1], %[s] wave_shr:1 row_mask:0xf bank_mask:0xf\n"          // stride of v[i-1]
+    "v_xor_b32 %[x1], %[v], %[a]\n"
+    "v_mov_b32_dpp %[q1], %[a1] wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+    "v_lshrrev_b32 %[u], 22, %[s1]\n"
+    "v_add_u32 %[t], %[a], %[s1]\n"
+    "v_mov_b32_dpp %[s2], %[s1] wave_shr:1 row_mask:0xf bank_mask:0xf\n"         // stride of v[i-2]
+    "v_cmp_ne_u32_e64 %[st1], %[a1], %[q1]\n"
+    "v_xor_b32 %[x2], %[v], %[t]\n"
+    "v_lshrrev_b32 %[t], 17, %[s2]\n"
+    "v_bitop3_b32 %[t], %[t], %[u], %[k3e0] bitop3:0x6c\n"                         // ((s2 >> 17) & 0x3e0) ^ (s1 >> 22): the DFCM class
+    "v_lshl_add_u32 %[a2], %[t], 2, %[t2]\n"
+    "v_cmp_ne_u32_e64 %[nz1], 0, %[x1]\n"
+    "v_cmp_ne_u32_e64 %[nz2], 0, %[x2]\n"
+    "v_mov_b32_dpp %[q2], %[a2] wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+    "v_cmp_gt_u32_e32 vcc, 0x100, %[x1]\n"
+    "v_cmp_ne_u32_e64 %[st2], %[a2], %[q2]\n"
+    "s_mov_b32 %[done], 0\n"
+    "s_mov_b32 %[adv], 0\n"
+    "s_cmp_eq_u64 %[st1], 0\n"
+    "s_cselect_b32 %[no1], 1, 0\n"                                                 // 1: no run of FCM classes starts in this step
+    "s_cmp_eq_u64 %[st2], 0\n"
+    "s_cselect_b32 %[no2], 1, 0\n"
+    "s_or_b64 %[nz2], %[nz2], vcc\n"                                               // a lane that is not an exact DFCM hit with a long FCM residual
+    "s_or_b64 vcc, %[st1], %[st2]\n"
+    "s_cmp_lg_u64 vcc, 0\n"
+    "s_cbranch_scc1 .Lhead_end_%=\n"                                               // some run starts: tables
+    "s_cmp_eq_u64 %[nz1], 0\n"
+    "s_cbranch_scc1 .Lhead_u0_%=\n"
+    "s_cmp_lg_u64 %[nz2], 0\n"
+    "s_cbranch_scc1 .Lhead_end_%=\n"
+    "s_mov_b64 exec, 0x3fffff\n"                                                   // 64 exact DFCM hits: 88 bytes, 22 dwords
+    "v_add_u32 %[t], %[posl], %[lane4]\n"
+    "s_mov_b32 %[adv], 88\n"
+    "ds_write_b32 %[t], %[pat5]\n"
+    "s_branch .Lhead_done_%=\n"
+    ".Lhead_u0_%=:\n"
+    "s_mov_b64 exec, 0x3f\n"                                                       // 64 exact FCM hits: 24 zero bytes (x1 is zero in every lane)
+    "v_add_u32 %[t], %[posl], %[lane4]\n"
+    "s_mov_b32 %[adv], 24\n"
+    "ds_write_b32 %[t], %[x1]\n"
+    ".Lhead_done_%=:\n"
+    "s_mov_b64 exec, -1\n"
+    "s_mov_b32 %[done], 1\n"
+    ".Lhead_end_%=:\n"
+    : [a] "=&v"(a), [s] "=&v"(s), [s1] "=&v"(s1), [s2] "=&v"(s2), [a1] "=&v"(a1), [a2] "=&v"(a2), [q1] "=&v"(q1), [q2] "=&v"(q2),
+      [t] "=&v"(t), [u] "=&v"(u), [x1] "=&v"(x1), [x2] "=&v"(x2), [st1] "=&s"(st1), [st2] "=&s"(st2), [nz1] "=&s"(nz1), [nz2] "=&s"(nz2),
+      [done] "=&s"(done), [adv] "=&s"(adv), [no1] "=&s"(no1), [no2] "=&s"(no2)
+    : [v] "v"(v), [vp] "v"(sw.vp), [sp] "v"(sw.sp), [s1p] "v"(sw.s1p), [a1p] "v"(sw.a1p), [a2p] "v"(sw.a2p), [t1] "s"(t1abs),
+      [t2] "s"(t1abs + 64u), [k3e0] "s"(0x3e0u), [posl] "s"(posl_abs), [lane4] "v"(lk.lane4), [pat5] "v"(lk.pat5)
+    : "vcc", "scc", "memory");
+  st1 = uni(st1);
+  st2 = uni(st2);
+  no1 = uni(no1);
+  no2 = uni(no2);
+  adv = uni(adv);
+  return uni(done);
+  }
+
+// one predictor's run starts (see resolve_h): pending write, exchange by the lanes where a run starts or ends, prediction of the
+// starts.  ft = starts that met an entry nobody wrote in this segment; sent collects the lanes whose payload is the sentinel.
+__device__ __forceinline__ void resolve_asm(uint32_t ad, uint32_t adp, uint32_t pay, uint32_t payp, uint64_t st, uint32_t pend,
+                                            uint32_t& p, uint64_t& ft, uint64_t& sent)
+  {
+  uint32_t old;
+  asm volatile(
+    "s_cmp_eq_u32 %[pend], 0\n"
+    "s_cbranch_scc1 .Lres_np_%=\n"
+    "s_mov_b32 exec_lo, 0\n"                                                       // the previous step's last value: its lane 63 holds entry and payload
+    "s_brev_b32 exec_hi, 1\n"
+    "ds_write_b32 %[adp], %[payp]\n"
+    "v_cmp_eq_u32_e32 vcc, %[ksent], %[payp]\n"
+    "s_mov_b64 exec, -1\n"
+    "s_or_b64 %[sent], %[sent], vcc\n"
+    ".Lres_np_%=:\n"
+    "s_lshr_b64 vcc, %[st], 1\n"                                                   // a run ends where the next lane starts one; lane 63 always
+    "s_bitset1_b32 vcc_hi, 31\n"
+    "s_or_b64 exec, vcc, %[st]\n"
+    "ds_wrxchg_rtn_b32 %[old], %[ad], %[pay]\n"
+    "s_mov_b64 exec, -1\n"
+    "v_cmp_eq_u32_e32 vcc, %[ksent], %[pay]\n"
+    "s_or_b64 %[sent], %[sent], vcc\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    "v_cndmask_b32_e64 %[p], %[p], %[old], %[st]\n"
+    "v_cmp_eq_u32_e32 vcc, %[ksent], %[old]\n"
+    "s_and_b64 %[ft], vcc, %[st]\n"
+    : [p] "+v"(p), [old] "=&v"(old), [ft] "=&s"(ft), [sent] "+s"(sent)
+    : [ad] "v"(ad), [adp] "v"(adp), [pay] "v"(pay), [payp] "v"(payp), [st] "s"(st), [pend] "s"(pend), [ksent] "s"(SENT)
+    : "vcc", "scc", "memory");
+  ft = uni(ft);
+  sent = uni(sent);
+  }
+
+// residual selection, byte layout, byte stores of a full step (see step_tail); hole = the lanes whose value is deferred (four zero
+// bytes, code 0).  Returns the bytes staged; hq = LDS address of the lane's group header, pre = residual bytes of the lanes below.
+__device__ __forceinline__ uint32_t tail_asm(uint32_t v, uint32_t a, uint32_t p1, uint32_t p2, uint64_t hole, uint32_t posl_abs,
+                                             const LaneK& lk, uint32_t& hq, uint32_t& pre)
+  {
+  uint32_t x1, x2, c1, c2, len, x, code, inc, bc, t, total;
+  uint64_t nzl;
+  asm volatile(
+    "v_xor_b32 %[x1], %[v], %[p1]\n"                                               // FCM residual
+    "v_add_u32 %[t], %[a], %[p2]\n"
+    "v_xor_b32 %[x2], %[v], %[t]\n"                                                // DFCM residual
+    "v_ffbh_u32 %[c1], %[x1]\n"
+    "v_ffbh_u32 %[c2], %[x2]\n"
+    "v_min_u32 %[c1], 32, %[c1]\n"                                                 // leading zero bits: 0..32
+    "v_min_u32 %[c2], 31, %[c2]\n"                                                 // 0..31: a DFCM residual takes at least one byte
+    "v_lshrrev_b32 %[c1], 3, %[c1]\n"                                              // leading zero bytes m1
+    "v_lshrrev_b32 %[c2], 3, %[c2]\n"                                              // m2
+    "v_cmp_gt_u32_e32 vcc, %[c2], %[c1]\n"                                         // DFCM iff its residual is shorter (fpsc.c:146-189)
+    "v_max_u32 %[t], %[c1], %[c2]\n"
+    "v_cndmask_b32_e32 %[x], %[x1], %[x2], vcc\n"
+    "v_sub_u32 %[len], 4, %[t]\n"
+    "v_cndmask_b32_e64 %[t], 0, 4, vcc\n"
+    "v_add_u32 %[code], %[len], %[t]\n"
+    "s_cmp_eq_u64 %[hole], 0\n"
+    "s_cbranch_scc1 .Ltail_nh_%=\n"
+    "v_cndmask_b32_e64 %[len], %[len], 4, %[hole]\n"                               // deferred values: four zero bytes, code 0
+    "v_cndmask_b32_e64 %[code], %[code], 0, %[hole]\n"
+    "v_cndmask_b32_e64 %[x], %[x], 0, %[hole]\n"
+    "s_nop 0\n"
+    ".Ltail_nh_%=:\n"
+    "v_lshrrev_b32 %[x1], 24, %[x]\n"                                              // (x1, x2 from here on: bytes 3 and 1 of the residual)
+    "v_lshlrev_b32 %[bc], %[sh3], %[code]\n"
+    "v_add_u32_dpp %[inc], %[len], %[len] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    "v_lshrrev_b32 %[x2], 8, %[x]\n"
+    "v_cmp_ne_u32_e64 %[nzl], 0, %[len]\n"
+    "v_add_u32_dpp %[inc], %[inc], %[inc] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    "v_or_b32_dpp %[bc], %[bc], %[bc] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    "s_nop 0\n"
+    "v_add_u32_dpp %[inc], %[inc], %[inc] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    "v_or_b32_dpp %[bc], %[bc], %[bc] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    "s_nop 0\n"
+    "v_add_u32_dpp %[inc], %[inc], %[inc] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    "v_or_b32_dpp %[bc], %[bc], %[bc] row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    "s_nop 0\n"
+    "v_add_u32_dpp %[inc], %[inc], %[inc] row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+    "v_lshrrev_b32 %[t], 8, %[bc]\n"
+    "s_nop 0\n"
+    "v_add_u32_dpp %[inc], %[inc], %[inc] row_bcast:31 row_mask:0xc bank_mask:0xf\n"       // inclusive sum of the lengths
+    "v_sub_u32 %[pre], %[inc], %[len]\n"                                           // bytes of the residuals below my lane
+    "v_add3_u32 %[hq], %[posl], %[grp3], %[pre]\n"                                 // my group's header, my residual behind it at hq + 3
+    "v_add3_u32 %[c2], %[hq], %[len], -1\n"                                        // the four bytes that END with my residual's last byte
+    "v_readlane_b32 %[total], %[inc], 63\n"
+    "s_mov_b64 exec, %[nzl]\n"
+    "ds_write_b8 %[c2], %[x1]\n"                                                   // most significant byte first, in this order (see step_tail)
+    "ds_write_b8_d16_hi %[c2], %[x] offset:1\n"
+    "ds_write_b8 %[c2], %[x2] offset:2\n"
+    "ds_write_b8 %[c2], %[x] offset:3\n"
+    "s_mov_b64 exec, %[lead]\n"
+    "ds_write_b8_d16_hi %[hq], %[bc]\n"                                            // three header bytes, big-endian, by the lanes that lead a group
+    "ds_write_b8 %[hq], %[t] offset:1\n"
+    "ds_write_b8 %[hq], %[bc] offset:2\n"
+    "s_mov_b64 exec, -1\n"
+    "s_add_u32 %[total], %[total], 24\n"
+    : [x1] "=&v"(x1), [x2] "=&v"(x2), [c1] "=&v"(c1), [c2] "=&v"(c2), [len] "=&v"(len), [x] "=&v"(x), [code] "=&v"(code),
+      [inc] "=&v"(inc), [bc] "=&v"(bc), [hq] "=&v"(hq), [pre] "=&v"(pre), [t] "=&v"(t), [total] "=&s"(total), [nzl] "=&s"(nzl)
+    : [v] "v"(v), [a] "v"(a), [p1] "v"(p1), [p2] "v"(p2), [posl] "s"(posl_abs), [grp3] "v"(lk.grp3), [sh3] "v"(lk.sh3),
+      [lead] "s"(0x0101010101010101ull), [hole] "s"(hole)
+    : "vcc", "scc", "memory");
+  return uni(total);
+  }
+
+// the records of a step's deferred values (see step_tail)
+__device__ __forceinline__ void write_records(uint64_t ft1, uint64_t ft2, uint32_t v, uint32_t a, uint32_t a1, uint32_t a2, uint32_t p1,
+                                              uint32_t p2, uint32_t hq, uint32_t pre, uint32_t t1abs, uint32_t sbase, Sweep& sw,
+                                              const LaneK& lk, const RecSink& sink)
+  {
+  const uint64_t hm = ft1 | ft2;
+  const bool f1 = (ft1 >> lk.lane) & 1ull, f2 = (ft2 >> lk.lane) & 1ull;
+  const uint32_t pre_lead = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lk.lane & ~7u) << 2), (int)pre);
+  const uint32_t idx = sw.nrec + popc_below(hm);
+  if (f1 || f2)
+    {
+    u32x4 w;
+    w[0] = sw.flushed + (hq - sbase) + 3u;
+    w[1] = (3u + pre - pre_lead) | ((lk.lane & 7u) << 8) | ((uint32_t)f1 << 12) | ((uint32_t)f2 << 13) | (((a1 >> 2) & 15u) << 16) |
+           (((a2 - (t1abs + 64u)) >> 2) << 20);
+    w[2] = v;
+    w[3] = a;
+    uint32_t* r = sink.recs + RECW * idx;
+    *(u32x4*)r = w;
+    r[4] = f1 ? (f2 ? 0u : p2) : p1;
+    }
+  sw.nrec += (uint32_t)__popcll(hm);
+  }
+
+// one full step with the pieces above
+template <bool HOOK>
+__device__ __forceinline__ void code_step_asm(uint32_t v, uint32_t t1abs, uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase,
+                                              Sweep& sw, const LaneK& lk, const RecSink& sink, uint32_t sabotage)
+  {
+  const uint32_t sbase = (uint32_t)(uintptr_t)(lds_u8*)stage;        // LDS address of the staging area (uniform)
+  flush_end(sw, stage, gbase, lk);
+  uint32_t a, s, s1, a1, a2, adv, no1, no2;
+  uint64_t st1, st2;
+  if (step_head_asm(v, sw, t1abs, sbase + sw.posl, lk, a, s, s1, a1, a2, st1, st2, no1, no2, adv))
+    {
+    sw.posl += adv;
+    sw.pend1 = sw.pend2 = 1u;
+    }
+  else
+    {
+    uint32_t p1 = a, p2 = s1;                                // inside a run: previous value / previous stride
+    uint64_t ft1 = 0, ft2 = 0, sent = 0;
+    if (no1 == 0u)
+      resolve_asm(a1, sw.a1p, v, sw.vp, st1, sw.pend1, p1, ft1, sent);
+    if (no2 == 0u)
+      resolve_asm(a2, sw.a2p, s, sw.sp, st2, sw.pend2, p2, ft2, sent);
+    if (HOOK && sabotage)
+      {
+      // test hook (libtrico_testhooks.so only), see resolve_h
+      if (((st1 >> lk.lane) & 1ull) && lk.lane >= 32u) p1 ^= 0x100u;
+      if (((st2 >> lk.lane) & 1ull) && lk.lane >= 32u) p2 ^= 0x100u;
+      }
+    sw.pend1 = no1;                                          // (as integers: a bool that lives across blocks ends up as a lane mask)
+    sw.pend2 = no2;
+    if (sent)
+      sw.flags |= FLAG_SENTINEL;
+    uint32_t hq, pre;
+    const uint32_t staged = tail_asm(v, a, p1, p2, ft1 | ft2, sbase + sw.posl, lk, hq, pre);
+    if (ft1 | ft2)
+      write_records(ft1, ft2, v, a, a1, a2, p1, p2, hq, pre, t1abs, sbase, sw, lk, sink);
+    sw.posl += staged;
+    }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  flush_begin(sw, stage, gbase, lk);
+  sw.vp = v; sw.sp = s; sw.s1p = s1; sw.a1p = a1; sw.a2p = a2;
+  }
+
+// store the bytes of staged word `w` (byte offset off inside the slot, multiple of 4) that lie below hi
+__device__ __forceinline__ void store_span(uint8_t* __restrict__ gbase, uint32_t off, uint32_t w, uint32_t hi)
+  {
+  if (off + 4u <= hi)
+    *(uint32_t*)(gbase + off) = w;
+  else
+    for (uint32_t bb = 0; bb < 4u; ++bb)
+      if (off + bb < hi)
+        gbase[off + bb] = (uint8_t)(w >> (8u * bb));
+  }
+
+// ---- the sweep ---------------------------------------------------------------------------------------------------------------
+// what a wave is given to start a segment with
+__device__ __forceinline__ void sweep_begin(Sweep& sw, const uint32_t* __restrict__ src, uint32_t n, uint32_t arity, uint32_t c, uint32_t g,
+                                            uint32_t i_begin, uint32_t* __restrict__ T, uint8_t* __restrict__ stage, uint32_t lane)
+  {
+  for (uint32_t k = lane; k < (uint32_t)TAB; k += 64u)
+    T[k] = SENT;
+  sw.pend1 = sw.pend2 = 0u;
+  sw.posl = 0;
+  sw.flushed = 0;
+  sw.fl_nb = 0;
+  sw.nrec = 0;
+  sw.flags = 0;
+  sw.a1p = sw.a2p = 0xfffffffeu;                       // the first value of a segment always looks at the table
+  // the three values before the segment (0 before the stream: the reference starts from zeroed state, fpsc.c:104-116)
+  const uint32_t m1 = i_begin >= 1u ? src[(size_t)(i_begin - 1u) * arity + c] : 0u;
+  const uint32_t m2 = i_begin >= 2u ? src[(size_t)(i_begin - 2u) * arity + c] : 0u;
+  const uint32_t m3 = i_begin >= 3u ? src[(size_t)(i_begin - 3u) * arity + c] : 0u;
+  sw.vp = m1;
+  sw.sp = m1 - m2;
+  sw.s1p = m2 - m3;
+  if (g == 0)
+    {
+    if (lane == 0)
+      {
+      stage[0] = 0x25;                      // (4/2) << 4 | (10/2), fpsc.c:120
+      stage[1] = (uint8_t)(n >> 24); stage[2] = (uint8_t)(n >> 16); stage[3] = (uint8_t)(n >> 8); stage[4] = (uint8_t)n;
+      }
+    sw.posl = 5u;
+    }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+
+// what is left in the staging area (< 256 bytes) goes to the slot; returns the bytes the wave produced
+__device__ __forceinline__ uint32_t sweep_end(Sweep& sw, uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase, const LaneK& lk)
+  {
+  flush_end(sw, stage, gbase, lk);
+  if (lk.lane4 < sw.posl)
+    store_span(gbase + sw.flushed, lk.lane4, ((const uint32_t*)stage)[lk.lane], sw.posl);
+  return sw.flushed + sw.posl;
+  }
+
+// The write-side guard (workgroups S .. S + G - 1 of the sweep): workgroup j codes the first GUARD_STEPS steps of a sampled segment
+// again - compiled step, run starts resolved with BALLOTS, nothing that depends on the order in which the LDS unit applies an
+// exchange - into a slot and a record list of its own.  The fix-up kernel compares them with what the sweep made of that segment
+// (k_fpc32_fixup, workgroups beyond S): same bytes, same records, or FLAG_ORDER.
+struct GuardMeta { uint32_t seg, bytes, nrec, pad; };
+
+template <bool HOOK>
+__device__ __forceinline__ void guard_segment(const uint32_t* __restrict__ src, uint32_t n, uint32_t arity, uint32_t L, uint32_t S, uint32_t j,
+                                              uint32_t c, uint32_t lane, uint32_t seed, uint32_t* __restrict__ lds, uint8_t* __restrict__ gslots,
+                                              uint32_t* __restrict__ grecs, GuardMeta* __restrict__ gmeta)
+  {
+  const uint32_t g = (uint32_t)(((uint64_t)j * 0x9E3779B1ull + seed) % S);        // which segment: from a counter of the encodes
+  uint32_t* T = lds + c * LDSW;
+  uint8_t* stage = (uint8_t*)(T + TAB);
+  const uint32_t t1abs = (uint32_t)(uintptr_t)(lds_u8*)T;
+  const LaneK lk = lane_constants(lane);
+  const uint32_t i_begin = g * L;
+  const uint32_t seg_end = (n - i_begin < L) ? n : i_begin + L;
+  const uint32_t i_end = (seg_end - i_begin < 64u * GUARD_STEPS) ? seg_end : i_begin + 64u * GUARD_STEPS;
+  const size_t row = (size_t)j * arity + c;
+  uint8_t* gbase = gslots + row * GUARD_CAP;
+  const RecSink sink = { grecs + row * RCAP * RECW };
+  Sweep sw;
+  sweep_begin(sw, src, n, arity, c, g, i_begin, T, stage, lane);
+#pragma unroll 1
+  for (uint32_t i0 = i_begin; i0 < i_end; i0 += 64u)
+    {
+    const uint32_t i = i0 + lane;
+    const uint32_t v = i < seg_end ? src[(size_t)i * arity + c] : 0u;
+    if (i0 + 64u <= seg_end)
+      code_step<true, true, HOOK>(v, i0, seg_end, n, t1abs, stage, gbase, sw, lk, sink, 0u);
+    else
+      code_step<false, true, HOOK>(v, i0, seg_end, n, t1abs, stage, gbase, sw, lk, sink, 0u);
+    }
+  const uint32_t bytes = sweep_end(sw, stage, gbase, lk);
+  if (lane == 0)
+    gmeta[row] = GuardMeta{ g, bytes, sw.nrec, 0u };
+  }
+
+#ifndef TRICO_SWEEP_WAVES
+#define TRICO_SWEEP_WAVES 8
+#endif
+template <bool HOOK, bool ASM>
+__global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(TRICO_SWEEP_WAVES, 8)))
+k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t L, uint32_t S, uint32_t* __restrict__ outT,
+              uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap, uint32_t* __restrict__ segbytes,
+              uint32_t* __restrict__ nrec, uint32_t* __restrict__ recs, uint32_t tune, uint32_t sabotage, uint32_t seed,
+              uint8_t* __restrict__ gslots, uint32_t* __restrict__ grecs, GuardMeta* __restrict__ gmeta)
+  {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;      // (c in a scalar register)
+  const uint32_t g = blockIdx.x;
+  if (g >= S)
+    {
+    guard_segment<HOOK>(src, n, (uint32_t)arity, L, S, g - S, c, lane, seed, lds, gslots, grecs, gmeta);
+    return;
+    }
+  volatile uint32_t* prog = lds + arity * LDSW;        // [4] progress of the component waves
+  uint32_t* T = lds + c * LDSW;
+  uint8_t* stage = (uint8_t*)(T + TAB);
+  const uint32_t t1abs = (uint32_t)(uintptr_t)(lds_u8*)T;                  // LDS address of the wave's tables (a multiple of 64)
+  const LaneK lk = lane_constants(lane);
+  const uint32_t i_begin = g * L;
+  const uint32_t i_end = (n - i_begin < L) ? n : i_begin + L;
+  uint8_t* gbase = slots + (size_t)c * slot_stride + (size_t)g * segcap;
+  const size_t rowi = (size_t)g * arity + c;
+  const RecSink sink = { recs + rowi * RCAP * RECW };
+  Sweep sw;
+  sweep_begin(sw, src, n, (uint32_t)arity, c, g, i_begin, T, stage, lane);
+  // rolling prefetch: the next PF steps' values; a slot is loaded again as soon as its step begins (always PF steps in flight, never
+  // more: 320 workgroups per XCD share 4 MB of L2)
+  const uint32_t voff = (lane * (uint32_t)arity + c) * 4u;
+  uint32_t cur[PF];
+#pragma unroll
+  for (int pu = 0; pu < PF; ++pu)
+    {
+    const uint32_t ii = i_begin + 64u * pu;
+    const uint8_t* base = (const uint8_t*)(src + (size_t)ii * arity);
+    cur[pu] = (ii < i_end && ii + lane < i_end) ? *(const uint32_t*)(base + voff) : 0u;
+    }
+  const uint32_t lag = (tune >> 8) & 255u;             // blocks a component wave may run ahead of the slowest (0 = any)
+  const bool prio = (tune & 255u) != 0u;
+  if (lane == 0)
+    prog[c] = i_begin;
+  if (lag)
+    __syncthreads();                                   // everybody's progress word is this workgroup's before anybody compares
+  uint32_t vlast = 0, ilast = 0xffffffffu;             // the last, partial step of the stream, if this segment has it
+  for (uint32_t ib = i_begin; ib < i_end; ib += 64u * PF)
+    {
+    if (prio)
+      {
+      // the component that is behind gets the issue slots first: the waves of a workgroup hold their LDS until the last of them
+      // is done, and the sweep ends when the slowest component does
+      if (lane == 0)
+        prog[c] = ib;
+      uint32_t ahead = 0;
+      for (int o = 0; o < arity; ++o)
+        ahead = max(ahead, (uint32_t)__builtin_amdgcn_readfirstlane((int)prog[o]) + 1u);      // (a finished wave's 0xffffffff counts as 0)
+      if (ib + 1u + 64u * PF <= ahead)
+        __builtin_amdgcn_s_setprio(3);
+      else
+        __builtin_amdgcn_s_setprio(0);
+      // ... and with a lag the ones in front wait for it (bounded), so that the component waves read the same cache lines at about
+      // the same time and the interleaved array comes over HBM once
+      for (uint32_t spin = 0; lag && spin < 4096u; ++spin)
+        {
+        uint32_t lo = 0xffffffffu;
+        for (int o = 0; o < arity; ++o)
+          lo = min(lo, (uint32_t)__builtin_amdgcn_readfirstlane((int)prog[o]));
+        if (lo == 0xffffffffu || ib <= lo + lag * 64u * PF)
+          break;
+        __builtin_amdgcn_s_sleep(2);
+        }
+      }
+    const uint8_t* nbase = (const uint8_t*)(src + (size_t)(ib + 64u * PF) * arity);
+    if (ib + 128u * PF <= i_end)
+      {
+      // this block and the one the loads reach into lie inside the segment: no bounds, no activity masks
+#pragma unroll
+      for (int pu = 0; pu < PF; ++pu)
+        {
+        const uint32_t vcur = cur[pu];
+        uint32_t vo = voff;
+        asm volatile("" : "+v"(vo));                   // (keeps the 32-bit offset in this block: scalar base + vector offset addressing)
+        cur[pu] = *(const uint32_t*)(nbase + (size_t)(256u * (uint32_t)pu) * arity + vo);
+        if (ASM)
+          code_step_asm<HOOK>(vcur, t1abs, stage, gbase, sw, lk, sink, sabotage);
+        else
+          code_step<true, false, HOOK>(vcur, ib + 64u * pu, i_end, n, t1abs, stage, gbase, sw, lk, sink, sabotage);
+        }
+      }
+    else
+      {
+#pragma unroll 1
+      for (int pu = 0; pu < PF; ++pu)
+        {
+        const uint32_t i0 = ib + 64u * pu;
+        if (i0 >= i_end)
+          break;
+        uint32_t vcur = cur[0];
+#pragma unroll
+        for (int q = 1; q < PF; ++q)
+          vcur = pu == q ? cur[q] : vcur;
+        if (i0 + 64u > i_end)
+          {
+          vlast = vcur;                                // (behind the loop: the step with activity masks is compiled code of its own)
+          ilast = i0;
+          break;
+          }
+        const uint32_t in = i0 + 64u * PF + lane;
+        const uint32_t nv = in < i_end ? *(const uint32_t*)(nbase + (size_t)(256u * (uint32_t)pu) * arity + voff) : 0u;
+#pragma unroll
+        for (int q = 0; q < PF; ++q)
+          cur[q] = pu == q ? nv : cur[q];
+        if (ASM)
+          code_step_asm<HOOK>(vcur, t1abs, stage, gbase, sw, lk, sink, sabotage);
+        else
+          code_step<true, false, HOOK>(vcur, i0, i_end, n, t1abs, stage, gbase, sw, lk, sink, sabotage);
+        }
+      }
+    }
+  if (ilast != 0xffffffffu)
+    code_step<false, false, HOOK>(vlast, ilast, i_end, n, t1abs, stage, gbase, sw, lk, sink, sabotage);
+  const uint32_t bytes = sweep_end(sw, stage, gbase, lk);
+  if (lane == 0)
+    prog[c] = 0xffffffffu;                             // done: nobody is behind me any more, nobody waits for me
+  // what the segment leaves behind: the tables with the last value's writes applied (SENT = not written here)
+  if (lane == 63u)
+    {
+    if (sw.pend1) *lds_at(sw.a1p) = sw.vp;
+    if (sw.pend2) *lds_at(sw.a2p) = sw.sp;
+    }
+  if ((sw.pend1 && __ballot(lane == 63u && sw.vp == SENT)) || (sw.pend2 && __ballot(lane == 63u && sw.sp == SENT)))
+    sw.flags |= FLAG_SENTINEL;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (uint32_t k = lane; k < (uint32_t)TAB; k += 64u)
+    outT[rowi * ROW + k] = T[k];
+  if (lane == 0)
+    {
+    segbytes[(size_t)c * S + g] = bytes;
+    nrec[rowi] = sw.nrec | (sw.flags << 16);
+    }
+  }
+
+// ---- cross-segment scan: incoming payload of (segment, class) = the published entry of the nearest earlier segment that wrote
+// the class, else 0 (the reference's zeroed tables, fpsc.c:104-105) -------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_fpc32_pscan_a(const uint32_t* __restrict__ outT, uint32_t S, int arity, uint32_t* __restrict__ chlast)
+  {
+  const uint32_t col = blockIdx.x * 256u + threadIdx.x;      // (component, class)
+  const uint32_t ncol = (uint32_t)arity * TAB;
+  if (col >= ncol)
+    return;
+  const uint32_t c = col / TAB, k = col % TAB;
+  const uint32_t g0 = blockIdx.y * CH, g1 = (g0 + CH < S) ? g0 + CH : S;
+  uint32_t last = SENT;
+#pragma unroll 8
+  for (uint32_t g = g0; g < g1; ++g)
+    {
+    const uint32_t t = outT[((size_t)g * arity + c) * ROW + k];
+    last = t != SENT ? t : last;
+    }
+  chlast[(size_t)blockIdx.y * ncol + col] = last;
+  }
+
+__global__ void __launch_bounds__(256) k_fpc32_pscan_b(const uint32_t* __restrict__ outT, uint32_t S, int arity,
+                                                       const uint32_t* __restrict__ chlast, uint32_t* __restrict__ inc)
+  {
+  const uint32_t col = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t ncol = (uint32_t)arity * TAB;
+  if (col >= ncol)
+    return;
+  const uint32_t c = col / TAB, k = col % TAB;
+  uint32_t carry = 0;
+#pragma unroll 8
+  for (uint32_t j = 0; j < blockIdx.y; ++j)
+    {
+    const uint32_t t = chlast[(size_t)j * ncol + col];
+    carry = t != SENT ? t : carry;
+    }
+  const uint32_t g0 = blockIdx.y * CH, g1 = (g0 + CH < S) ? g0 + CH : S;
+#pragma unroll 8
+  for (uint32_t g = g0; g < g1; ++g)
+    {
+    const size_t r = ((size_t)g * arity + c) * ROW + k;
+    const uint32_t t = outT[r];
+    inc[r] = carry;
+    carry = t != SENT ? t : carry;
+    }
+  }
+
+// ---- the deferred values: residual, length and code from the incoming entries (fpsc.c:133-189 for one value) -----------------
+// One workgroup per (segment, component) with records.  The record keeps the result for the gather (w6 = residual, w7 = length |
+// code << 4); the segment's size loses the unused bytes of its reserved fields (rawbytes keeps what the slot holds).
+// Workgroups S .. S + G - 1 are the second half of the write-side guard: what guard workgroup j coded with ballots (guard_segment)
+// against what the sweep left for that segment - the bytes, the number of records up to there and the records themselves.  A
+// difference raises FLAG_ORDER for the component (it travels with the segment's record count to k_fpc32_offsets and the host).
+__global__ void __launch_bounds__(256) k_fpc32_fixup(int arity, uint32_t S, const uint32_t* __restrict__ inc, uint32_t* __restrict__ segbytes,
+                                                     uint32_t* __restrict__ rawbytes, uint32_t* __restrict__ nrec, uint32_t* __restrict__ recs,
+                                                     const uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap,
+                                                     const uint8_t* __restrict__ gslots, const uint32_t* __restrict__ grecs,
+                                                     const GuardMeta* __restrict__ gmeta)
+  {
+  __shared__ uint32_t part[4];
+  const uint32_t g = blockIdx.x, c = blockIdx.y;
+  if (g >= S)
+    {
+    const size_t row = (size_t)(g - S) * arity + c;
+    const GuardMeta m = gmeta[row];
+    const size_t rowi = (size_t)m.seg * arity + c;
+    const uint32_t* mine = (const uint32_t*)(slots + (size_t)c * slot_stride + (size_t)m.seg * segcap);
+    const uint32_t* theirs = (const uint32_t*)(gslots + row * GUARD_CAP);
+    const uint32_t H = nrec[rowi] & 0xffffu;
+    bool diff = H < m.nrec || segbytes[(size_t)c * S + m.seg] < m.bytes;
+    for (uint32_t t = threadIdx.x; 4u * t < m.bytes; t += 256u)
+      {
+      const uint32_t keep = 4u * t + 4u <= m.bytes ? 0xffffffffu : (1u << (8u * (m.bytes & 3u))) - 1u;
+      diff = diff || ((mine[t] ^ theirs[t]) & keep) != 0u;
+      }
+    const uint32_t* ra = recs + rowi * RCAP * RECW, * rb = grecs + row * RCAP * RECW;
+    for (uint32_t t = threadIdx.x; t < 5u * m.nrec && !(H < m.nrec); t += 256u)
+      diff = diff || ra[RECW * (t / 5u) + t % 5u] != rb[RECW * (t / 5u) + t % 5u];
+    if (threadIdx.x == 0 && H > m.nrec)
+      diff = diff || ra[RECW * m.nrec] < m.bytes;            // a record of the sweep inside the compared bytes that the guard does not have
+    if (diff)
+      atomicOr(&nrec[rowi], FLAG_ORDER << 16);
+    return;
+    }
+  const size_t rowi = (size_t)g * arity + c;
+  const uint32_t H = nrec[rowi] & 0xffffu;
+  if (H == 0u)
+    return;
+  uint32_t* list = recs + rowi * RCAP * RECW;
+  const uint32_t* row = inc + rowi * ROW;
+  uint32_t unused = 0;
+  for (uint32_t j = threadIdx.x; j < H; j += 256u)
+    {
+    const u32x4 w = *(const u32x4*)(list + RECW * j);
+    const uint32_t known = list[RECW * j + 4u];
+    const bool ft1 = (w[1] >> 12) & 1u, ft2 = (w[1] >> 13) & 1u;
+    const uint32_t k1 = (w[1] >> 16) & 15u, k2 = 16u + ((w[1] >> 20) & 1023u);
+    const uint32_t v = w[2], a = w[3];
+    const uint32_t p1 = ft1 ? row[k1] : known;
+    const uint32_t p2 = ft2 ? row[k2] : known;
+    const uint32_t x1 = v ^ p1, x2 = v ^ (a + p2);
+    const uint32_t n1 = (39u - (uint32_t)__clz((int)x1)) >> 3;
+    const uint32_t n2 = (39u - (uint32_t)__clz((int)(x2 | 1u))) >> 3;
+    const bool use2 = n2 < n1;
+    const uint32_t len = use2 ? n2 : n1, x = use2 ? x2 : x1, code = use2 ? (n2 | 4u) : n1;
+    list[RECW * j + 6u] = x;
+    list[RECW * j + 7u] = len | (code << 4);
+    unused += 4u - len;
+    }
+  const uint32_t incl = wave_scan_incl(unused);
+  if ((threadIdx.x & 63u) == 63u)
+    part[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    {
+    const uint32_t raw = segbytes[(size_t)c * S + g];
+    rawbytes[(size_t)c * S + g] = raw;
+    segbytes[(size_t)c * S + g] = raw - (part[0] + part[1] + part[2] + part[3]);
+    }
+  }
+
+// ---- gather: segment slots -> contiguous payload ----------------------------------------------------------------------------
+// grid (S, components); each workgroup moves one segment.  Without records: the destination is written as aligned 16-byte vectors,
+// the source (a 256-byte aligned slot) is read as 4 + 1 dwords per vector and re-aligned with v_alignbyte.
+// With records the slot passes through LDS in chunks of 4 KiB of SOURCE bytes: a chunk near a record is parked, the records put
+// their residual bytes and code bits where they belong and mark the unused bytes of their fields, a prefix sum over the valid bytes
+// of every 16-byte piece says where it goes; every chunk then lands in an output ring whose positions are congruent to the
+// destination's modulo 16 and leaves it as aligned 16-byte vectors.  Nothing is searched: a record knows its slot position.
+constexpr uint32_t GCH = 4096;                     // source bytes per chunk (256 threads x 16)
+constexpr uint32_t ORING = 16384;                  // output ring (power of two; see the overlap argument at the flush)
+constexpr uint32_t MAXCH = 2048;                   // chunks per slot the record index covers (8 MiB slots; beyond: every chunk looks at all records)
+struct GatherDst { uint8_t* p[3]; };
+
+__global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap, uint32_t S,
+                                                      const uint32_t* __restrict__ segbytes, const uint32_t* __restrict__ rawbytes,
+                                                      const uint32_t* __restrict__ segoff, GatherDst dst, const uint32_t* __restrict__ nrec,
+                                                      const uint32_t* __restrict__ recs, int arity, int c0)
+  {
+  const uint32_t g = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+  const uint32_t cc = (uint32_t)c0 + c;                                           // component in the workspace's numbering
+  const uint32_t len = segbytes[(size_t)cc * S + g];
+  const uint8_t* s = slots + (size_t)cc * slot_stride + (size_t)g * segcap;       // 256-byte aligned, segcap has 280 bytes of slack
+  uint8_t* d = dst.p[c] + segoff[(size_t)cc * S + g];
+  const size_t rowi = (size_t)g * arity + cc;
+  const uint32_t H = nrec[rowi] & 0xffffu;
+  if (H == 0u)
+    {
+    const uint32_t head = (uint32_t)((16u - ((uintptr_t)d & 15u)) & 15u);         // bytes until d is 16-byte aligned
+    const uint32_t h = head < len ? head : len;
+    const uint32_t body = (len - h) >> 4;                                         // aligned destination vectors
+    u32x4* dd = (u32x4*)(d + h);
+    const uint32_t done = h + 16u * body;
+    if (tid < h)
+      d[tid] = s[tid];
+    const uint32_t* ss = (const uint32_t*)s + (h >> 2);
+    const uint32_t sh = h & 3u;
+    // destination vector t holds source bytes h + 16t .. h + 16t + 15
+    for (uint32_t t = tid; t < body; t += 256u)
+      {
+      const u32x4 lo = *(const u32x4*)(ss + 4u * t);                              // 4-byte aligned 16-byte load
+      const uint32_t hi = ss[4u * t + 4u];
+      u32x4 o;
+      o[0] = __builtin_amdgcn_alignbyte(lo[1], lo[0], sh);
+      o[1] = __builtin_amdgcn_alignbyte(lo[2], lo[1], sh);
+      o[2] = __builtin_amdgcn_alignbyte(lo[3], lo[2], sh);
+      o[3] = __builtin_amdgcn_alignbyte(hi, lo[3], sh);
+      __builtin_nontemporal_store(o, dd + t);
+      }
+    if (tid < len - done)
+      d[done + tid] = s[done + tid];
+    return;
+    }
+  __shared__ __attribute__((aligned(16))) uint8_t SB[GCH];       // the parked chunk
+  __shared__ uint32_t U[GCH / 32];                               // its unused bytes, one bit each
+  __shared__ __attribute__((aligned(16))) uint8_t O[ORING];      // output ring
+  __shared__ uint32_t cfirst[MAXCH + 2];                         // first record whose field ends in chunk >= i; bit 31: a record touches chunk i
+  __shared__ uint32_t wsum[4];
+  const uint32_t slen = rawbytes[(size_t)cc * S + g];
+  const uint32_t* list = recs + rowi * RCAP * RECW;
+  const uint32_t nchunk = (slen + GCH - 1u) / GCH;
+  const bool indexed = nchunk <= MAXCH;
+  if (indexed)
+    {
+    for (uint32_t q = tid; q <= nchunk + 1u; q += 256u)
+      cfirst[q] = H;
+    __syncthreads();
+    for (uint32_t j = tid; j < H; j += 256u)
+      atomicMin(&cfirst[(list[RECW * j] + 3u) / GCH], j);
+    __syncthreads();
+    if (tid == 0)
+      for (uint32_t q = nchunk; q-- > 0u;)
+        cfirst[q] = min(cfirst[q], cfirst[q + 1u]);
+    __syncthreads();
+    // the chunks a record touches: the one its header begins in and the one its field ends in (at most 34 bytes apart)
+    for (uint32_t j = tid; j < H; j += 256u)
+      {
+      const uint32_t pos = list[RECW * j], hdr = pos - (list[RECW * j + 1u] & 255u);
+      atomicOr(&cfirst[hdr / GCH], 0x80000000u);
+      atomicOr(&cfirst[(pos + 3u) / GCH], 0x80000000u);
+      }
+    __syncthreads();
+    }
+  const uint32_t A = (uint32_t)((uintptr_t)d & 15u);             // ring position p <-> destination byte (d - A) + p
+  uint8_t* dbase = d - A;
+  uint32_t wpos = A, rpos = 0;
+  const uint32_t lane = tid & 63u, wv = tid >> 6;
+  for (uint32_t ci = 0; ci < nchunk; ++ci)
+    {
+    const uint32_t cb = ci * GCH, sb = cb + 16u * tid;
+    u32x4 vec = { 0u, 0u, 0u, 0u };
+    if (sb < slen)
+      vec = *(const u32x4*)(s + sb);
+    const uint32_t r0 = indexed ? cfirst[ci] & 0x7fffffffu : 0u;
+    uint32_t r1 = indexed ? (cfirst[ci + 1u] & 0x7fffffffu) + 9u : H;      // (a header lies at most 31 bytes = 7 fields before its record's field)
+    r1 = r1 < H ? r1 : H;
+    const bool dirty = indexed ? (cfirst[ci] >> 31) != 0u : true;
+    uint32_t m16 = 0;
+    if (dirty)
+      {
+      *(u32x4*)(SB + 16u * tid) = vec;
+      if (tid < GCH / 32u)
+        U[tid] = 0u;
+      __syncthreads();
+      for (uint32_t j = r0 + tid; j < r1; j += 256u)
+        {
+        const uint32_t pos = list[RECW * j], meta = list[RECW * j + 1u], x = list[RECW * j + 6u], lc = list[RECW * j + 7u];
+        const uint32_t ln = lc & 15u, code = lc >> 4;
+        const uint32_t hdr = pos - (meta & 255u), h24 = code << (3u * ((meta >> 8) & 7u));
+        for (uint32_t b = 0; b < 4u; ++b)
+          {
+          const uint32_t q = pos + b - cb;                       // wraps to a huge number before the chunk
+          if (q < GCH)
+            {
+            if (b < ln)
+              SB[q] = (uint8_t)(x >> (8u * (ln - 1u - b)));
+            else
+              atomicOr(&U[q >> 5], 1u << (q & 31u));
+            }
+          }
+        for (uint32_t b = 0; b < 3u; ++b)
+          {
+          const uint32_t q = hdr + b - cb;
+          const uint32_t by = (h24 >> (8u * (2u - b))) & 255u;
+          if (q < GCH && by)
+            atomicOr((uint32_t*)SB + (q >> 2), by << (8u * (q & 3u)));      // (records of one group share its header)
+          }
+        }
+      __syncthreads();
+      vec = *(const u32x4*)(SB + 16u * tid);
+      m16 = (U[tid >> 1] >> (16u * (tid & 1u))) & 0xffffu;
+      }
+    if (sb + 16u > slen)
+      m16 |= sb >= slen ? 0xffffu : (0xffffu << (slen - sb)) & 0xffffu;        // beyond the slot's content
+    uint32_t off, total;
+    const bool plain = !dirty && cb + GCH <= slen;               // (uniform)
+    if (plain)
+      {
+      off = 16u * tid;
+      total = GCH;
+      }
+    else
+      {
+      const uint32_t cnt = 16u - (uint32_t)__popc(m16);
+      const uint32_t incl = wave_scan_incl(cnt);
+      if (lane == 63u)
+        wsum[wv] = incl;
+      __syncthreads();
+      off = incl - cnt;
+      total = 0;
+      for (uint32_t w = 0; w < 4u; ++w)
+        {
+        off += w < wv ? wsum[w] : 0u;
+        total += wsum[w];
+        }
+      }
+    {
+    const uint32_t p = (wpos + off) & (ORING - 1u);
+    if (m16 == 0u && p + 16u <= ORING)
+      {
+      // sixteen bytes in a row, not dword aligned in general (gfx950 executes unaligned LDS dword stores)
+      const uint32_t ad = (uint32_t)(uintptr_t)(lds_u8*)O + p;
+      asm volatile("ds_write_b32 %0, %1\n"
+                   "ds_write_b32 %0, %2 offset:4\n"
+                   "ds_write_b32 %0, %3 offset:8\n"
+                   "ds_write_b32 %0, %4 offset:12"
+                   :: "v"(ad), "v"(vec[0]), "v"(vec[1]), "v"(vec[2]), "v"(vec[3]) : "memory");
+      }
+    else
+      {
+      uint32_t q = p;
+#pragma unroll
+      for (int b = 0; b < 16; ++b)
+        if (!((m16 >> b) & 1u))
+          {
+          O[q] = (uint8_t)(vec[b >> 2] >> (8 * (b & 3)));
+          q = (q + 1u) & (ORING - 1u);
+          }
+      }
+    }
+    wpos += total;
+    __syncthreads();
+    // Whole vectors leave the ring.  No barrier behind the reads: the next chunk writes [wpos, wpos + 4096) with wpos < rpos + 4096
+    // (less than 256 vectors stay behind), which in a ring of 16 KiB cannot reach the 4 KiB read here, and the chunk after that
+    // is behind the next chunk's barrier.
+    while (wpos - rpos >= GCH)
+      {
+      const uint32_t p = rpos + 16u * tid;
+      const u32x4 o = *(const u32x4*)(O + (p & (ORING - 1u)));
+      if (p >= A)
+        __builtin_nontemporal_store(o, (u32x4*)(dbase + p));
+      else
+        for (uint32_t b = A; b < 16u; ++b)                        // the first vector of the segment: its first A bytes are the neighbour's
+          dbase[b] = (uint8_t)(o[b >> 2] >> (8u * (b & 3u)));
+      rpos += GCH;
+      }
+    }
+  // what is left: whole vectors, then the bytes of the last partial one
+  {
+  const uint32_t nvec = (wpos - rpos) >> 4;
+  for (uint32_t t = tid; t < nvec; t += 256u)
+    {
+    const uint32_t p = rpos + 16u * t;
+    const u32x4 o = *(const u32x4*)(O + (p & (ORING - 1u)));
+    if (p >= A)
+      __builtin_nontemporal_store(o, (u32x4*)(dbase + p));
+    else
+      for (uint32_t b = A; b < 16u && b < wpos; ++b)
+        dbase[b] = (uint8_t)(o[b >> 2] >> (8u * (b & 3u)));
+    }
+  const uint32_t p = rpos + 16u * nvec + tid;
+  if (tid < 16u && p < wpos && p >= A)
+    dbase[p] = O[p & (ORING - 1u)];
+  }
+  }
+
+unsigned guard_workgroups(const Plan& p) { return p.S < GUARD_WGS ? p.S : GUARD_WGS; }
+
+} // namespace
+
+int launch_fpc32_sweep(const uint32_t* d_src, uint32_t n, int arity, const Plan& p, uint8_t* d_ws)
+  {
+  hipStream_t st = current_stream();
+  uint32_t* outT = (uint32_t*)(d_ws + p.off_summ);
+  uint32_t* inc = (uint32_t*)(d_ws + p.off_inc);
+  uint32_t* chlast = (uint32_t*)(d_ws + p.off_chmax);
+  uint32_t* segbytes = (uint32_t*)(d_ws + p.off_segbytes);
+  uint32_t* rawbytes = (uint32_t*)(d_ws + p.off_rawbytes);
+  uint32_t* nrec = (uint32_t*)(d_ws + p.off_nrec);
+  uint32_t* recs = (uint32_t*)(d_ws + p.off_recs);
+  uint8_t* slots = d_ws + p.off_slots;
+  uint8_t* gslots = d_ws + p.off_gslots;
+  uint32_t* grecs = (uint32_t*)(d_ws + p.off_grecs);
+  GuardMeta* gmeta = (GuardMeta*)(d_ws + p.off_gmeta);
+  static const uint32_t tune = [] {
+    const char* e = getenv("TRICO_FPC32_PRIO"), * l = getenv("TRICO_FPC32_LAG");
+    return (e ? (uint32_t)atoi(e) & 255u : 1u) | ((l ? (uint32_t)atoi(l) & 255u : 0u) << 8);
+  }();
+  static const bool use_asm = [] { const char* e = getenv("TRICO_FPC32_ASM"); return !(e && e[0] == '0'); }();      // (0: the compiled step, for A/B runs)
+  static std::atomic<uint32_t> encodes{ 0 };
+  const uint32_t seed = encodes.fetch_add(1u) * 0x85EBCA6Bu;                // which segments the guard samples: another set every encode
+  const unsigned threads = 64u * (unsigned)arity;
+  const size_t lds = (size_t)arity * LDSW * 4 + 16;
+  const unsigned G = guard_workgroups(p);
+#ifdef TRICO_HIP_TEST_HOOKS
+  static const uint32_t sabotage = [] { const char* e = getenv("TRICO_HIP_ENCODE_SABOTAGE"); return e ? (uint32_t)atoi(e) : 0u; }();
+  constexpr bool HOOK = true;
+#else
+  const uint32_t sabotage = 0u;
+  constexpr bool HOOK = false;
+#endif
+  if (use_asm)
+    hipLaunchKernelGGL((k_fpc32_sweep<HOOK, true>), dim3(p.S + G), dim3(threads), lds, st, d_src, n, arity, p.L, p.S, outT,
+                       slots, p.slot_stride, p.segcap, segbytes, nrec, recs, tune, sabotage, seed, gslots, grecs, gmeta);
+  else
+    hipLaunchKernelGGL((k_fpc32_sweep<HOOK, false>), dim3(p.S + G), dim3(threads), lds, st, d_src, n, arity, p.L, p.S, outT,
+                       slots, p.slot_stride, p.segcap, segbytes, nrec, recs, tune, sabotage, seed, gslots, grecs, gmeta);
+  const unsigned colblocks = ((unsigned)arity * TAB + 255u) / 256u;
+  hipLaunchKernelGGL(k_fpc32_pscan_a, dim3(colblocks, p.nch), dim3(256), 0, st, outT, p.S, arity, chlast);
+  hipLaunchKernelGGL(k_fpc32_pscan_b, dim3(colblocks, p.nch), dim3(256), 0, st, outT, p.S, arity, chlast, inc);
+  hipLaunchKernelGGL(k_fpc32_fixup, dim3(p.S + G, arity), dim3(256), 0, st, arity, p.S, inc, segbytes, rawbytes, nrec, recs,
+                     slots, p.slot_stride, p.segcap, gslots, grecs, gmeta);
+  return hip_ok(hipGetLastError(), "fpc32 encode kernels (sweep)") ? 1 : 0;
+  }
+
+int launch_fpc32_gather_rec(const Plan& p, int arity, int c0, int count, const uint8_t* d_ws, uint8_t* const d_dst[3])
+  {
+  GatherDst dst = { { d_dst[0], count > 1 ? d_dst[1] : nullptr, count > 2 ? d_dst[2] : nullptr } };
+  hipLaunchKernelGGL(k_fpc32_gather, dim3(p.S, count), dim3(256), 0, current_stream(), d_ws + p.off_slots, p.slot_stride, p.segcap, p.S,
+                     (const uint32_t*)(d_ws + p.off_segbytes), (const uint32_t*)(d_ws + p.off_rawbytes), (const uint32_t*)(d_ws + p.off_segoff),
+                     dst, (const uint32_t*)(d_ws + p.off_nrec), (const uint32_t*)(d_ws + p.off_recs), arity, c0);
+  return hip_ok(hipGetLastError(), "k_fpc32_gather") ? 1 : 0;
+  }
+
+} // namespace fpc32
+} // namespace trico

@@ -166,6 +166,7 @@ ProfSpan::~ProfSpan()
 static int g_device_state = 0;   // 0 unknown, 1 ok, -1 none
 static thread_local uint32_t g_stats[4] = { 0, 0, 0, 0 };      // words 0, 1: the last trico_hip_int_encode of this thread
 static std::atomic<uint32_t> g_repeats{ 0 }, g_other_writer{ 0 };   // words 2, 3: process-wide (a batch may be led by another thread)
+static std::atomic<uint32_t> g_recoded_order{ 0 }, g_recoded_sentinel{ 0 };   // trico_hip_encode_stats
 
 void stats_count_repeat() { g_repeats += 1; }
 void set_current_stream(hipStream_t s) { g_stream = s; }
@@ -510,21 +511,41 @@ int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int
   }
   if (width == 4 && defaults && !force_serial_stage(1) && n != 0)
     {
-    // sizes + the flag of the tagged-table code sweep (k_fpc32_encode.hip): raised, the payloads are not to be trusted
-    uint32_t four[4] = { 0, 0, 0, 0 };
-    if (!read_back_words(ctx, d_sizes, 4, four))
+    // sizes + the flags of the one-sweep coder's waves (k_fpc32_sweep.hip): a sampled step whose LDS exchange was not in lane
+    // order, or a payload equal to the coder's "never written" mark.  Raised, the payloads are not to be trusted: the stream is
+    // coded again by the two-sweep coder with ballots, which depends on neither; a device that showed the first is not asked again.
+    uint32_t six[6] = { 0, 0, 0, 0, 0, 0 };
+    if (!read_back_words(ctx, d_sizes, 6, six))
       return 0;
-    if (four[3] != 0)
+    uint32_t raised = 0;
+    for (int c = 0; c < arity; ++c)
+      raised |= six[3 + c];
+    if (raised != 0)
       {
-      fpc32_distrust_atomic();
+      if (raised & FPC32_FLAG_ORDER)
+        {
+        fpc32_distrust_lane_order();
+        g_recoded_order += 1;
+        }
+      if (raised & FPC32_FLAG_SENTINEL)
+        g_recoded_sentinel += 1;
       if (getenv("TRICO_HIP_DEBUG"))
-        fprintf(stderr, "trico_hip: the LDS unit applied an atomic out of lane order; encoding again with the ballot kernel\n");
-      if (!launch_fpc32_encode(d_src, n, arity, ctx->out.p, stride, d_sizes, ctx->tmp.p, ctx->tmp.cap) || !read_back_words(ctx, d_sizes, 4, four) ||
-          four[3] != 0)
+        fprintf(stderr, "trico_hip: float encoder flags 0x%x (1: LDS exchange out of lane order, 2: payload equals the table mark); "
+                        "coding the stream again with the ballot coder\n", raised);
+      raised = 0;
+      if (!launch_fpc32_encode(d_src, n, arity, ctx->out.p, stride, d_sizes, ctx->tmp.p, ctx->tmp.cap, FPC32_CODER_BALLOT) ||
+          !read_back_words(ctx, d_sizes, 6, six))
         return 0;
+      for (int c = 0; c < arity; ++c)
+        raised |= six[3 + c];
+      if (raised != 0)
+        {
+        set_error("float encoder: the ballot coder raised a flag");
+        return 0;
+        }
       }
     for (int c = 0; c < arity; ++c)
-      ctx->out_sizes[c] = four[c];
+      ctx->out_sizes[c] = six[c];
     }
   else if (!read_back_words(ctx, d_sizes, arity, ctx->out_sizes))
     return 0;
@@ -582,8 +603,9 @@ int fpc_selfcheck_launch(const void* d_vals, uint32_t n, int arity, int width, c
     const size_t ws = fpc32_encode_workspace(n, arity);
     if (!vws.reserve(ws))
       return 0;
-    // (always the ballot kernel: the check does not depend on the order the LDS unit applies atomics in)
-    return launch_fpc32_encode(d_vals, n, arity, nullptr, 0, d_vsizes, vws.p, vws.cap, false) &&
+    // (always the two-sweep coder with ballots: the check depends neither on the order the LDS unit applies an exchange in nor on
+    // anything else the coder that wrote the archive rests on)
+    return launch_fpc32_encode(d_vals, n, arity, nullptr, 0, d_vsizes, vws.p, vws.cap, FPC32_CODER_BALLOT) &&
            launch_fpc32_compare(n, arity, vws.p, d_vsizes, d_pay, sizes, d_status, 0x100u);
     }
   const size_t stride = align_up(fpc_bound(n, 8), 256);
@@ -1224,6 +1246,12 @@ void trico_hip_last_stats(uint32_t out[4])
   out[1] = g_stats[1];
   out[2] = g_repeats.load();
   out[3] = g_other_writer.load();
+  }
+
+void trico_hip_encode_stats(uint32_t out[2])
+  {
+  out[0] = g_recoded_order.load();
+  out[1] = g_recoded_sentinel.load();
   }
 
 void trico_hip_profile_enable(int on) { g_prof_on = on != 0; }
