@@ -43,6 +43,13 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
+def torch_device_count():
+    """Devices this process could use, without initialising any of them (a parent that has touched the GPU must not exec or fork
+    ranks; torch.cuda.device_count() only counts on this image)."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
 def _spawn_ranks_if_needed():
     """`python bench.py --gpus N` without a launcher: start N ranks (fresh processes, one per GPU, RCCL rendezvous on
     127.0.0.1) through torch.distributed.run BEFORE this process touches the GPU, relay their output and exit with their
@@ -57,6 +64,11 @@ def _spawn_ranks_if_needed():
             n = int(a.split("=", 1)[1])
     if n <= 1:
         return
+    have = torch_device_count()
+    if have < n:
+        # (before any rendezvous: N ranks on fewer devices would sit in the RCCL bootstrap until somebody kills them)
+        sys.stderr.write("bench.py: --gpus %d asked for, %d device(s) visible: not started\n" % (n, have))
+        sys.exit(2)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -88,7 +100,7 @@ def _pmc_file_traffic(path):
         m = re.match(r"^\s+(FETCH_SIZE|WRITE_SIZE)\s+(\d+) per dispatch", line)
         if m and kernel and kernel.startswith("k_fpc32"):
             (fetch if m.group(1) == "FETCH_SIZE" else write)[kernel] = float(m.group(2)) * disp[kernel]
-    launches = disp.get("k_fpc32_code", 0)
+    launches = disp.get("k_fpc32_sweep", 0) or disp.get("k_fpc32_code", 0)
     if not fetch or not write or not launches:
         return None
     return int((2.0 * sum(fetch.values()) + sum(write.values())) * 1024.0 / launches)
@@ -133,28 +145,31 @@ def pmc_traffic(mesh, live=True):
 
 def encoder_variants(W, H):
     """The float-vertex encoder alone (tools/perf_fpc32.py: hipEvent span of its launch sequence over the 50 M vertices, 5 timed
-    encodes) as child processes: the default against the opt-in one-sweep encoder (TRICO_FPC32_SWEEPS=1), on both meshes.  Same
-    bytes in every case (tests/test_gpu_onesweep.py); `frac` is algorithmic bytes / span / 8 TB/s like the roofline block."""
+    encodes) as child processes, on both meshes: the library's own choice (the one-sweep coder, k_fpc32_sweep.hip) against the other
+    coders it contains - two sweeps with the exchange (round 3's encoder, TRICO_FPC32_SWEEPS=2) and two sweeps with ballots (what a
+    flagged stream is coded with again and what the decoders' self-check uses, TRICO_FPC32_XCHG=0).  Same bytes in every case
+    (tests/test_gpu_onesweep.py); `frac` is algorithmic bytes / span / 8 TB/s like the roofline block."""
     import re
     rows = []
     for mesh in ("grid", "walk"):
-        for sweeps in ("2", "1"):
-            env = dict(os.environ, TRICO_FPC32_SWEEPS=sweeps)
+        for coder, add in (("default", {}), ("two sweeps, exchange", {"TRICO_FPC32_SWEEPS": "2"}), ("two sweeps, ballots", {"TRICO_FPC32_XCHG": "0"})):
+            env = dict(os.environ)
+            env.update(add)
             try:
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "perf_fpc32.py"), mesh, str(W), str(H)], env=env, timeout=240,
                                    capture_output=True, text=True)
                 m = re.search(r"kernel span avg ([0-9.]+) ms; raw ([0-9.]+) MB comp ([0-9.]+) MB", r.stdout)
                 if r.returncode != 0 or not m:
-                    rows.append({"mesh": mesh, "sweeps": int(sweeps), "error": (r.stdout + r.stderr)[-200:]})
+                    rows.append({"mesh": mesh, "coder": coder, "error": (r.stdout + r.stderr)[-200:]})
                     continue
                 ms, raw, comp = float(m.group(1)), float(m.group(2)), float(m.group(3))
                 gb = (raw + comp) / 1e3 / (ms * 1e-3)
-                rows.append({"mesh": mesh, "sweeps": int(sweeps), "avg_launch_ms": ms, "achieved": round(gb, 1), "unit": "GB/s",
+                rows.append({"mesh": mesh, "coder": coder, "avg_launch_ms": ms, "achieved": round(gb, 1), "unit": "GB/s",
                              "frac": round(gb / HBM_PEAK_GBPS, 5)})
             except Exception as e:      # noqa: BLE001
-                rows.append({"mesh": mesh, "sweeps": int(sweeps), "error": repr(e)[:200]})
-    return {"what": "float-vertex encoder alone, default (two sweeps) vs TRICO_FPC32_SWEEPS=1 (one sweep, opt-in); measured traffic of the "
-                    "one-sweep encoder: profiles/r03c_fpc32_onesweep.txt (2.8 x algorithmic on the grid mesh, 2.1 x on the walk mesh)",
+                rows.append({"mesh": mesh, "coder": coder, "error": repr(e)[:200]})
+    return {"what": "float-vertex encoder alone on both meshes: the library's choice (one sweep) against the two-sweep coders it also "
+                    "contains (environment switches, measurements only); traffic of the default on both meshes: profiles/r04_*",
             "rows": rows}
 
 
@@ -598,6 +613,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    if local_rank >= torch.cuda.device_count() or world > torch.cuda.device_count():
+        # under a launcher: the same check as _spawn_ranks_if_needed, before the rendezvous
+        sys.stderr.write("bench.py: rank %d of %d has no device of its own (%d visible): not started\n" % (rank, world, torch.cuda.device_count()))
+        sys.exit(2)
     if world > 1 or args.shard == "streams":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_PORT", "29531")

@@ -82,7 +82,9 @@ TRICO_API int trico_hip_int_decode(trico_hip_ctx* ctx, const uint8_t* const payl
  * everything is in place.  `payloads[c]` / `dst` may be host or device pointers; dst == NULL skips the job.
  * fp: arity 1..3 components of `width` 4 / 8 bytes, n values per component, payloads[0..arity);
  * int: `width` 1, 2, 4 or 8 byte planes, n integers, payloads[0..width).
- * Returns 1 if every job succeeded; jobs[i].ok says which did (a malformed stream fails alone). */
+ * Returns 1 if every job succeeded; jobs[i].ok says which did: 1 decoded, 0 the stream is malformed or its decode failed (a
+ * malformed stream fails alone), -1 not attempted - the batch as a whole could not run (workspaces, a launch or a copy failed):
+ * nothing is known about the stream, decoding it in a smaller batch or by itself may succeed. */
 typedef struct trico_hip_decode_job
   {
   int32_t is_int, arity, width;
@@ -90,7 +92,7 @@ typedef struct trico_hip_decode_job
   const uint8_t* payloads[8];
   uint32_t sizes[8];
   void* dst;
-  int32_t ok;              /* out */
+  int32_t ok;              /* out: 1, 0 or -1, see above */
   int32_t reserved;
   } trico_hip_decode_job;
 TRICO_API int trico_hip_decode_jobs(trico_hip_decode_job* jobs, int count);

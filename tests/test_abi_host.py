@@ -172,3 +172,47 @@ def test_cmake_package_builds_a_consumer(native_libs, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     r = subprocess.run([str(bld / "consumer")], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip() == "8", r.stdout + r.stderr        # the empty archive: magic + version
+
+
+def test_static_library_links_a_consumer(native_libs, tmp_path):
+    """The reference's default flavour is a static library (reference CMakeLists.txt:19-20, trico/CMakeLists.txt:27-34:
+    TRICO_SHARED=no): trico_amd/lib/libtrico.a holds the same objects as libtrico.so.  A C program links against it (hipcc as the
+    link driver: the archive carries the gfx950 code objects and needs the HIP runtime) and runs the host-only calls."""
+    import subprocess
+    lib = os.path.join(ROOT, "trico_amd", "lib", "libtrico.a")
+    assert os.path.exists(lib)
+    src = tmp_path / "consumer.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <trico/trico.h>
+int main(void)
+  {
+  void* a = trico_open_archive_for_writing(1024);
+  if (!a || trico_get_size(a) != 8 || trico_get_version(a) != 0) return 1;
+  trico_close_archive(a);
+  printf("static ok\n");
+  return 0;
+  }
+''')
+    obj = tmp_path / "consumer.o"
+    exe = tmp_path / "consumer"
+    subprocess.run(["gcc", "-std=c11", "-I" + os.path.join(ROOT, "include"), "-c", str(src), "-o", str(obj)], check=True)
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", str(obj), lib, "-ldl", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "static ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`python bench.py --gpus N` on a box with fewer than N devices (here: none) says so on stderr and exits non-zero within
+    seconds, as a launcher's rank does - instead of sitting in the RCCL rendezvous."""
+    import subprocess
+    import sys
+    import time
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "device(s) visible" in out.stderr and out.stdout.strip() == "", out.stdout + out.stderr
+    env = dict(os.environ, WORLD_SIZE="2", RANK="1", LOCAL_RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=120,
+                         env=env)
+    assert out.returncode != 0 and "no device of its own" in out.stderr, out.stdout + out.stderr
+    assert time.time() - t0 < 100

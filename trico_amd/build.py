@@ -24,6 +24,7 @@ INCLUDE = os.path.join(ROOT, "include")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CC = os.environ.get("CC", "gcc")
 ARCH = "gfx950"
+EXTRA = os.environ.get("TRICO_HIPCC_FLAGS", "").split()      # experiments: extra compiler flags for the HIP sources (e.g. -DTRICO_PF=4)
 
 HOST_C = ["host/archive.c", "host/lowlevel.c"]
 HIP_SRC = sorted(f for f in os.listdir(os.path.join(CSRC, "hip")) if f.endswith(".hip"))
@@ -71,8 +72,8 @@ def build(force=False, verbose=True, test_hooks=False):
         obj = os.path.join(OBJDIR, f + ".o")
         if force or _stale(obj, [src] + headers):
             _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-                  "-Wall", "-Wno-unused-function", "-I" + INCLUDE, "-I" + os.path.join(CSRC, "hip"),
-                  "-c", src, "-o", obj])
+                  "-Wall", "-Wno-unused-function", "-I" + INCLUDE, "-I" + os.path.join(CSRC, "hip")] + EXTRA +
+                 ["-c", src, "-o", obj])
         objs.append(obj)
         if test_hooks and f in HOOKED:
             hobj = os.path.join(OBJDIR, f + ".hooks.o")

@@ -51,6 +51,7 @@ struct trico_hip_ctx
   trico_hip_ctx() { chain.kind = 1; }
   // the decode the self-check belongs to (it may have to be repeated)
   bool chk_active = false;
+  bool other_writer_seen = false;      // a stream of this context decoded to values that do not code back even in reference order
   const uint8_t* chk_pay[3] = { nullptr, nullptr, nullptr };
   uint32_t chk_sizes[3] = { 0, 0, 0 };
   int chk_arity = 0, chk_width = 0;

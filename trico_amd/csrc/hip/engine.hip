@@ -433,6 +433,8 @@ static int run_batch(trico_hip_decode_job* jobs, int count)
       {
       if (kind[i] == K_BAD)
         set_error("trico_hip_decode_jobs: bad job");
+      else
+        j.ok = -1;                                // not attempted (workspaces, a launch or a copy failed): nothing is known about the stream
       all_ok = 0;
       continue;
       }
@@ -554,8 +556,16 @@ int trico_hip_decode_jobs(trico_hip_decode_job* jobs, int count)
       at = 0;
       for (Waiter* w = batch; w; w = w->next)
         {
+        bool attempted = true;
         for (int i = 0; i < w->count; ++i)
+          {
           w->jobs[i].ok = all[at + i].ok;
+          attempted = attempted && all[at + i].ok >= 0;
+          }
+        // the combined batch could not be launched (its workspaces are the sum of everybody's): one caller's resource problem is
+        // not the others' - every caller's jobs run again as a batch of their own
+        if (!attempted)
+          (void)run_batch(w->jobs, w->count);
         at += w->count;
         }
       free(all);
@@ -567,7 +577,7 @@ int trico_hip_decode_jobs(trico_hip_decode_job* jobs, int count)
     Waiter* nx = w->next;                       // (a follower's Waiter lives on its stack: gone once it is woken with done set)
     int r = result_all < 0 ? 0 : 1;
     for (int i = 0; r && i < w->count; ++i)
-      r = w->jobs[i].ok ? 1 : 0;
+      r = w->jobs[i].ok > 0 ? 1 : 0;
     w->result = r;
     w->done = true;
     w = nx;

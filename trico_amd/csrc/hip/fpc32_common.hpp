@@ -73,7 +73,7 @@ inline Plan make_plan(uint32_t n, int arity)
   p.off_segoff = o;    o += align_up(p.rows * 4, 256);
   p.off_gslots = o;    o += align_up((size_t)GUARD_WGS * arity * GUARD_SLOT, 256);
   p.off_grecs = o;     o += align_up((size_t)GUARD_WGS * arity * RCAP * RECW * 4, 256);
-  p.off_gmeta = o;     o += align_up((size_t)GUARD_WGS * arity * 16, 256);
+  p.off_gmeta = o;     o += align_up((size_t)GUARD_WGS * 3 * 16, 256);
   p.off_slots = o;     o += p.slot_stride * arity;
   p.total = o + 256;
   return p;

@@ -35,7 +35,10 @@ namespace fpc32 {
 
 namespace {
 
-constexpr int PF = 8;                             // steps (of 64 values) whose loads are kept in flight per wave
+#ifndef TRICO_PF
+#define TRICO_PF 6
+#endif
+constexpr int PF = TRICO_PF;                      // steps (of 64 values) whose loads are kept in flight per wave
 constexpr int STAGE_LIVE = 544;                   // < 256 unflushed + <= 280 of the step, rounded
 constexpr int STAGE = STAGE_LIVE + 256;           // + 4 dump bytes per lane
 constexpr int LDSW = 1248;                        // per-wave LDS words: TAB + STAGE / 4 = 1240, rounded so that every wave's table starts
@@ -51,7 +54,7 @@ typedef __attribute__((address_space(3))) volatile uint8_t lds_vu8;
 struct LaneK                                      // per-lane constants
   {
   uint32_t lane, lane4;
-  uint32_t sh3, grp3;
+  uint32_t sh3, grp3, c4sh;                       // 3 * (lane % 8), 3 * (lane / 8), 4 << sh3
   uint32_t pat5;                                  // this lane's dword of the 88-byte pattern of a step of 64 exact DFCM hits
   bool lead;
   };
@@ -65,20 +68,29 @@ struct Sweep                                      // running state of a wave
   uint32_t fw0, ft;                               // ... per lane: its word of the block and of what moves to the front
   uint32_t nrec;                                  // records written so far
   uint32_t flags;                                 // FLAG_* raised by this wave
+  uint64_t sent;                                  // lanes that stored the sentinel as a payload, in any step (code_step_asm)
+  uint32_t ustate, ustride;                       // 24 / 88: the previous step was a constant one of that size (see step_uniform_asm); its stride
   };
 
 constexpr uint32_t DUMP = STAGE_LIVE + 1;          // a lane's four dump bytes: stage + DUMP - 1 + 4 * lane
 
+// Global memory goes through buffer descriptors: scalar base + scalar offset + the lane's constant offset, so that neither the
+// rolling prefetch nor the flush costs a vector instruction for its address, and loads past the end of the array return zeros
+// instead of needing bounds code.  (Word 3 as for every raw 32-bit buffer on gfx9.)
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint64_t bytes)
+  {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : (uint32_t)bytes), 0x00020000);
+  }
+
 // second half of a flush (see flush_begin): the word read from the staging area a step ago goes to the slot, the unflushed rest
 // moves to the front.  Must run before the next byte is staged.
-__device__ __forceinline__ void flush_end(Sweep& sw, uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase, const LaneK& lk)
+__device__ __forceinline__ void flush_end(Sweep& sw, uint8_t* __restrict__ stage, rsrc_t slot, const LaneK& lk)
   {
   if (sw.fl_nb)
     {
     // (streaming stores: the slot is read again only by the gather, and the lines should not push the input out of the L2)
-    uint32_t off = lk.lane4;
-    asm volatile("" : "+v"(off));                  // (keeps the 32-bit offset in this block: scalar base + vector offset addressing)
-    __builtin_nontemporal_store(sw.fw0, (uint32_t*)(gbase + sw.fl_off + off));
+    __builtin_amdgcn_raw_buffer_store_b32(sw.fw0, slot, lk.lane4, sw.fl_off, 2);
     ((uint32_t*)stage)[lk.lane] = sw.ft;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     sw.fl_nb = 0u;
@@ -86,24 +98,29 @@ __device__ __forceinline__ void flush_end(Sweep& sw, uint8_t* __restrict__ stage
   }
 
 // first half of a flush: a full 256-byte block goes to the slot as aligned dwords, the rest moves to the front of the staging area.
-// Only the LDS reads are issued here; their data is used by flush_end() in the next step, right before its first byte is staged
-// (LDS operations of a wave execute in order), so the wave never waits for the round trip.  Two full blocks at once (a step of
-// more than 256 bytes on top of nearly 256) are rare: the first one leaves on the spot.
-__device__ __forceinline__ void flush_begin(Sweep& sw, const uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase, const LaneK& lk)
+// Only the LDS reads are issued here - in every step, wanted or not: two reads cost no vector instruction, a choice would - and
+// their data is used by flush_end() in the next step, right before its first byte is staged (LDS operations of a wave execute in
+// order), so the wave never waits for the round trip.  Two full blocks at once (a step of more than 256 bytes on top of nearly 256)
+// are rare: the first one leaves on the spot.
+__device__ __forceinline__ void flush_begin(Sweep& sw, uint8_t* __restrict__ stage, rsrc_t slot, const LaneK& lk)
   {
+  uint32_t* stw = (uint32_t*)stage;
+  if (sw.posl >= 512u)
+    {
+    __builtin_amdgcn_raw_buffer_store_b32(stw[lk.lane], slot, lk.lane4, sw.flushed, 2);
+    const uint32_t w1 = stw[64u + lk.lane], w2 = stw[128u + lk.lane];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    stw[lk.lane] = w1;
+    stw[64u + lk.lane] = w2;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    sw.flushed += 256u;
+    sw.posl -= 256u;
+    }
+  sw.fw0 = stw[lk.lane];
+  sw.ft = stw[64u + lk.lane];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (sw.posl >= 256u)
     {
-    const uint32_t* stw = (const uint32_t*)stage;
-    uint32_t first = 0;
-    if (sw.posl >= 512u)
-      {
-      *(uint32_t*)(gbase + sw.flushed + lk.lane4) = stw[lk.lane];
-      sw.flushed += 256u;
-      first = 64u;
-      }
-    sw.fw0 = stw[first + lk.lane];
-    sw.ft = stw[first + 64u + lk.lane];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     sw.fl_nb = 1u;
     sw.fl_off = sw.flushed;
     sw.flushed += 256u;
@@ -317,7 +334,7 @@ __device__ __forceinline__ void step_general(uint32_t v, uint32_t a, uint32_t s,
 // and the stream).  The last step of a stream takes this path, the guard workgroups (BALLOT), and every step under TRICO_FPC32_ASM=0.
 template <bool FULL, bool BALLOT, bool HOOK>
 __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_end, uint32_t n, uint32_t t1abs,
-                                          uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase, Sweep& sw, const LaneK& lk,
+                                          uint8_t* __restrict__ stage, rsrc_t slot, Sweep& sw, const LaneK& lk,
                                           const RecSink& sink, uint32_t sabotage)
   {
   const uint32_t i = i0 + lk.lane;
@@ -337,7 +354,7 @@ __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_en
   if (!FULL) { st1 = st1 && act; st2 = st2 && act; }
   const bool any1 = __ballot(st1) != 0ull, any2 = __ballot(st2) != 0ull;
   const uint32_t sbase = (uint32_t)(uintptr_t)(lds_u8*)stage;        // LDS address of the staging area (uniform)
-  flush_end(sw, stage, gbase, lk);
+  flush_end(sw, stage, slot, lk);
   // Every value continues its runs and every prediction is exact: the 64 values are a constant - eight groups of a zero header
   // (FCM hit: code 0, no byte), or of header b6 db 6d and eight zero bytes (DFCM hit: code 5, residual byte 0x00; it is the choice
   // only if the FCM residual needs more than one byte, fpsc.c:146-189).  One LDS store, no byte layout.
@@ -359,7 +376,7 @@ __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_en
   else
     step_general<FULL, BALLOT, HOOK>(v, a, s, s1, a1, a2, st1, st2, any1, any2, act, i, i_end, n, t1abs, sbase, sw, lk, sink, sabotage);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  flush_begin(sw, stage, gbase, lk);
+  flush_begin(sw, stage, slot, lk);
   sw.vp = v; sw.sp = s; sw.s1p = s1; sw.a1p = a1; sw.a2p = a2;
   }
 
@@ -370,6 +387,7 @@ __device__ __forceinline__ LaneK lane_constants(uint32_t lane)
   lk.lane4 = 4u * lane;
   lk.sh3 = 3u * (lane & 7u);
   lk.grp3 = 3u * (lane >> 3);
+  lk.c4sh = 4u << lk.sh3;
   lk.lead = (lane & 7u) == 0u;
   uint32_t w = 0;
   for (uint32_t b = 0; b < 4u; ++b)
@@ -394,13 +412,11 @@ __device__ __forceinline__ LaneK lane_constants(uint32_t lane)
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uint32_t)(x >> 32)) << 32) | uni((uint32_t)x); }
 
-// head: classes, run starts, and the constant step.  done = 1: the step is coded (24 or 88 bytes staged, posl advanced).
-__device__ __forceinline__ uint32_t step_head_asm(uint32_t v, const Sweep& sw, uint32_t t1abs, uint32_t posl_abs, const LaneK& lk,
-                                                  uint32_t& a, uint32_t& s, uint32_t& s1, uint32_t& a1, uint32_t& a2,
-                                                  uint64_t& st1, uint64_t& st2, uint32_t& no1, uint32_t& no2, uint32_t& adv)
+// head: classes and run starts.  no1 / no2 = 1: no run of FCM / DFCM classes starts in this step.
+__device__ __forceinline__ void step_head_asm(uint32_t v, const Sweep& sw, uint32_t t1abs, uint32_t& a, uint32_t& s, uint32_t& s1,
+                                              uint32_t& a1, uint32_t& a2, uint64_t& st1, uint64_t& st2, uint32_t& no1, uint32_t& no2)
   {
-  uint32_t s2, q1, q2, t, u, x1, x2, done;
-  uint64_t nz1, nz2;
+  uint32_t s2, q1, q2, t, u;
   asm volatile(
     "s_nop 1\n"
     "v_mov_b32_dpp %[a], %[vp] wave_ror:1 row_mask:0xf bank_mask:0xf\n"
@@ -413,69 +429,76 @@ __device__ __forceinline__ uint32_t step_head_asm(uint32_t v, const Sweep& sw, u
     "v_lshrrev_b32 %[t], 26, %[a]\n"
     "v_and_or_b32 %[a1], %[t], 60, %[t1]\n"                                        // FCM entry: table + 4 * (top four bits of v[i-1])
     "v_mov_b32_dpp %[s1], %[s] wave_shr:1 row_mask:0xf bank_mask:0xf\n"          // stride of v[i-1]
-    "v_xor_b32 %[x1], %[v], %[a]\n"
+    "s_nop 0\n"
     "v_mov_b32_dpp %[q1], %[a1] wave_shr:1 row_mask:0xf bank_mask:0xf\n"
     "v_lshrrev_b32 %[u], 22, %[s1]\n"
-    "v_add_u32 %[t], %[a], %[s1]\n"
     "v_mov_b32_dpp %[s2], %[s1] wave_shr:1 row_mask:0xf bank_mask:0xf\n"         // stride of v[i-2]
     "v_cmp_ne_u32_e64 %[st1], %[a1], %[q1]\n"
-    "v_xor_b32 %[x2], %[v], %[t]\n"
     "v_lshrrev_b32 %[t], 17, %[s2]\n"
     "v_bitop3_b32 %[t], %[t], %[u], %[k3e0] bitop3:0x6c\n"                         // ((s2 >> 17) & 0x3e0) ^ (s1 >> 22): the DFCM class
     "v_lshl_add_u32 %[a2], %[t], 2, %[t2]\n"
-    "v_cmp_ne_u32_e64 %[nz1], 0, %[x1]\n"
-    "v_cmp_ne_u32_e64 %[nz2], 0, %[x2]\n"
-    "v_mov_b32_dpp %[q2], %[a2] wave_shr:1 row_mask:0xf bank_mask:0xf\n"
-    "v_cmp_gt_u32_e32 vcc, 0x100, %[x1]\n"
-    "v_cmp_ne_u32_e64 %[st2], %[a2], %[q2]\n"
-    "s_mov_b32 %[done], 0\n"
-    "s_mov_b32 %[adv], 0\n"
     "s_cmp_eq_u64 %[st1], 0\n"
-    "s_cselect_b32 %[no1], 1, 0\n"                                                 // 1: no run of FCM classes starts in this step
+    "s_cselect_b32 %[no1], 1, 0\n"
+    "v_mov_b32_dpp %[q2], %[a2] wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+    "v_cmp_ne_u32_e64 %[st2], %[a2], %[q2]\n"
     "s_cmp_eq_u64 %[st2], 0\n"
     "s_cselect_b32 %[no2], 1, 0\n"
-    "s_or_b64 %[nz2], %[nz2], vcc\n"                                               // a lane that is not an exact DFCM hit with a long FCM residual
-    "s_or_b64 vcc, %[st1], %[st2]\n"
-    "s_cmp_lg_u64 vcc, 0\n"
-    "s_cbranch_scc1 .Lhead_end_%=\n"                                               // some run starts: tables
-    "s_cmp_eq_u64 %[nz1], 0\n"
-    "s_cbranch_scc1 .Lhead_u0_%=\n"
-    "s_cmp_lg_u64 %[nz2], 0\n"
-    "s_cbranch_scc1 .Lhead_end_%=\n"
-    "s_mov_b64 exec, 0x3fffff\n"                                                   // 64 exact DFCM hits: 88 bytes, 22 dwords
-    "v_add_u32 %[t], %[posl], %[lane4]\n"
-    "s_mov_b32 %[adv], 88\n"
-    "ds_write_b32 %[t], %[pat5]\n"
-    "s_branch .Lhead_done_%=\n"
-    ".Lhead_u0_%=:\n"
-    "s_mov_b64 exec, 0x3f\n"                                                       // 64 exact FCM hits: 24 zero bytes (x1 is zero in every lane)
-    "v_add_u32 %[t], %[posl], %[lane4]\n"
-    "s_mov_b32 %[adv], 24\n"
-    "ds_write_b32 %[t], %[x1]\n"
-    ".Lhead_done_%=:\n"
-    "s_mov_b64 exec, -1\n"
-    "s_mov_b32 %[done], 1\n"
-    ".Lhead_end_%=:\n"
     : [a] "=&v"(a), [s] "=&v"(s), [s1] "=&v"(s1), [s2] "=&v"(s2), [a1] "=&v"(a1), [a2] "=&v"(a2), [q1] "=&v"(q1), [q2] "=&v"(q2),
-      [t] "=&v"(t), [u] "=&v"(u), [x1] "=&v"(x1), [x2] "=&v"(x2), [st1] "=&s"(st1), [st2] "=&s"(st2), [nz1] "=&s"(nz1), [nz2] "=&s"(nz2),
-      [done] "=&s"(done), [adv] "=&s"(adv), [no1] "=&s"(no1), [no2] "=&s"(no2)
+      [t] "=&v"(t), [u] "=&v"(u), [st1] "=&s"(st1), [st2] "=&s"(st2), [no1] "=&s"(no1), [no2] "=&s"(no2)
     : [v] "v"(v), [vp] "v"(sw.vp), [sp] "v"(sw.sp), [s1p] "v"(sw.s1p), [a1p] "v"(sw.a1p), [a2p] "v"(sw.a2p), [t1] "s"(t1abs),
-      [t2] "s"(t1abs + 64u), [k3e0] "s"(0x3e0u), [posl] "s"(posl_abs), [lane4] "v"(lk.lane4), [pat5] "v"(lk.pat5)
-    : "vcc", "scc", "memory");
+      [t2] "s"(t1abs + 64u), [k3e0] "s"(0x3e0u)
+    : "scc", "memory");
   st1 = uni(st1);
   st2 = uni(st2);
   no1 = uni(no1);
   no2 = uni(no2);
-  adv = uni(adv);
-  return uni(done);
+  }
+
+// The constant step (no run starts): every prediction exact -> 24 or 88 bytes staged with one store.  Returns the bytes staged, 0 if
+// the step is not one.
+__device__ __forceinline__ uint32_t step_const_asm(uint32_t v, uint32_t a, uint32_t s1, uint32_t posl_abs, const LaneK& lk)
+  {
+  uint32_t x1, x2, t, adv;
+  uint64_t nz1, nz2;
+  asm volatile(
+    "v_xor_b32 %[x1], %[v], %[a]\n"
+    "v_add_u32 %[t], %[a], %[s1]\n"
+    "v_cmp_ne_u32_e64 %[nz1], 0, %[x1]\n"
+    "v_xor_b32 %[x2], %[v], %[t]\n"
+    "v_cmp_gt_u32_e32 vcc, 0x100, %[x1]\n"
+    "v_cmp_ne_u32_e64 %[nz2], 0, %[x2]\n"
+    "s_mov_b32 %[adv], 0\n"
+    "s_cmp_eq_u64 %[nz1], 0\n"
+    "s_cbranch_scc1 .Lconst_u0_%=\n"
+    "s_or_b64 %[nz2], %[nz2], vcc\n"                                               // a lane that is not an exact DFCM hit with a long FCM residual
+    "s_cmp_lg_u64 %[nz2], 0\n"
+    "s_cbranch_scc1 .Lconst_end_%=\n"
+    "s_mov_b64 exec, 0x3fffff\n"                                                   // 64 exact DFCM hits: 88 bytes, 22 dwords
+    "v_add_u32 %[t], %[posl], %[lane4]\n"
+    "s_mov_b32 %[adv], 88\n"
+    "ds_write_b32 %[t], %[pat5]\n"                                                 // (not dword aligned: gfx950 executes it)
+    "s_branch .Lconst_done_%=\n"
+    ".Lconst_u0_%=:\n"
+    "s_mov_b64 exec, 0x3f\n"                                                       // 64 exact FCM hits: 24 zero bytes (x1 is zero in every lane)
+    "v_add_u32 %[t], %[posl], %[lane4]\n"
+    "s_mov_b32 %[adv], 24\n"
+    "ds_write_b32 %[t], %[x1]\n"
+    ".Lconst_done_%=:\n"
+    "s_mov_b64 exec, -1\n"
+    ".Lconst_end_%=:\n"
+    : [x1] "=&v"(x1), [x2] "=&v"(x2), [t] "=&v"(t), [nz1] "=&s"(nz1), [nz2] "=&s"(nz2), [adv] "=&s"(adv)
+    : [v] "v"(v), [a] "v"(a), [s1] "v"(s1), [posl] "s"(posl_abs), [lane4] "v"(lk.lane4), [pat5] "v"(lk.pat5)
+    : "vcc", "scc", "memory");
+  return uni(adv);
   }
 
 // one predictor's run starts (see resolve_h): pending write, exchange by the lanes where a run starts or ends, prediction of the
-// starts.  ft = starts that met an entry nobody wrote in this segment; sent collects the lanes whose payload is the sentinel.
-__device__ __forceinline__ void resolve_asm(uint32_t ad, uint32_t adp, uint32_t pay, uint32_t payp, uint64_t st, uint32_t pend,
-                                            uint32_t& p, uint64_t& ft, uint64_t& sent)
+// starts (the others keep pdef).  ft = starts that met an entry nobody wrote in this segment; sent collects the lanes whose payload
+// is the sentinel.
+__device__ __forceinline__ uint32_t resolve_asm(uint32_t ad, uint32_t adp, uint32_t pay, uint32_t payp, uint32_t pdef, uint64_t st,
+                                                uint32_t pend, uint64_t& ft, uint64_t& sent)
   {
-  uint32_t old;
+  uint32_t old, p;
   asm volatile(
     "s_cmp_eq_u32 %[pend], 0\n"
     "s_cbranch_scc1 .Lres_np_%=\n"
@@ -494,22 +517,24 @@ __device__ __forceinline__ void resolve_asm(uint32_t ad, uint32_t adp, uint32_t 
     "v_cmp_eq_u32_e32 vcc, %[ksent], %[pay]\n"
     "s_or_b64 %[sent], %[sent], vcc\n"
     "s_waitcnt lgkmcnt(0)\n"
-    "v_cndmask_b32_e64 %[p], %[p], %[old], %[st]\n"
+    "v_cndmask_b32_e64 %[p], %[pdef], %[old], %[st]\n"
     "v_cmp_eq_u32_e32 vcc, %[ksent], %[old]\n"
     "s_and_b64 %[ft], vcc, %[st]\n"
-    : [p] "+v"(p), [old] "=&v"(old), [ft] "=&s"(ft), [sent] "+s"(sent)
-    : [ad] "v"(ad), [adp] "v"(adp), [pay] "v"(pay), [payp] "v"(payp), [st] "s"(st), [pend] "s"(pend), [ksent] "s"(SENT)
+    : [p] "=&v"(p), [old] "=&v"(old), [ft] "=&s"(ft), [sent] "+s"(sent)
+    : [ad] "v"(ad), [adp] "v"(adp), [pay] "v"(pay), [payp] "v"(payp), [pdef] "v"(pdef), [st] "s"(st), [pend] "s"(pend), [ksent] "s"(SENT)
     : "vcc", "scc", "memory");
   ft = uni(ft);
   sent = uni(sent);
+  return p;
   }
 
 // residual selection, byte layout, byte stores of a full step (see step_tail); hole = the lanes whose value is deferred (four zero
-// bytes, code 0).  Returns the bytes staged; hq = LDS address of the lane's group header, pre = residual bytes of the lanes below.
-__device__ __forceinline__ uint32_t tail_asm(uint32_t v, uint32_t a, uint32_t p1, uint32_t p2, uint64_t hole, uint32_t posl_abs,
-                                             const LaneK& lk, uint32_t& hq, uint32_t& pre)
+// bytes, code 0).  posl1 = LDS address of the first free staging byte - 1.  Returns the bytes staged; for the records: hq1 = LDS
+// address of the lane's group header - 1, inc = residual bytes of the lanes up to and including this one, len = of this one.
+__device__ __forceinline__ uint32_t tail_asm(uint32_t v, uint32_t a, uint32_t p1, uint32_t p2, uint64_t hole, uint32_t posl1,
+                                             const LaneK& lk, uint32_t& hq1, uint32_t& inc, uint32_t& len)
   {
-  uint32_t x1, x2, c1, c2, len, x, code, inc, bc, t, total;
+  uint32_t x1, x2, c1, c2, x, bc, t, total;
   uint64_t nzl;
   asm volatile(
     "v_xor_b32 %[x1], %[v], %[p1]\n"                                               // FCM residual
@@ -525,69 +550,67 @@ __device__ __forceinline__ uint32_t tail_asm(uint32_t v, uint32_t a, uint32_t p1
     "v_max_u32 %[t], %[c1], %[c2]\n"
     "v_cndmask_b32_e32 %[x], %[x1], %[x2], vcc\n"
     "v_sub_u32 %[len], 4, %[t]\n"
-    "v_cndmask_b32_e64 %[t], 0, 4, vcc\n"
-    "v_add_u32 %[code], %[len], %[t]\n"
+    "v_cndmask_b32_e32 %[t], 0, %[c4sh], vcc\n"                                    // code = length, + 4 for DFCM: already at the code's place in the header
+    "v_lshl_or_b32 %[bc], %[len], %[sh3], %[t]\n"
     "s_cmp_eq_u64 %[hole], 0\n"
     "s_cbranch_scc1 .Ltail_nh_%=\n"
     "v_cndmask_b32_e64 %[len], %[len], 4, %[hole]\n"                               // deferred values: four zero bytes, code 0
-    "v_cndmask_b32_e64 %[code], %[code], 0, %[hole]\n"
+    "v_cndmask_b32_e64 %[bc], %[bc], 0, %[hole]\n"
     "v_cndmask_b32_e64 %[x], %[x], 0, %[hole]\n"
     "s_nop 0\n"
     ".Ltail_nh_%=:\n"
-    "v_lshrrev_b32 %[x1], 24, %[x]\n"                                              // (x1, x2 from here on: bytes 3 and 1 of the residual)
-    "v_lshlrev_b32 %[bc], %[sh3], %[code]\n"
-    "v_add_u32_dpp %[inc], %[len], %[len] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-    "v_lshrrev_b32 %[x2], 8, %[x]\n"
-    "v_cmp_ne_u32_e64 %[nzl], 0, %[len]\n"
-    "v_add_u32_dpp %[inc], %[inc], %[inc] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    "v_perm_b32 %[x1], %[x], %[x], %[kswap]\n"                                     // (x1 from here on: the residual, bytes reversed)
     "v_or_b32_dpp %[bc], %[bc], %[bc] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-    "s_nop 0\n"
-    "v_add_u32_dpp %[inc], %[inc], %[inc] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    "v_add_u32_dpp %[inc], %[len], %[len] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    "v_cmp_ne_u32_e64 %[nzl], 0, %[len]\n"
     "v_or_b32_dpp %[bc], %[bc], %[bc] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    "v_add_u32_dpp %[inc], %[inc], %[inc] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
     "s_nop 0\n"
-    "v_add_u32_dpp %[inc], %[inc], %[inc] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
     "v_or_b32_dpp %[bc], %[bc], %[bc] row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-    "s_nop 0\n"
-    "v_add_u32_dpp %[inc], %[inc], %[inc] row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+    "v_add_u32_dpp %[inc], %[inc], %[inc] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    "s_nop 1\n"
+    "v_add_u32_dpp %[inc], %[inc], %[inc] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
     "v_lshrrev_b32 %[t], 8, %[bc]\n"
     "s_nop 0\n"
+    "v_add_u32_dpp %[inc], %[inc], %[inc] row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+    "s_nop 1\n"
     "v_add_u32_dpp %[inc], %[inc], %[inc] row_bcast:31 row_mask:0xc bank_mask:0xf\n"       // inclusive sum of the lengths
-    "v_sub_u32 %[pre], %[inc], %[len]\n"                                           // bytes of the residuals below my lane
-    "v_add3_u32 %[hq], %[posl], %[grp3], %[pre]\n"                                 // my group's header, my residual behind it at hq + 3
-    "v_add3_u32 %[c2], %[hq], %[len], -1\n"                                        // the four bytes that END with my residual's last byte
+    "v_add3_u32 %[c2], %[posl1], %[grp3], %[inc]\n"                                // the four bytes that END with my residual's last byte
+    "v_sub_u32 %[hq1], %[c2], %[len]\n"                                            // my group's header - 1 (my residual begins 4 behind it)
     "v_readlane_b32 %[total], %[inc], 63\n"
     "s_mov_b64 exec, %[nzl]\n"
     "ds_write_b8 %[c2], %[x1]\n"                                                   // most significant byte first, in this order (see step_tail)
     "ds_write_b8_d16_hi %[c2], %[x] offset:1\n"
-    "ds_write_b8 %[c2], %[x2] offset:2\n"
+    "ds_write_b8_d16_hi %[c2], %[x1] offset:2\n"
     "ds_write_b8 %[c2], %[x] offset:3\n"
     "s_mov_b64 exec, %[lead]\n"
-    "ds_write_b8_d16_hi %[hq], %[bc]\n"                                            // three header bytes, big-endian, by the lanes that lead a group
-    "ds_write_b8 %[hq], %[t] offset:1\n"
-    "ds_write_b8 %[hq], %[bc] offset:2\n"
+    "ds_write_b8_d16_hi %[hq1], %[bc] offset:1\n"                                  // three header bytes, big-endian, by the lanes that lead a group
+    "ds_write_b8 %[hq1], %[t] offset:2\n"
+    "ds_write_b8 %[hq1], %[bc] offset:3\n"
     "s_mov_b64 exec, -1\n"
     "s_add_u32 %[total], %[total], 24\n"
-    : [x1] "=&v"(x1), [x2] "=&v"(x2), [c1] "=&v"(c1), [c2] "=&v"(c2), [len] "=&v"(len), [x] "=&v"(x), [code] "=&v"(code),
-      [inc] "=&v"(inc), [bc] "=&v"(bc), [hq] "=&v"(hq), [pre] "=&v"(pre), [t] "=&v"(t), [total] "=&s"(total), [nzl] "=&s"(nzl)
-    : [v] "v"(v), [a] "v"(a), [p1] "v"(p1), [p2] "v"(p2), [posl] "s"(posl_abs), [grp3] "v"(lk.grp3), [sh3] "v"(lk.sh3),
-      [lead] "s"(0x0101010101010101ull), [hole] "s"(hole)
+    : [x1] "=&v"(x1), [x2] "=&v"(x2), [c1] "=&v"(c1), [c2] "=&v"(c2), [len] "=&v"(len), [x] "=&v"(x),
+      [inc] "=&v"(inc), [bc] "=&v"(bc), [hq1] "=&v"(hq1), [t] "=&v"(t), [total] "=&s"(total), [nzl] "=&s"(nzl)
+    : [v] "v"(v), [a] "v"(a), [p1] "v"(p1), [p2] "v"(p2), [posl1] "s"(posl1), [grp3] "v"(lk.grp3), [sh3] "v"(lk.sh3), [c4sh] "v"(lk.c4sh),
+      [lead] "s"(0x0101010101010101ull), [hole] "s"(hole), [kswap] "s"(0x00010203u)
     : "vcc", "scc", "memory");
   return uni(total);
   }
 
 // the records of a step's deferred values (see step_tail)
 __device__ __forceinline__ void write_records(uint64_t ft1, uint64_t ft2, uint32_t v, uint32_t a, uint32_t a1, uint32_t a2, uint32_t p1,
-                                              uint32_t p2, uint32_t hq, uint32_t pre, uint32_t t1abs, uint32_t sbase, Sweep& sw,
+                                              uint32_t p2, uint32_t hq1, uint32_t inc, uint32_t len, uint32_t t1abs, uint32_t sbase, Sweep& sw,
                                               const LaneK& lk, const RecSink& sink)
   {
   const uint64_t hm = ft1 | ft2;
   const bool f1 = (ft1 >> lk.lane) & 1ull, f2 = (ft2 >> lk.lane) & 1ull;
+  const uint32_t pre = inc - len;
   const uint32_t pre_lead = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lk.lane & ~7u) << 2), (int)pre);
   const uint32_t idx = sw.nrec + popc_below(hm);
   if (f1 || f2)
     {
     u32x4 w;
-    w[0] = sw.flushed + (hq - sbase) + 3u;
+    w[0] = sw.flushed + (hq1 + 1u - sbase) + 3u;
     w[1] = (3u + pre - pre_lead) | ((lk.lane & 7u) << 8) | ((uint32_t)f1 << 12) | ((uint32_t)f2 << 13) | (((a1 >> 2) & 15u) << 16) |
            (((a2 - (t1abs + 64u)) >> 2) << 20);
     w[2] = v;
@@ -599,28 +622,108 @@ __device__ __forceinline__ void write_records(uint64_t ft1, uint64_t ft2, uint32
   sw.nrec += (uint32_t)__popcll(hm);
   }
 
+// A constant step BEHIND a constant step of the same kind - the rows of a grid, the flat parts of a scan - needs neither classes nor
+// run starts.  After 64 exact DFCM hits (88 bytes) every stride of the step was the same S, and so was the stride before it: the
+// DFCM class of every value of the next step is f(S, S) as long as its strides are S again, the value two back is a - S, and the
+// step is another 64 hits iff  stride == S,  top four bits of a == top four bits of a - S (no FCM run start),  v ^ a >= 256  in
+// every lane: 9 vector instructions instead of 26.  After 64 exact FCM hits (24 bytes) all values were equal, all strides 0: the
+// next step is the same iff v == a in every lane.  Only vp is kept up to date in such a stretch; the step that ends it rebuilds the
+// other registers the head wants (uniform_leave).  Returns the bytes staged, 0 if the step is not one.
+__device__ __forceinline__ uint32_t step_uniform_asm(uint32_t v, uint32_t vp, uint32_t state, uint32_t S, uint32_t posl_abs, const LaneK& lk)
+  {
+  uint32_t a, t, x1, adv;
+  uint64_t m;
+  asm volatile(
+    "s_nop 1\n"
+    "v_mov_b32_dpp %[a], %[vp] wave_ror:1 row_mask:0xf bank_mask:0xf\n"
+    "s_mov_b32 %[adv], 0\n"
+    "s_cmp_eq_u32 %[state], 24\n"
+    "v_mov_b32_dpp %[a], %[v] wave_shr:1 row_mask:0xf bank_mask:0xf\n"          // a = v[i-1]
+    "v_xor_b32 %[x1], %[v], %[a]\n"
+    "s_cbranch_scc1 .Luni_zero_%=\n"
+    "v_sub_u32 %[t], %[v], %[a]\n"                                                 // stride of v[i]
+    "v_cmp_ne_u32_e64 %[m], %[S], %[t]\n"
+    "v_subrev_u32 %[t], %[S], %[a]\n"                                              // v[i-2], if the strides are what they were
+    "v_cmp_gt_u32_e32 vcc, 0x100, %[x1]\n"
+    "v_xor_b32 %[t], %[t], %[a]\n"
+    "s_or_b64 %[m], %[m], vcc\n"
+    "v_cmp_lt_u32_e32 vcc, 0xfffffff, %[t]\n"                                      // v[i-2] and v[i-1] in different FCM classes
+    "s_or_b64 %[m], %[m], vcc\n"
+    "s_cmp_lg_u64 %[m], 0\n"
+    "s_cbranch_scc1 .Luni_end_%=\n"
+    "s_mov_b64 exec, 0x3fffff\n"
+    "v_add_u32 %[t], %[posl], %[lane4]\n"
+    "s_mov_b32 %[adv], 88\n"
+    "ds_write_b32 %[t], %[pat5]\n"                                                 // (not dword aligned: gfx950 executes it)
+    "s_branch .Luni_done_%=\n"
+    ".Luni_zero_%=:\n"
+    "v_cmp_ne_u32_e32 vcc, 0, %[x1]\n"
+    "s_cmp_lg_u64 vcc, 0\n"
+    "s_cbranch_scc1 .Luni_end_%=\n"
+    "s_mov_b64 exec, 0x3f\n"
+    "v_add_u32 %[t], %[posl], %[lane4]\n"
+    "s_mov_b32 %[adv], 24\n"
+    "ds_write_b32 %[t], %[x1]\n"                                                   // (x1 is zero in every lane)
+    ".Luni_done_%=:\n"
+    "s_mov_b64 exec, -1\n"
+    ".Luni_end_%=:\n"
+    : [a] "=&v"(a), [t] "=&v"(t), [x1] "=&v"(x1), [m] "=&s"(m), [adv] "=&s"(adv)
+    : [v] "v"(v), [vp] "v"(vp), [state] "s"(state), [S] "s"(S), [posl] "s"(posl_abs), [lane4] "v"(lk.lane4), [pat5] "v"(lk.pat5)
+    : "vcc", "scc", "memory");
+  return uni(adv);
+  }
+
+// the registers of the previous step that such a stretch did not keep: stride, stride before it, table addresses of its last value
+__device__ __forceinline__ void uniform_leave(Sweep& sw, uint32_t t1abs)
+  {
+  const uint32_t S = sw.ustate == 88u ? sw.ustride : 0u;
+  sw.sp = S;
+  sw.s1p = S;
+  sw.a1p = ((dpp_shr1(0u, sw.vp) >> 26) & 0x3cu) | t1abs;                          // (lane 63 is the one that counts: the value before the last)
+  sw.a2p = (((((S >> 22) & 31u) << 5) ^ (S >> 22)) << 2) + (t1abs + 64u);
+  sw.ustate = 0u;
+  }
+
 // one full step with the pieces above
 template <bool HOOK>
-__device__ __forceinline__ void code_step_asm(uint32_t v, uint32_t t1abs, uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase,
+__device__ __forceinline__ void code_step_asm(uint32_t v, uint32_t t1abs, uint8_t* __restrict__ stage, rsrc_t slot,
                                               Sweep& sw, const LaneK& lk, const RecSink& sink, uint32_t sabotage)
   {
   const uint32_t sbase = (uint32_t)(uintptr_t)(lds_u8*)stage;        // LDS address of the staging area (uniform)
-  flush_end(sw, stage, gbase, lk);
-  uint32_t a, s, s1, a1, a2, adv, no1, no2;
-  uint64_t st1, st2;
-  if (step_head_asm(v, sw, t1abs, sbase + sw.posl, lk, a, s, s1, a1, a2, st1, st2, no1, no2, adv))
+  flush_end(sw, stage, slot, lk);
+  if (sw.ustate)
     {
-    sw.posl += adv;
+    const uint32_t staged = step_uniform_asm(v, sw.vp, sw.ustate, sw.ustride, sbase + sw.posl, lk);
+    if (staged)
+      {
+      sw.posl += staged;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      flush_begin(sw, stage, slot, lk);
+      sw.vp = v;
+      return;
+      }
+    uniform_leave(sw, t1abs);
+    }
+  uint32_t a, s, s1, a1, a2, no1, no2;
+  uint64_t st1, st2;
+  step_head_asm(v, sw, t1abs, a, s, s1, a1, a2, st1, st2, no1, no2);
+  uint32_t staged = 0;
+  if (no1 & no2)
+    staged = step_const_asm(v, a, s1, sbase + sw.posl, lk);
+  if (staged)
+    {
     sw.pend1 = sw.pend2 = 1u;
+    sw.ustate = staged;                                      // the next step may be the same again: see step_uniform_asm
+    sw.ustride = (uint32_t)__builtin_amdgcn_readlane((int)s, 63);
     }
   else
     {
-    uint32_t p1 = a, p2 = s1;                                // inside a run: previous value / previous stride
-    uint64_t ft1 = 0, ft2 = 0, sent = 0;
+    uint32_t p1 = 0, p2 = s1;                                // inside a run: previous value / previous stride
+    uint64_t ft1 = 0, ft2 = 0;
     if (no1 == 0u)
-      resolve_asm(a1, sw.a1p, v, sw.vp, st1, sw.pend1, p1, ft1, sent);
+      p1 = resolve_asm(a1, sw.a1p, v, sw.vp, a, st1, sw.pend1, ft1, sw.sent);
     if (no2 == 0u)
-      resolve_asm(a2, sw.a2p, s, sw.sp, st2, sw.pend2, p2, ft2, sent);
+      p2 = resolve_asm(a2, sw.a2p, s, sw.sp, s1, st2, sw.pend2, ft2, sw.sent);
     if (HOOK && sabotage)
       {
       // test hook (libtrico_testhooks.so only), see resolve_h
@@ -629,16 +732,18 @@ __device__ __forceinline__ void code_step_asm(uint32_t v, uint32_t t1abs, uint8_
       }
     sw.pend1 = no1;                                          // (as integers: a bool that lives across blocks ends up as a lane mask)
     sw.pend2 = no2;
-    if (sent)
-      sw.flags |= FLAG_SENTINEL;
-    uint32_t hq, pre;
-    const uint32_t staged = tail_asm(v, a, p1, p2, ft1 | ft2, sbase + sw.posl, lk, hq, pre);
+    uint32_t hq1, inc, len;
+    // (two copies of the tail: with no FCM run start, which is the rule, the FCM prediction IS the previous value - no move)
+    if (no1)
+      staged = tail_asm(v, a, a, p2, ft2, sbase + sw.posl - 1u, lk, hq1, inc, len);
+    else
+      staged = tail_asm(v, a, p1, p2, ft1 | ft2, sbase + sw.posl - 1u, lk, hq1, inc, len);
     if (ft1 | ft2)
-      write_records(ft1, ft2, v, a, a1, a2, p1, p2, hq, pre, t1abs, sbase, sw, lk, sink);
-    sw.posl += staged;
+      write_records(ft1, ft2, v, a, a1, a2, no1 ? a : p1, p2, hq1, inc, len, t1abs, sbase, sw, lk, sink);
     }
+  sw.posl += staged;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  flush_begin(sw, stage, gbase, lk);
+  flush_begin(sw, stage, slot, lk);
   sw.vp = v; sw.sp = s; sw.s1p = s1; sw.a1p = a1; sw.a2p = a2;
   }
 
@@ -666,6 +771,9 @@ __device__ __forceinline__ void sweep_begin(Sweep& sw, const uint32_t* __restric
   sw.fl_nb = 0;
   sw.nrec = 0;
   sw.flags = 0;
+  sw.sent = 0;
+  sw.ustate = 0;
+  sw.ustride = 0;
   sw.a1p = sw.a2p = 0xfffffffeu;                       // the first value of a segment always looks at the table
   // the three values before the segment (0 before the stream: the reference starts from zeroed state, fpsc.c:104-116)
   const uint32_t m1 = i_begin >= 1u ? src[(size_t)(i_begin - 1u) * arity + c] : 0u;
@@ -687,9 +795,9 @@ __device__ __forceinline__ void sweep_begin(Sweep& sw, const uint32_t* __restric
   }
 
 // what is left in the staging area (< 256 bytes) goes to the slot; returns the bytes the wave produced
-__device__ __forceinline__ uint32_t sweep_end(Sweep& sw, uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase, const LaneK& lk)
+__device__ __forceinline__ uint32_t sweep_end(Sweep& sw, uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase, rsrc_t slot, const LaneK& lk)
   {
-  flush_end(sw, stage, gbase, lk);
+  flush_end(sw, stage, slot, lk);
   if (lk.lane4 < sw.posl)
     store_span(gbase + sw.flushed, lk.lane4, ((const uint32_t*)stage)[lk.lane], sw.posl);
   return sw.flushed + sw.posl;
@@ -716,6 +824,7 @@ __device__ __forceinline__ void guard_segment(const uint32_t* __restrict__ src, 
   const uint32_t i_end = (seg_end - i_begin < 64u * GUARD_STEPS) ? seg_end : i_begin + 64u * GUARD_STEPS;
   const size_t row = (size_t)j * arity + c;
   uint8_t* gbase = gslots + row * GUARD_CAP;
+  const rsrc_t slot = make_rsrc(gbase, GUARD_CAP);
   const RecSink sink = { grecs + row * RCAP * RECW };
   Sweep sw;
   sweep_begin(sw, src, n, arity, c, g, i_begin, T, stage, lane);
@@ -725,11 +834,11 @@ __device__ __forceinline__ void guard_segment(const uint32_t* __restrict__ src, 
     const uint32_t i = i0 + lane;
     const uint32_t v = i < seg_end ? src[(size_t)i * arity + c] : 0u;
     if (i0 + 64u <= seg_end)
-      code_step<true, true, HOOK>(v, i0, seg_end, n, t1abs, stage, gbase, sw, lk, sink, 0u);
+      code_step<true, true, HOOK>(v, i0, seg_end, n, t1abs, stage, slot, sw, lk, sink, 0u);
     else
-      code_step<false, true, HOOK>(v, i0, seg_end, n, t1abs, stage, gbase, sw, lk, sink, 0u);
+      code_step<false, true, HOOK>(v, i0, seg_end, n, t1abs, stage, slot, sw, lk, sink, 0u);
     }
-  const uint32_t bytes = sweep_end(sw, stage, gbase, lk);
+  const uint32_t bytes = sweep_end(sw, stage, gbase, slot, lk);
   if (lane == 0)
     gmeta[row] = GuardMeta{ g, bytes, sw.nrec, 0u };
   }
@@ -740,7 +849,7 @@ __device__ __forceinline__ void guard_segment(const uint32_t* __restrict__ src, 
 template <bool HOOK, bool ASM>
 __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(TRICO_SWEEP_WAVES, 8)))
 k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t L, uint32_t S, uint32_t* __restrict__ outT,
-              uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap, uint32_t* __restrict__ segbytes,
+              uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap, uint32_t* __restrict__ segbytes, uint32_t* __restrict__ rawbytes,
               uint32_t* __restrict__ nrec, uint32_t* __restrict__ recs, uint32_t tune, uint32_t sabotage, uint32_t seed,
               uint8_t* __restrict__ gslots, uint32_t* __restrict__ grecs, GuardMeta* __restrict__ gmeta)
   {
@@ -760,22 +869,23 @@ k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t 
   const uint32_t i_begin = g * L;
   const uint32_t i_end = (n - i_begin < L) ? n : i_begin + L;
   uint8_t* gbase = slots + (size_t)c * slot_stride + (size_t)g * segcap;
+  const rsrc_t slot = make_rsrc(gbase, segcap);
   const size_t rowi = (size_t)g * arity + c;
   const RecSink sink = { recs + rowi * RCAP * RECW };
   Sweep sw;
   sweep_begin(sw, src, n, (uint32_t)arity, c, g, i_begin, T, stage, lane);
   // rolling prefetch: the next PF steps' values; a slot is loaded again as soon as its step begins (always PF steps in flight, never
-  // more: 320 workgroups per XCD share 4 MB of L2)
+  // more: 320 workgroups per XCD share 4 MB of L2).  The descriptor begins at the segment and ends with the array: what a load
+  // beyond the segment fetches belongs to the next one and is not used, beyond the array it is zero.
+  const rsrc_t in = make_rsrc(src + (size_t)i_begin * arity, ((uint64_t)n - i_begin) * (uint64_t)arity * 4u);
   const uint32_t voff = (lane * (uint32_t)arity + c) * 4u;
+  const uint32_t stepb = 256u * (uint32_t)arity;       // bytes of the interleaved array a step covers
   uint32_t cur[PF];
 #pragma unroll
   for (int pu = 0; pu < PF; ++pu)
-    {
-    const uint32_t ii = i_begin + 64u * pu;
-    const uint8_t* base = (const uint8_t*)(src + (size_t)ii * arity);
-    cur[pu] = (ii < i_end && ii + lane < i_end) ? *(const uint32_t*)(base + voff) : 0u;
-    }
-  const uint32_t lag = (tune >> 8) & 255u;             // blocks a component wave may run ahead of the slowest (0 = any)
+    cur[pu] = __builtin_amdgcn_raw_buffer_load_b32(in, voff, stepb * (uint32_t)pu, 0);
+  uint32_t soff = stepb * PF;                          // where the next load goes
+  const uint32_t lag = (tune >> 8) & 255u;             // eighths of a block a component wave may run ahead of the slowest (0 = any)
   const bool prio = (tune & 255u) != 0u;
   if (lane == 0)
     prog[c] = i_begin;
@@ -804,30 +914,29 @@ k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t 
         uint32_t lo = 0xffffffffu;
         for (int o = 0; o < arity; ++o)
           lo = min(lo, (uint32_t)__builtin_amdgcn_readfirstlane((int)prog[o]));
-        if (lo == 0xffffffffu || ib <= lo + lag * 64u * PF)
+        if (lo == 0xffffffffu || ib <= lo + lag * 8u * PF)
           break;
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(12);                    // (768 cycles: the wave that is waited for needs the issue slots, not the waiting ones)
         }
       }
-    const uint8_t* nbase = (const uint8_t*)(src + (size_t)(ib + 64u * PF) * arity);
-    if (ib + 128u * PF <= i_end)
+    if (ib + 64u * PF <= i_end)
       {
-      // this block and the one the loads reach into lie inside the segment: no bounds, no activity masks
+      // eight full steps: no activity masks
 #pragma unroll
       for (int pu = 0; pu < PF; ++pu)
         {
         const uint32_t vcur = cur[pu];
-        uint32_t vo = voff;
-        asm volatile("" : "+v"(vo));                   // (keeps the 32-bit offset in this block: scalar base + vector offset addressing)
-        cur[pu] = *(const uint32_t*)(nbase + (size_t)(256u * (uint32_t)pu) * arity + vo);
+        cur[pu] = __builtin_amdgcn_raw_buffer_load_b32(in, voff, soff, 0);
+        soff += stepb;
         if (ASM)
-          code_step_asm<HOOK>(vcur, t1abs, stage, gbase, sw, lk, sink, sabotage);
+          code_step_asm<HOOK>(vcur, t1abs, stage, slot, sw, lk, sink, sabotage);
         else
-          code_step<true, false, HOOK>(vcur, ib + 64u * pu, i_end, n, t1abs, stage, gbase, sw, lk, sink, sabotage);
+          code_step<true, false, HOOK>(vcur, ib + 64u * pu, i_end, n, t1abs, stage, slot, sw, lk, sink, sabotage);
         }
       }
     else
       {
+      // the end of the segment: fewer than eight steps, nothing more to fetch
 #pragma unroll 1
       for (int pu = 0; pu < PF; ++pu)
         {
@@ -844,21 +953,21 @@ k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t 
           ilast = i0;
           break;
           }
-        const uint32_t in = i0 + 64u * PF + lane;
-        const uint32_t nv = in < i_end ? *(const uint32_t*)(nbase + (size_t)(256u * (uint32_t)pu) * arity + voff) : 0u;
-#pragma unroll
-        for (int q = 0; q < PF; ++q)
-          cur[q] = pu == q ? nv : cur[q];
         if (ASM)
-          code_step_asm<HOOK>(vcur, t1abs, stage, gbase, sw, lk, sink, sabotage);
+          code_step_asm<HOOK>(vcur, t1abs, stage, slot, sw, lk, sink, sabotage);
         else
-          code_step<true, false, HOOK>(vcur, i0, i_end, n, t1abs, stage, gbase, sw, lk, sink, sabotage);
+          code_step<true, false, HOOK>(vcur, i0, i_end, n, t1abs, stage, slot, sw, lk, sink, sabotage);
         }
       }
     }
+  if (ASM && sw.ustate)
+    uniform_leave(sw, t1abs);
   if (ilast != 0xffffffffu)
-    code_step<false, false, HOOK>(vlast, ilast, i_end, n, t1abs, stage, gbase, sw, lk, sink, sabotage);
-  const uint32_t bytes = sweep_end(sw, stage, gbase, lk);
+    {
+    // (the values beyond the stream come back as zeros, or as the next segment's: the step masks them by index)
+    code_step<false, false, HOOK>(vlast, ilast, i_end, n, t1abs, stage, slot, sw, lk, sink, sabotage);
+    }
+  const uint32_t bytes = sweep_end(sw, stage, gbase, slot, lk);
   if (lane == 0)
     prog[c] = 0xffffffffu;                             // done: nobody is behind me any more, nobody waits for me
   // what the segment leaves behind: the tables with the last value's writes applied (SENT = not written here)
@@ -867,14 +976,15 @@ k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t 
     if (sw.pend1) *lds_at(sw.a1p) = sw.vp;
     if (sw.pend2) *lds_at(sw.a2p) = sw.sp;
     }
-  if ((sw.pend1 && __ballot(lane == 63u && sw.vp == SENT)) || (sw.pend2 && __ballot(lane == 63u && sw.sp == SENT)))
+  if ((sw.pend1 && __ballot(lane == 63u && sw.vp == SENT)) || (sw.pend2 && __ballot(lane == 63u && sw.sp == SENT)) || sw.sent != 0ull)
     sw.flags |= FLAG_SENTINEL;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   for (uint32_t k = lane; k < (uint32_t)TAB; k += 64u)
     outT[rowi * ROW + k] = T[k];
   if (lane == 0)
     {
-    segbytes[(size_t)c * S + g] = bytes;
+    segbytes[(size_t)c * S + g] = bytes;                 // (what the fix-up kernel takes the unused bytes of the deferred values off)
+    rawbytes[(size_t)c * S + g] = bytes;                 // what the slot holds
     nrec[rowi] = sw.nrec | (sw.flags << 16);
     }
   }
@@ -926,19 +1036,19 @@ __global__ void __launch_bounds__(256) k_fpc32_pscan_b(const uint32_t* __restric
   }
 
 // ---- the deferred values: residual, length and code from the incoming entries (fpsc.c:133-189 for one value) -----------------
-// One workgroup per (segment, component) with records.  The record keeps the result for the gather (w6 = residual, w7 = length |
+// One workgroup per (segment, component) with records (what a thread does is a chain of three memory round trips: the more threads, the better).  The record keeps the result for the gather (w6 = residual, w7 = length |
 // code << 4); the segment's size loses the unused bytes of its reserved fields (rawbytes keeps what the slot holds).
 // Workgroups S .. S + G - 1 are the second half of the write-side guard: what guard workgroup j coded with ballots (guard_segment)
 // against what the sweep left for that segment - the bytes, the number of records up to there and the records themselves.  A
 // difference raises FLAG_ORDER for the component (it travels with the segment's record count to k_fpc32_offsets and the host).
-__global__ void __launch_bounds__(256) k_fpc32_fixup(int arity, uint32_t S, const uint32_t* __restrict__ inc, uint32_t* __restrict__ segbytes,
-                                                     uint32_t* __restrict__ rawbytes, uint32_t* __restrict__ nrec, uint32_t* __restrict__ recs,
-                                                     const uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap,
-                                                     const uint8_t* __restrict__ gslots, const uint32_t* __restrict__ grecs,
-                                                     const GuardMeta* __restrict__ gmeta)
+// what one workgroup of k_fpc32_fixup does for its (segment or guard row, component)
+__device__ __forceinline__ void fixup_rows(int arity, uint32_t S, const uint32_t* __restrict__ inc, uint32_t* __restrict__ segbytes,
+                                           uint32_t* __restrict__ rawbytes, uint32_t* __restrict__ nrec, uint32_t* __restrict__ recs,
+                                           const uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap,
+                                           const uint8_t* __restrict__ gslots, const uint32_t* __restrict__ grecs,
+                                           const GuardMeta* __restrict__ gmeta, uint32_t g, uint32_t c, uint32_t lane,
+                                           uint32_t* __restrict__ part)
   {
-  __shared__ uint32_t part[4];
-  const uint32_t g = blockIdx.x, c = blockIdx.y;
   if (g >= S)
     {
     const size_t row = (size_t)(g - S) * arity + c;
@@ -947,16 +1057,16 @@ __global__ void __launch_bounds__(256) k_fpc32_fixup(int arity, uint32_t S, cons
     const uint32_t* mine = (const uint32_t*)(slots + (size_t)c * slot_stride + (size_t)m.seg * segcap);
     const uint32_t* theirs = (const uint32_t*)(gslots + row * GUARD_CAP);
     const uint32_t H = nrec[rowi] & 0xffffu;
-    bool diff = H < m.nrec || segbytes[(size_t)c * S + m.seg] < m.bytes;
-    for (uint32_t t = threadIdx.x; 4u * t < m.bytes; t += 256u)
+    bool diff = H < m.nrec || rawbytes[(size_t)c * S + m.seg] < m.bytes;      // (rawbytes: the segment's own workgroup may be changing segbytes right now)
+    for (uint32_t t = lane; 4u * t < m.bytes; t += 256u)
       {
       const uint32_t keep = 4u * t + 4u <= m.bytes ? 0xffffffffu : (1u << (8u * (m.bytes & 3u))) - 1u;
       diff = diff || ((mine[t] ^ theirs[t]) & keep) != 0u;
       }
     const uint32_t* ra = recs + rowi * RCAP * RECW, * rb = grecs + row * RCAP * RECW;
-    for (uint32_t t = threadIdx.x; t < 5u * m.nrec && !(H < m.nrec); t += 256u)
+    for (uint32_t t = lane; t < 5u * m.nrec && !(H < m.nrec); t += 256u)
       diff = diff || ra[RECW * (t / 5u) + t % 5u] != rb[RECW * (t / 5u) + t % 5u];
-    if (threadIdx.x == 0 && H > m.nrec)
+    if (lane == 0 && H > m.nrec)
       diff = diff || ra[RECW * m.nrec] < m.bytes;            // a record of the sweep inside the compared bytes that the guard does not have
     if (diff)
       atomicOr(&nrec[rowi], FLAG_ORDER << 16);
@@ -967,9 +1077,9 @@ __global__ void __launch_bounds__(256) k_fpc32_fixup(int arity, uint32_t S, cons
   if (H == 0u)
     return;
   uint32_t* list = recs + rowi * RCAP * RECW;
-  const uint32_t* row = inc + rowi * ROW;
+  const uint32_t* row = inc + rowi * ROW;              // (the segment's incoming tables; parking the row in LDS first is slower)
   uint32_t unused = 0;
-  for (uint32_t j = threadIdx.x; j < H; j += 256u)
+  for (uint32_t j = lane; j < H; j += 256u)
     {
     const u32x4 w = *(const u32x4*)(list + RECW * j);
     const uint32_t known = list[RECW * j + 4u];
@@ -988,28 +1098,93 @@ __global__ void __launch_bounds__(256) k_fpc32_fixup(int arity, uint32_t S, cons
     unused += 4u - len;
     }
   const uint32_t incl = wave_scan_incl(unused);
-  if ((threadIdx.x & 63u) == 63u)
-    part[threadIdx.x >> 6] = incl;
+  if ((lane & 63u) == 63u)
+    part[lane >> 6] = incl;
   __syncthreads();
-  if (threadIdx.x == 0)
+  if (lane == 0)
     {
-    const uint32_t raw = segbytes[(size_t)c * S + g];
-    rawbytes[(size_t)c * S + g] = raw;
-    segbytes[(size_t)c * S + g] = raw - (part[0] + part[1] + part[2] + part[3]);
+    segbytes[(size_t)c * S + g] = rawbytes[(size_t)c * S + g] - (part[0] + part[1] + part[2] + part[3]);
     }
+  }
+
+__global__ void __launch_bounds__(256) k_fpc32_fixup(int arity, uint32_t S, const uint32_t* __restrict__ inc, uint32_t* __restrict__ segbytes,
+                                                     uint32_t* __restrict__ rawbytes, uint32_t* __restrict__ nrec, uint32_t* __restrict__ recs,
+                                                     const uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap,
+                                                     const uint8_t* __restrict__ gslots, const uint32_t* __restrict__ grecs,
+                                                     const GuardMeta* __restrict__ gmeta)
+  {
+  // (The scan of the segment sizes stays a launch of its own, k_fpc32_offsets: done by "the workgroup that finishes last", the 7,700
+  // atomic increments of the counter that finds it took 0.4 ms - they are served one after the other.)
+  __shared__ uint32_t part[4];
+  const uint32_t g = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
+  fixup_rows(arity, S, inc, segbytes, rawbytes, nrec, recs, slots, slot_stride, segcap, gslots, grecs, gmeta, g, c, lane, part);
   }
 
 // ---- gather: segment slots -> contiguous payload ----------------------------------------------------------------------------
 // grid (S, components); each workgroup moves one segment.  Without records: the destination is written as aligned 16-byte vectors,
 // the source (a 256-byte aligned slot) is read as 4 + 1 dwords per vector and re-aligned with v_alignbyte.
-// With records the slot passes through LDS in chunks of 4 KiB of SOURCE bytes: a chunk near a record is parked, the records put
-// their residual bytes and code bits where they belong and mark the unused bytes of their fields, a prefix sum over the valid bytes
-// of every 16-byte piece says where it goes; every chunk then lands in an output ring whose positions are congruent to the
-// destination's modulo 16 and leaves it as aligned 16-byte vectors.  Nothing is searched: a record knows its slot position.
-constexpr uint32_t GCH = 4096;                     // source bytes per chunk (256 threads x 16)
-constexpr uint32_t ORING = 16384;                  // output ring (power of two; see the overlap argument at the flush)
-constexpr uint32_t MAXCH = 2048;                   // chunks per slot the record index covers (8 MiB slots; beyond: every chunk looks at all records)
+// With records the slot is cut into sub-chunks of 1 KiB of SOURCE bytes (more for slots beyond 2 MiB).  A pass over the records
+// counts the unused bytes of every sub-chunk - a prefix sum says where its output begins - and marks the ones a record touches.
+// Then every WAVE takes sub-chunks by itself, no barrier: an untouched one is the copy with a shift again; a touched one passes
+// through the wave's own LDS, 64 x 16 bytes at a time: the records put their residual bytes and code bits into a patch area (ORed
+// into the lanes' bytes: the sweep left zeros there) and mark the unused bytes of their fields, a wave scan over the valid bytes
+// of every lane says where they go, and they land in a small output ring whose positions are congruent to the destination's
+// modulo 16 and leave it as aligned 16-byte vectors.  Every output byte is written once, by the wave that owns it; the partial
+// vectors at the ends of a sub-chunk's output go byte by byte.  Nothing is searched: a record knows its slot position.
+constexpr uint32_t GSUB = 1024;                    // source bytes per piece (64 lanes x 16)
+constexpr uint32_t MAXSUB = 2048;                  // sub-chunks per slot
+constexpr uint32_t WRING = 2048;                   // a wave's output ring (power of two; at most 15 + 1024 bytes are in it at a time)
 struct GatherDst { uint8_t* p[3]; };
+
+// 16 bytes in a row to LDS byte address ad.  An LDS dword store at an address that is not a multiple of four costs about eight
+// aligned ones on gfx950, so: up to three single bytes until the next dword boundary, the dwords from there on (the vector shifted
+// accordingly), and the up to three bytes behind the last whole dword.
+__device__ __forceinline__ void lds_store16(uint32_t ad, const u32x4& vec)
+  {
+  const uint32_t r = ad & 3u, lead = (4u - r) & 3u;              // bytes in front of the first aligned dword
+  lds_vu8* ob = (lds_vu8*)(uintptr_t)ad;
+  if (lead > 0u) ob[0] = (uint8_t)vec[0];
+  if (lead > 1u) ob[1] = (uint8_t)(vec[0] >> 8);
+  if (lead > 2u) ob[2] = (uint8_t)(vec[0] >> 16);
+  lds_u32* ow = (lds_u32*)(uintptr_t)(ad + lead);
+  ow[0] = __builtin_amdgcn_alignbyte(vec[1], vec[0], lead);
+  ow[1] = __builtin_amdgcn_alignbyte(vec[2], vec[1], lead);
+  ow[2] = __builtin_amdgcn_alignbyte(vec[3], vec[2], lead);
+  if (r == 0u)
+    ow[3] = vec[3];
+  lds_vu8* oe = (lds_vu8*)(uintptr_t)(ad + 16u - r);
+  if (r > 0u) oe[0] = (uint8_t)(vec[3] >> (8u * (4u - r)));
+  if (r > 1u) oe[1] = (uint8_t)(vec[3] >> (8u * (5u - r)));
+  if (r > 2u) oe[2] = (uint8_t)(vec[3] >> 24);
+  }
+
+// `len` bytes from sc (4-byte aligned) to dd, by one wave or one workgroup (`threads` of them, this one is `t0`)
+__device__ __forceinline__ void copy_shifted(uint8_t* __restrict__ dd, const uint8_t* __restrict__ sc, uint32_t len, uint32_t t0, uint32_t threads)
+  {
+  const uint32_t head = (uint32_t)((16u - ((uintptr_t)dd & 15u)) & 15u);         // bytes until dd is 16-byte aligned
+  const uint32_t h = head < len ? head : len;
+  const uint32_t body = (len - h) >> 4;                                           // aligned destination vectors
+  const uint32_t done = h + 16u * body;
+  if (t0 < h)
+    dd[t0] = sc[t0];
+  const uint32_t* ss = (const uint32_t*)sc + (h >> 2);
+  const uint32_t sh = h & 3u;
+  u32x4* dv = (u32x4*)(dd + h);
+  // destination vector t holds source bytes h + 16t .. h + 16t + 15
+  for (uint32_t t = t0; t < body; t += threads)
+    {
+    const u32x4 lo = *(const u32x4*)(ss + 4u * t);                                // 4-byte aligned 16-byte load
+    const uint32_t hi = ss[4u * t + 4u];
+    u32x4 o;
+    o[0] = __builtin_amdgcn_alignbyte(lo[1], lo[0], sh);
+    o[1] = __builtin_amdgcn_alignbyte(lo[2], lo[1], sh);
+    o[2] = __builtin_amdgcn_alignbyte(lo[3], lo[2], sh);
+    o[3] = __builtin_amdgcn_alignbyte(hi, lo[3], sh);
+    __builtin_nontemporal_store(o, dv + t);
+    }
+  if (t0 < len - done)
+    dd[done + t0] = sc[done + t0];
+  }
 
 __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap, uint32_t S,
                                                       const uint32_t* __restrict__ segbytes, const uint32_t* __restrict__ rawbytes,
@@ -1025,192 +1200,238 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
   const uint32_t H = nrec[rowi] & 0xffffu;
   if (H == 0u)
     {
-    const uint32_t head = (uint32_t)((16u - ((uintptr_t)d & 15u)) & 15u);         // bytes until d is 16-byte aligned
-    const uint32_t h = head < len ? head : len;
-    const uint32_t body = (len - h) >> 4;                                         // aligned destination vectors
-    u32x4* dd = (u32x4*)(d + h);
-    const uint32_t done = h + 16u * body;
-    if (tid < h)
-      d[tid] = s[tid];
-    const uint32_t* ss = (const uint32_t*)s + (h >> 2);
-    const uint32_t sh = h & 3u;
-    // destination vector t holds source bytes h + 16t .. h + 16t + 15
-    for (uint32_t t = tid; t < body; t += 256u)
-      {
-      const u32x4 lo = *(const u32x4*)(ss + 4u * t);                              // 4-byte aligned 16-byte load
-      const uint32_t hi = ss[4u * t + 4u];
-      u32x4 o;
-      o[0] = __builtin_amdgcn_alignbyte(lo[1], lo[0], sh);
-      o[1] = __builtin_amdgcn_alignbyte(lo[2], lo[1], sh);
-      o[2] = __builtin_amdgcn_alignbyte(lo[3], lo[2], sh);
-      o[3] = __builtin_amdgcn_alignbyte(hi, lo[3], sh);
-      __builtin_nontemporal_store(o, dd + t);
-      }
-    if (tid < len - done)
-      d[done + tid] = s[done + tid];
+    copy_shifted(d, s, len, tid, 256u);
     return;
     }
-  __shared__ __attribute__((aligned(16))) uint8_t SB[GCH];       // the parked chunk
-  __shared__ uint32_t U[GCH / 32];                               // its unused bytes, one bit each
-  __shared__ __attribute__((aligned(16))) uint8_t O[ORING];      // output ring
-  __shared__ uint32_t cfirst[MAXCH + 2];                         // first record whose field ends in chunk >= i; bit 31: a record touches chunk i
-  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t sub_out[MAXSUB + 1];                       // output offset of sub-chunk k (first: its unused bytes)
+  __shared__ uint16_t rfirst[MAXSUB + 2];                        // first record whose field ends in sub-chunk >= k
+  __shared__ uint32_t touched[MAXSUB / 32];                      // a record has a byte in sub-chunk k
+  __shared__ uint32_t wsum[4], next_sub;
+  __shared__ __attribute__((aligned(16))) uint32_t wlds[4][(GSUB + GSUB / 8 + WRING + 32) / 4];       // per wave: patches, unused marks, output ring
   const uint32_t slen = rawbytes[(size_t)cc * S + g];
   const uint32_t* list = recs + rowi * RCAP * RECW;
-  const uint32_t nchunk = (slen + GCH - 1u) / GCH;
-  const bool indexed = nchunk <= MAXCH;
-  if (indexed)
+  uint32_t subshift = 10;
+  while (((slen - 1u) >> subshift) >= MAXSUB)
+    ++subshift;
+  const uint32_t subsize = 1u << subshift, nsub = ((slen - 1u) >> subshift) + 1u;
+  for (uint32_t k = tid; k <= nsub; k += 256u)
+    sub_out[k] = 0u;
+  if (tid < MAXSUB / 32u)
+    touched[tid] = 0u;
+  if (tid == 0)
+    next_sub = 4u;
+  __syncthreads();
+  uint32_t* rpos = &wlds[0][0];                                  // [H] the records' slot positions (the waves' buffers are idle until the setup is done)
+  for (uint32_t j = tid; j < H; j += 256u)
     {
-    for (uint32_t q = tid; q <= nchunk + 1u; q += 256u)
-      cfirst[q] = H;
-    __syncthreads();
-    for (uint32_t j = tid; j < H; j += 256u)
-      atomicMin(&cfirst[(list[RECW * j] + 3u) / GCH], j);
-    __syncthreads();
-    if (tid == 0)
-      for (uint32_t q = nchunk; q-- > 0u;)
-        cfirst[q] = min(cfirst[q], cfirst[q + 1u]);
-    __syncthreads();
-    // the chunks a record touches: the one its header begins in and the one its field ends in (at most 34 bytes apart)
-    for (uint32_t j = tid; j < H; j += 256u)
-      {
-      const uint32_t pos = list[RECW * j], hdr = pos - (list[RECW * j + 1u] & 255u);
-      atomicOr(&cfirst[hdr / GCH], 0x80000000u);
-      atomicOr(&cfirst[(pos + 3u) / GCH], 0x80000000u);
-      }
-    __syncthreads();
+    const uint32_t pos = list[RECW * j], hdr = pos - (list[RECW * j + 1u] & 255u), ln = list[RECW * j + 7u] & 15u;
+    rpos[j] = pos;
+    for (uint32_t bb = ln; bb < 4u; ++bb)
+      atomicAdd(&sub_out[(pos + bb) >> subshift], 1u);
+    const uint32_t k0 = hdr >> subshift, k1 = (pos + 3u) >> subshift;           // (at most 34 bytes apart)
+    atomicOr(&touched[k0 >> 5], 1u << (k0 & 31u));
+    atomicOr(&touched[k1 >> 5], 1u << (k1 & 31u));
     }
-  const uint32_t A = (uint32_t)((uintptr_t)d & 15u);             // ring position p <-> destination byte (d - A) + p
-  uint8_t* dbase = d - A;
-  uint32_t wpos = A, rpos = 0;
-  const uint32_t lane = tid & 63u, wv = tid >> 6;
-  for (uint32_t ci = 0; ci < nchunk; ++ci)
+  __syncthreads();
+  for (uint32_t k = tid; k <= nsub; k += 256u)
     {
-    const uint32_t cb = ci * GCH, sb = cb + 16u * tid;
-    u32x4 vec = { 0u, 0u, 0u, 0u };
-    if (sb < slen)
-      vec = *(const u32x4*)(s + sb);
-    const uint32_t r0 = indexed ? cfirst[ci] & 0x7fffffffu : 0u;
-    uint32_t r1 = indexed ? (cfirst[ci + 1u] & 0x7fffffffu) + 9u : H;      // (a header lies at most 31 bytes = 7 fields before its record's field)
-    r1 = r1 < H ? r1 : H;
-    const bool dirty = indexed ? (cfirst[ci] >> 31) != 0u : true;
-    uint32_t m16 = 0;
-    if (dirty)
+    // first record whose field ends at or behind the start of sub-chunk k (the records are in slot order); the search runs in LDS:
+    // ten dependent loads from memory per workgroup were a third of this kernel's time
+    const uint32_t lim = k << subshift;
+    uint32_t lo = 0, hi = H;
+    while (lo < hi)
       {
-      *(u32x4*)(SB + 16u * tid) = vec;
-      if (tid < GCH / 32u)
-        U[tid] = 0u;
-      __syncthreads();
-      for (uint32_t j = r0 + tid; j < r1; j += 256u)
-        {
-        const uint32_t pos = list[RECW * j], meta = list[RECW * j + 1u], x = list[RECW * j + 6u], lc = list[RECW * j + 7u];
-        const uint32_t ln = lc & 15u, code = lc >> 4;
-        const uint32_t hdr = pos - (meta & 255u), h24 = code << (3u * ((meta >> 8) & 7u));
-        for (uint32_t b = 0; b < 4u; ++b)
-          {
-          const uint32_t q = pos + b - cb;                       // wraps to a huge number before the chunk
-          if (q < GCH)
-            {
-            if (b < ln)
-              SB[q] = (uint8_t)(x >> (8u * (ln - 1u - b)));
-            else
-              atomicOr(&U[q >> 5], 1u << (q & 31u));
-            }
-          }
-        for (uint32_t b = 0; b < 3u; ++b)
-          {
-          const uint32_t q = hdr + b - cb;
-          const uint32_t by = (h24 >> (8u * (2u - b))) & 255u;
-          if (q < GCH && by)
-            atomicOr((uint32_t*)SB + (q >> 2), by << (8u * (q & 3u)));      // (records of one group share its header)
-          }
-        }
-      __syncthreads();
-      vec = *(const u32x4*)(SB + 16u * tid);
-      m16 = (U[tid >> 1] >> (16u * (tid & 1u))) & 0xffffu;
+      const uint32_t mid = (lo + hi) >> 1;
+      if (rpos[mid] + 3u < lim) lo = mid + 1u; else hi = mid;
       }
-    if (sb + 16u > slen)
-      m16 |= sb >= slen ? 0xffffu : (0xffffu << (slen - sb)) & 0xffffu;        // beyond the slot's content
-    uint32_t off, total;
-    const bool plain = !dirty && cb + GCH <= slen;               // (uniform)
-    if (plain)
-      {
-      off = 16u * tid;
-      total = GCH;
-      }
-    else
-      {
-      const uint32_t cnt = 16u - (uint32_t)__popc(m16);
-      const uint32_t incl = wave_scan_incl(cnt);
-      if (lane == 63u)
-        wsum[wv] = incl;
-      __syncthreads();
-      off = incl - cnt;
-      total = 0;
-      for (uint32_t w = 0; w < 4u; ++w)
-        {
-        off += w < wv ? wsum[w] : 0u;
-        total += wsum[w];
-        }
-      }
-    {
-    const uint32_t p = (wpos + off) & (ORING - 1u);
-    if (m16 == 0u && p + 16u <= ORING)
-      {
-      // sixteen bytes in a row, not dword aligned in general (gfx950 executes unaligned LDS dword stores)
-      const uint32_t ad = (uint32_t)(uintptr_t)(lds_u8*)O + p;
-      asm volatile("ds_write_b32 %0, %1\n"
-                   "ds_write_b32 %0, %2 offset:4\n"
-                   "ds_write_b32 %0, %3 offset:8\n"
-                   "ds_write_b32 %0, %4 offset:12"
-                   :: "v"(ad), "v"(vec[0]), "v"(vec[1]), "v"(vec[2]), "v"(vec[3]) : "memory");
-      }
-    else
-      {
-      uint32_t q = p;
-#pragma unroll
-      for (int b = 0; b < 16; ++b)
-        if (!((m16 >> b) & 1u))
-          {
-          O[q] = (uint8_t)(vec[b >> 2] >> (8 * (b & 3)));
-          q = (q + 1u) & (ORING - 1u);
-          }
-      }
+    rfirst[k] = (uint16_t)lo;
     }
-    wpos += total;
-    __syncthreads();
-    // Whole vectors leave the ring.  No barrier behind the reads: the next chunk writes [wpos, wpos + 4096) with wpos < rpos + 4096
-    // (less than 256 vectors stay behind), which in a ring of 16 KiB cannot reach the 4 KiB read here, and the chunk after that
-    // is behind the next chunk's barrier.
-    while (wpos - rpos >= GCH)
-      {
-      const uint32_t p = rpos + 16u * tid;
-      const u32x4 o = *(const u32x4*)(O + (p & (ORING - 1u)));
-      if (p >= A)
-        __builtin_nontemporal_store(o, (u32x4*)(dbase + p));
-      else
-        for (uint32_t b = A; b < 16u; ++b)                        // the first vector of the segment: its first A bytes are the neighbour's
-          dbase[b] = (uint8_t)(o[b >> 2] >> (8u * (b & 3u)));
-      rpos += GCH;
-      }
-    }
-  // what is left: whole vectors, then the bytes of the last partial one
+  __syncthreads();
   {
-  const uint32_t nvec = (wpos - rpos) >> 4;
-  for (uint32_t t = tid; t < nvec; t += 256u)
+  // exclusive prefix sum of the sub-chunks' valid bytes
+  const uint32_t per = (nsub + 255u) / 256u;
+  const uint32_t k0 = tid * per < nsub ? tid * per : nsub, k1 = k0 + per < nsub ? k0 + per : nsub;
+  uint32_t sum = 0;
+  for (uint32_t k = k0; k < k1; ++k)
     {
-    const uint32_t p = rpos + 16u * t;
-    const u32x4 o = *(const u32x4*)(O + (p & (ORING - 1u)));
-    if (p >= A)
-      __builtin_nontemporal_store(o, (u32x4*)(dbase + p));
-    else
-      for (uint32_t b = A; b < 16u && b < wpos; ++b)
-        dbase[b] = (uint8_t)(o[b >> 2] >> (8u * (b & 3u)));
+    const uint32_t sl = slen - (k << subshift);
+    sum += (sl < subsize ? sl : subsize) - sub_out[k];
     }
-  const uint32_t p = rpos + 16u * nvec + tid;
-  if (tid < 16u && p < wpos && p >= A)
-    dbase[p] = O[p & (ORING - 1u)];
+  const uint32_t incl = wave_scan_incl(sum);
+  if ((tid & 63u) == 63u)
+    wsum[tid >> 6] = incl;
+  __syncthreads();
+  uint32_t run = incl - sum;
+  for (uint32_t w = 0; w < (tid >> 6); ++w)
+    run += wsum[w];
+  for (uint32_t k = k0; k < k1; ++k)
+    {
+    const uint32_t sl = slen - (k << subshift);
+    const uint32_t valid = (sl < subsize ? sl : subsize) - sub_out[k];
+    sub_out[k] = run;
+    run += valid;
+    }
+  if (tid == 255u)
+    sub_out[nsub] = run;                                           // (= len)
   }
+  __syncthreads();
+  // from here on every wave is on its own
+  const uint32_t lane = tid & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  uint8_t* PB = (uint8_t*)wlds[wv];                              // [GSUB] patches of the piece
+  uint32_t* U = wlds[wv] + GSUB / 4;                             // [GSUB / 32] its unused bytes, one bit each
+  uint8_t* O = (uint8_t*)(wlds[wv] + (GSUB + GSUB / 8) / 4);     // [WRING + 32] output ring
+  const uint32_t obase = (uint32_t)(uintptr_t)(lds_u8*)O;
+  uint32_t k = wv;
+  while (k < nsub)
+    {
+    const uint32_t sb0 = k << subshift;
+    const uint32_t sl = slen - sb0 < subsize ? slen - sb0 : subsize;             // source bytes of this sub-chunk
+    uint8_t* dd0 = d + sub_out[k];
+    if (!((touched[k >> 5] >> (k & 31u)) & 1u))
+      copy_shifted(dd0, s + sb0, sl, lane, 64u);
+    else
+      {
+      // ring position p <-> destination byte rbase + p, rbase 16-byte aligned
+      const uint32_t A = (uint32_t)((uintptr_t)dd0 & 15u);
+      uint8_t* rbase = dd0 - A;
+      uint32_t wpos = A, rpos = 0;
+      uint32_t rj = rfirst[k];
+      // The piece in hand and the loads of the next one: its 16 bytes per lane and the record each lane looks at first (a piece
+      // rarely has more than 64).  A wave has nobody to cover its memory round trips here, so they are started a piece ahead.
+      struct Rec { uint32_t pos, meta, x, lc; };
+      auto load_rec = [&](uint32_t j) -> Rec
+        {
+        Rec r = { 0xffffffffu, 0u, 0u, 0u };
+        if (j < H)
+          {
+          const u32x4 w = *(const u32x4*)(list + RECW * j);
+          const uint32_t* t = list + RECW * j + 6u;
+          r.pos = w[0]; r.meta = w[1]; r.x = t[0]; r.lc = t[1];
+          }
+        return r;
+        };
+      auto load_vec = [&](uint32_t pb) -> u32x4
+        {
+        const uint32_t sb = sb0 + pb + 16u * lane;
+        u32x4 v = { 0u, 0u, 0u, 0u };
+        if (sb < sb0 + sl)
+          v = *(const u32x4*)(s + sb);
+        return v;
+        };
+      u32x4 vnext = load_vec(0u);
+      Rec rnext = load_rec(rj + lane);
+      for (uint32_t pb = 0; pb < sl; pb += GSUB)
+        {
+        const uint32_t cb = sb0 + pb, sb = cb + 16u * lane;
+        const uint32_t pend = sl - pb < GSUB ? sb0 + sl : cb + GSUB;             // end of the piece in the slot
+        u32x4 vec = vnext;
+        const Rec r0 = rnext;
+        const uint32_t rj0 = rj;
+        // the records that are done with after this piece: their field ends inside it (they come first: slot order)
+        {
+        const uint32_t j = rj0 + lane;
+        rj += (uint32_t)__popcll(__ballot(j < H && r0.pos + 3u < pend));
+        }
+        if (pb + GSUB < sl)
+          {
+          vnext = load_vec(pb + GSUB);
+          rnext = load_rec(rj + lane);
+          }
+        *(u32x4*)(PB + 16u * lane) = u32x4{ 0u, 0u, 0u, 0u };
+        if (lane < GSUB / 32u)
+          U[lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // the records with a byte in the piece: from the first whose field ends in it to the last whose header begins in it
+        for (uint32_t j0 = rj0; j0 < H; j0 += 64u)
+          {
+          const uint32_t j = j0 + lane;
+          const Rec r = j0 == rj0 ? r0 : load_rec(j);
+          const uint32_t ln = r.lc & 15u, hdr = r.pos - (r.meta & 255u), h24 = (r.lc >> 4) << (3u * ((r.meta >> 8) & 7u));
+          const bool in = j < H && hdr < pend;
+          if (in)
+            {
+            for (uint32_t bb = 0; bb < 4u; ++bb)
+              {
+              const uint32_t q = r.pos + bb - cb;                  // wraps to a huge number before the piece
+              if (q < GSUB)
+                {
+                if (bb < ln)
+                  PB[q] = (uint8_t)(r.x >> (8u * (ln - 1u - bb)));
+                else
+                  atomicOr(&U[q >> 5], 1u << (q & 31u));
+                }
+              }
+            for (uint32_t bb = 0; bb < 3u; ++bb)
+              {
+              const uint32_t q = hdr + bb - cb;
+              const uint32_t by = (h24 >> (8u * (2u - bb))) & 255u;
+              if (q < GSUB && by)
+                atomicOr((uint32_t*)PB + (q >> 2), by << (8u * (q & 3u)));       // (records of one group share its header)
+              }
+            }
+          if (j0 != rj0)
+            rj += (uint32_t)__popcll(__ballot(j < H && r.pos + 3u < pend));     // (beyond the first 64: rnext was loaded too early)
+          if (__ballot(in) != ~0ull)
+            break;
+          if (j0 == rj0 && pb + GSUB < sl)
+            rnext = load_rec(0xffffffffu);                       // more than 64 records in the piece: rj is not final yet, see below
+          }
+        if (rnext.pos == 0xffffffffu && pb + GSUB < sl)
+          rnext = load_rec(rj + lane);                            // (also reloads for lanes past the last record: harmless)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        {
+        const u32x4 pt = *(const u32x4*)(PB + 16u * lane);
+        vec[0] |= pt[0]; vec[1] |= pt[1]; vec[2] |= pt[2]; vec[3] |= pt[3];
+        }
+        uint32_t m16 = (U[lane >> 1] >> (16u * (lane & 1u))) & 0xffffu;
+        if (sb + 16u > pend)
+          m16 |= sb >= pend ? 0xffffu : (0xffffu << (pend - sb)) & 0xffffu;       // beyond the sub-chunk's content
+        const uint32_t cnt = 16u - (uint32_t)__popc(m16);
+        const uint32_t incl = wave_scan_incl(cnt);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t p = (wpos + (incl - cnt)) & (WRING - 1u);
+        if (m16 == 0u && p + 19u <= WRING)
+          lds_store16(obase + p, vec);
+        else
+          {
+          uint32_t q = p;
+#pragma unroll
+          for (int bb = 0; bb < 16; ++bb)
+            if (!((m16 >> bb) & 1u))
+              {
+              O[q] = (uint8_t)(vec[bb >> 2] >> (8 * (bb & 3)));
+              q = (q + 1u) & (WRING - 1u);
+              }
+          }
+        wpos += total;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // whole vectors leave the ring (at most 65 are in it)
+        const uint32_t nvec = (wpos - rpos) >> 4;
+        for (uint32_t t = lane; t < nvec; t += 64u)
+          {
+          const uint32_t q = rpos + 16u * t;
+          const u32x4 o = *(const u32x4*)(O + (q & (WRING - 1u)));
+          if (q >= A)
+            __builtin_nontemporal_store(o, (u32x4*)(rbase + q));
+          else
+            for (uint32_t bb = A; bb < 16u; ++bb)                 // the first vector of the sub-chunk: its first A bytes are somebody else's
+              rbase[bb] = (uint8_t)(o[bb >> 2] >> (8u * (bb & 3u)));
+          }
+        rpos += 16u * nvec;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+      // the bytes of the last, partial vector
+      const uint32_t q = rpos + lane;
+      if (lane < 16u && q < wpos && q >= A)
+        rbase[q] = O[q & (WRING - 1u)];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+    // the next sub-chunk nobody has taken
+    uint32_t nk = 0;
+    if (lane == 0)
+      nk = atomicAdd(&next_sub, 1u);
+    k = (uint32_t)__builtin_amdgcn_readfirstlane((int)nk);
+    }
   }
 
 unsigned guard_workgroups(const Plan& p) { return p.S < GUARD_WGS ? p.S : GUARD_WGS; }
@@ -1233,7 +1454,7 @@ int launch_fpc32_sweep(const uint32_t* d_src, uint32_t n, int arity, const Plan&
   GuardMeta* gmeta = (GuardMeta*)(d_ws + p.off_gmeta);
   static const uint32_t tune = [] {
     const char* e = getenv("TRICO_FPC32_PRIO"), * l = getenv("TRICO_FPC32_LAG");
-    return (e ? (uint32_t)atoi(e) & 255u : 1u) | ((l ? (uint32_t)atoi(l) & 255u : 0u) << 8);
+    return (e ? (uint32_t)atoi(e) & 255u : 1u) | ((l ? (uint32_t)atoi(l) & 255u : 8u) << 8);
   }();
   static const bool use_asm = [] { const char* e = getenv("TRICO_FPC32_ASM"); return !(e && e[0] == '0'); }();      // (0: the compiled step, for A/B runs)
   static std::atomic<uint32_t> encodes{ 0 };
@@ -1250,10 +1471,10 @@ int launch_fpc32_sweep(const uint32_t* d_src, uint32_t n, int arity, const Plan&
 #endif
   if (use_asm)
     hipLaunchKernelGGL((k_fpc32_sweep<HOOK, true>), dim3(p.S + G), dim3(threads), lds, st, d_src, n, arity, p.L, p.S, outT,
-                       slots, p.slot_stride, p.segcap, segbytes, nrec, recs, tune, sabotage, seed, gslots, grecs, gmeta);
+                       slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, tune, sabotage, seed, gslots, grecs, gmeta);
   else
     hipLaunchKernelGGL((k_fpc32_sweep<HOOK, false>), dim3(p.S + G), dim3(threads), lds, st, d_src, n, arity, p.L, p.S, outT,
-                       slots, p.slot_stride, p.segcap, segbytes, nrec, recs, tune, sabotage, seed, gslots, grecs, gmeta);
+                       slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, tune, sabotage, seed, gslots, grecs, gmeta);
   const unsigned colblocks = ((unsigned)arity * TAB + 255u) / 256u;
   hipLaunchKernelGGL(k_fpc32_pscan_a, dim3(colblocks, p.nch), dim3(256), 0, st, outT, p.S, arity, chlast);
   hipLaunchKernelGGL(k_fpc32_pscan_b, dim3(colblocks, p.nch), dim3(256), 0, st, outT, p.S, arity, chlast, inc);

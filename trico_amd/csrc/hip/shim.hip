@@ -825,6 +825,11 @@ static int decode_complete(trico_hip_ctx* ctx, const char* what)
   uint32_t st = ctx->h_pinned[0];
   for (int attempt = g_first_attempt + 1; ctx->chk_active && st != 0 && (st & ~(CHECK_BITS | FPC_STATUS_TIMEOUT)) == 0 && attempt <= 3; ++attempt)
     {
+    // An archive that has already shown a stream of another writer (below) will show more: its streams fail the check every time,
+    // by construction, not because a chain lost its tables - they go straight to the last rung instead of through two more chain
+    // decodes each.
+    if (ctx->other_writer_seen && attempt < 3 && !(st & FPC_STATUS_TIMEOUT))
+      attempt = 3;
     // the payload parsed but the values do not code back to it: the chain went wrong (see fpc_chain_decode).  Twice more, then
     // in reference order without the scalar cache (20x slower).
     g_repeats += 1;
@@ -867,6 +872,17 @@ static int decode_complete(trico_hip_ctx* ctx, const char* what)
       // reference's encoder (another writer may choose other, equally decodable codes): the values stand, and word 3 of
       // trico_hip_last_stats counts the stream so that a caller can see it.
       g_other_writer += 1;
+      ctx->other_writer_seen = true;
+      static const bool strict = [] { const char* e = getenv("TRICO_HIP_STRICT"); return e && e[0] == '1'; }();
+      if (strict)
+        {
+        // TRICO_HIP_STRICT=1: a caller that only ever reads archives of the reference's own writer (or this library's) wants to hear
+        // about it instead of getting values
+        ctx->chk_active = false;
+        set_error("trico decode: the payload decodes, but the reference's encoder would not have written it (the values, decoded in "
+                  "reference order, do not code back to it); refused because TRICO_HIP_STRICT=1");
+        return 0;
+        }
       st = 0;
       }
     }

@@ -743,7 +743,12 @@ static void start_readahead(struct trico_archive* a, void* out)
     {
     (void)trico_hip_decode_jobs(jobs, n);            /* per-job results below: a stream that failed fails in its own read call */
     for (int i = 0; i < n; ++i)
-      ra[i].ok = jobs[i].ok;
+      {
+      ra[i].ok = jobs[i].ok > 0;
+      if (jobs[i].ok < 0)
+        release_entry(&ra[i]);                       /* not attempted (no memory for the batch, a launch that failed): the stream's own
+                                                        read call decodes it alone, as if there had been no read-ahead */
+      }
     a->ra = ra;
     a->ra_n = n;
     }
@@ -994,7 +999,7 @@ int trico_hip_read_archives(void* const* archives, int count, void* const* const
     struct trico_archive* a = (struct trico_archive*)archives[k];
     for (int s_ = 0; s_ < parsed[k]; ++s_)
       {
-      if (!jobs[at + s_].ok)
+      if (jobs[at + s_].ok <= 0)
         {
         all = 0;
         break;
