@@ -26,10 +26,11 @@ constexpr uint32_t SENT = 0x7fc0dead;
 constexpr uint32_t FLAG_ORDER = FPC32_FLAG_ORDER, FLAG_SENTINEL = FPC32_FLAG_SENTINEL;
 
 // Record of a deferred value (k_fpc32_sweep -> k_fpc32_fixup -> k_fpc32_gather):
-//   w0 slot offset of the value's four reserved bytes      w1 dh | gi << 8 | ft1 << 12 | ft2 << 13 | k1 << 16 | k2 << 20
+//   w0 slot offset of the value's four reserved bytes      w1 dh | gi << 8 | ft1 << 12 | ft2 << 13 | k2 << 20
 //   w2 the value   w3 its predecessor   w4 the prediction that IS known (one open class), else 0
 //   w6 residual, w7 length | code << 4  (written by the fix-up)
-// dh = distance from the group's header to the four bytes (3..31), gi = index in the group, k1 / k2 = FCM / DFCM class.
+// dh = distance from the group's header to the four bytes (3..31), gi = index in the group, k2 = DFCM class (the FCM class is
+// the top four bits of w3); ft1 / ft2 = the FCM / DFCM prediction is the one the segment does not know.
 
 struct Plan
   {

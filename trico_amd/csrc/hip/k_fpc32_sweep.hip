@@ -291,7 +291,7 @@ __device__ __forceinline__ void step_tail(uint32_t v, uint32_t a, uint32_t a1, u
       {
       u32x4 w;
       w[0] = sw.flushed + (hq - sbase) + 3u;
-      w[1] = (3u + pre - pre_lead) | ((lk.lane & 7u) << 8) | ((uint32_t)ft1 << 12) | ((uint32_t)ft2 << 13) | (((a1 >> 2) & 15u) << 16) |
+      w[1] = (3u + pre - pre_lead) | ((lk.lane & 7u) << 8) | ((uint32_t)ft1 << 12) | ((uint32_t)ft2 << 13) |
              (((a2 - (t1abs + 64u)) >> 2) << 20);
       w[2] = v;
       w[3] = a;
@@ -611,7 +611,7 @@ __device__ __forceinline__ void write_records(uint64_t ft1, uint64_t ft2, uint32
     {
     u32x4 w;
     w[0] = sw.flushed + (hq1 + 1u - sbase) + 3u;
-    w[1] = (3u + pre - pre_lead) | ((lk.lane & 7u) << 8) | ((uint32_t)f1 << 12) | ((uint32_t)f2 << 13) | (((a1 >> 2) & 15u) << 16) |
+    w[1] = (3u + pre - pre_lead) | ((lk.lane & 7u) << 8) | ((uint32_t)f1 << 12) | ((uint32_t)f2 << 13) |
            (((a2 - (t1abs + 64u)) >> 2) << 20);
     w[2] = v;
     w[3] = a;
@@ -1084,8 +1084,8 @@ __device__ __forceinline__ void fixup_rows(int arity, uint32_t S, const uint32_t
     const u32x4 w = *(const u32x4*)(list + RECW * j);
     const uint32_t known = list[RECW * j + 4u];
     const bool ft1 = (w[1] >> 12) & 1u, ft2 = (w[1] >> 13) & 1u;
-    const uint32_t k1 = (w[1] >> 16) & 15u, k2 = 16u + ((w[1] >> 20) & 1023u);
     const uint32_t v = w[2], a = w[3];
+    const uint32_t k1 = a >> 28, k2 = 16u + ((w[1] >> 20) & 1023u);        // (fpsc.c:96-97: the FCM class is the predecessor's top four bits)
     const uint32_t p1 = ft1 ? row[k1] : known;
     const uint32_t p2 = ft2 ? row[k2] : known;
     const uint32_t x1 = v ^ p1, x2 = v ^ (a + p2);
@@ -1123,7 +1123,7 @@ __global__ void __launch_bounds__(256) k_fpc32_fixup(int arity, uint32_t S, cons
 // ---- gather: segment slots -> contiguous payload ----------------------------------------------------------------------------
 // grid (S, components); each workgroup moves one segment.  Without records: the destination is written as aligned 16-byte vectors,
 // the source (a 256-byte aligned slot) is read as 4 + 1 dwords per vector and re-aligned with v_alignbyte.
-// With records the slot is cut into sub-chunks of 1 KiB of SOURCE bytes (more for slots beyond 2 MiB).  A pass over the records
+// With records the slot is cut into sub-chunks of 1 KiB of SOURCE bytes (more for slots beyond 512 KiB).  A pass over the records
 // counts the unused bytes of every sub-chunk - a prefix sum says where its output begins - and marks the ones a record touches.
 // Then every WAVE takes sub-chunks by itself, no barrier: an untouched one is the copy with a shift again; a touched one passes
 // through the wave's own LDS, 64 x 16 bytes at a time: the records put their residual bytes and code bits into a patch area (ORed
@@ -1132,8 +1132,8 @@ __global__ void __launch_bounds__(256) k_fpc32_fixup(int arity, uint32_t S, cons
 // modulo 16 and leave it as aligned 16-byte vectors.  Every output byte is written once, by the wave that owns it; the partial
 // vectors at the ends of a sub-chunk's output go byte by byte.  Nothing is searched: a record knows its slot position.
 constexpr uint32_t GSUB = 1024;                    // source bytes per piece (64 lanes x 16)
-constexpr uint32_t MAXSUB = 2048;                  // sub-chunks per slot
-constexpr uint32_t WRING = 2048;                   // a wave's output ring (power of two; at most 15 + 1024 bytes are in it at a time)
+constexpr uint32_t MAXSUB = 512;                   // sub-chunks per slot (LDS: 8 workgroups per compute unit)
+constexpr uint32_t WRING = 1024 + 64;              // a wave's output buffer: at most 15 + 1024 bytes are in it at a time (+ the slack of a 16-byte store)
 struct GatherDst { uint8_t* p[3]; };
 
 // 16 bytes in a row to LDS byte address ad.  An LDS dword store at an address that is not a multiple of four costs about eight
@@ -1275,7 +1275,42 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
     sub_out[nsub] = run;                                           // (= len)
   }
   __syncthreads();
-  // from here on every wave is on its own
+  // The sub-chunks no record touches first, by the whole workgroup: ONE loop over their 16-byte vectors (a copy with a shift as for
+  // a segment without records; a loop per stretch of such sub-chunks paid a memory round trip per stretch).
+  {
+  const uint32_t vshift = subshift - 4u, per = 1u << vshift;     // destination vectors a sub-chunk can have
+  for (uint32_t idx = tid; idx < (nsub << vshift); idx += 256u)
+    {
+    const uint32_t kk = idx >> vshift, i = idx & (per - 1u);
+    if ((touched[kk >> 5] >> (kk & 31u)) & 1u)
+      continue;
+    const uint32_t sb0 = kk << subshift;
+    const uint32_t sl = slen - sb0 < subsize ? slen - sb0 : subsize;
+    uint8_t* dd0 = d + sub_out[kk];
+    const uint8_t* sc = s + sb0;
+    const uint32_t head = (uint32_t)((16u - ((uintptr_t)dd0 & 15u)) & 15u);
+    const uint32_t h = head < sl ? head : sl;
+    const uint32_t body = (sl - h) >> 4, done = h + 16u * body;
+    if (i < body)
+      {
+      const uint32_t* ss = (const uint32_t*)sc + (h >> 2) + 4u * i;
+      const uint32_t sh = h & 3u;
+      const u32x4 lo = *(const u32x4*)ss;
+      const uint32_t hi = ss[4];
+      u32x4 o;
+      o[0] = __builtin_amdgcn_alignbyte(lo[1], lo[0], sh);
+      o[1] = __builtin_amdgcn_alignbyte(lo[2], lo[1], sh);
+      o[2] = __builtin_amdgcn_alignbyte(lo[3], lo[2], sh);
+      o[3] = __builtin_amdgcn_alignbyte(hi, lo[3], sh);
+      __builtin_nontemporal_store(o, (u32x4*)(dd0 + h) + i);
+      }
+    if (i < h)
+      dd0[i] = sc[i];
+    if (i < sl - done)
+      dd0[done + i] = sc[done + i];
+    }
+  }
+  // the others: from here on every wave is on its own
   const uint32_t lane = tid & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
   uint8_t* PB = (uint8_t*)wlds[wv];                              // [GSUB] patches of the piece
   uint32_t* U = wlds[wv] + GSUB / 4;                             // [GSUB / 32] its unused bytes, one bit each
@@ -1287,14 +1322,13 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
     const uint32_t sb0 = k << subshift;
     const uint32_t sl = slen - sb0 < subsize ? slen - sb0 : subsize;             // source bytes of this sub-chunk
     uint8_t* dd0 = d + sub_out[k];
-    if (!((touched[k >> 5] >> (k & 31u)) & 1u))
-      copy_shifted(dd0, s + sb0, sl, lane, 64u);
-    else
+    if ((touched[k >> 5] >> (k & 31u)) & 1u)
       {
-      // ring position p <-> destination byte rbase + p, rbase 16-byte aligned
-      const uint32_t A = (uint32_t)((uintptr_t)dd0 & 15u);
+      // buffer position p <-> destination byte rbase + p, rbase 16-byte aligned; after every piece the whole vectors leave and
+      // the (fewer than 16) bytes behind them move to the front: positions never wrap
+      uint32_t A = (uint32_t)((uintptr_t)dd0 & 15u);             // the first vector of the sub-chunk: its first A bytes are somebody else's
       uint8_t* rbase = dd0 - A;
-      uint32_t wpos = A, rpos = 0;
+      uint32_t wpos = A;
       uint32_t rj = rfirst[k];
       // The piece in hand and the loads of the next one: its 16 bytes per lane and the record each lane looks at first (a piece
       // rarely has more than 64).  A wave has nobody to cover its memory round trips here, so they are started a piece ahead.
@@ -1320,6 +1354,7 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
         };
       u32x4 vnext = load_vec(0u);
       Rec rnext = load_rec(rj + lane);
+      const uint32_t pbase = (uint32_t)(uintptr_t)(lds_u8*)PB;
       for (uint32_t pb = 0; pb < sl; pb += GSUB)
         {
         const uint32_t cb = sb0 + pb, sb = cb + 16u * lane;
@@ -1342,6 +1377,7 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
           U[lane] = 0u;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // the records with a byte in the piece: from the first whose field ends in it to the last whose header begins in it
+        bool again = false;                                        // more than 64 of them: rnext was loaded before rj was final
         for (uint32_t j0 = rj0; j0 < H; j0 += 64u)
           {
           const uint32_t j = j0 + lane;
@@ -1350,34 +1386,61 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
           const bool in = j < H && hdr < pend;
           if (in)
             {
-            for (uint32_t bb = 0; bb < 4u; ++bb)
+            const uint32_t q = r.pos - cb, hq = hdr - cb;          // (wrap to huge numbers before the piece)
+            if (q <= GSUB - 4u)
               {
-              const uint32_t q = r.pos + bb - cb;                  // wraps to a huge number before the piece
-              if (q < GSUB)
+              // the whole field lies in the piece: its residual bytes, most significant first, with one store (nobody else has a
+              // byte there), the unused ones behind them with one mask
+              const uint32_t be = ln ? __builtin_bswap32(r.x << (8u * (4u - ln))) : 0u;
+              asm volatile("ds_write_b32 %0, %1" :: "v"(pbase + q), "v"(be) : "memory");      // (not dword aligned: gfx950 executes it)
+              const uint32_t um = (0xfu << ln) & 0xfu, sh = q & 31u;
+              if (um)
                 {
-                if (bb < ln)
-                  PB[q] = (uint8_t)(r.x >> (8u * (ln - 1u - bb)));
-                else
-                  atomicOr(&U[q >> 5], 1u << (q & 31u));
+                atomicOr(&U[q >> 5], um << sh);
+                if (sh > 28u)
+                  atomicOr(&U[(q >> 5) + 1u], um >> (32u - sh));
                 }
               }
-            for (uint32_t bb = 0; bb < 3u; ++bb)
+            else
+              for (uint32_t bb = 0; bb < 4u; ++bb)
+                {
+                const uint32_t qq = q + bb;
+                if (qq < GSUB)
+                  {
+                  if (bb < ln)
+                    PB[qq] = (uint8_t)(r.x >> (8u * (ln - 1u - bb)));
+                  else
+                    atomicOr(&U[qq >> 5], 1u << (qq & 31u));
+                  }
+                }
+            if (h24)
               {
-              const uint32_t q = hdr + bb - cb;
-              const uint32_t by = (h24 >> (8u * (2u - bb))) & 255u;
-              if (q < GSUB && by)
-                atomicOr((uint32_t*)PB + (q >> 2), by << (8u * (q & 3u)));       // (records of one group share its header)
+              if (hq <= GSUB - 3u)
+                {
+                // the three header bytes, big-endian, as one or two ORs on dwords (records of one group share its header)
+                const uint32_t hw = __builtin_bswap32(h24 << 8), hs = 8u * (hq & 3u);
+                atomicOr((uint32_t*)PB + (hq >> 2), hw << hs);
+                if (hs > 8u)
+                  atomicOr((uint32_t*)PB + (hq >> 2) + 1u, hw >> (32u - hs));
+                }
+              else
+                for (uint32_t bb = 0; bb < 3u; ++bb)
+                  {
+                  const uint32_t qq = hq + bb;
+                  const uint32_t by = (h24 >> (8u * (2u - bb))) & 255u;
+                  if (qq < GSUB && by)
+                    atomicOr((uint32_t*)PB + (qq >> 2), by << (8u * (qq & 3u)));
+                  }
               }
             }
           if (j0 != rj0)
             rj += (uint32_t)__popcll(__ballot(j < H && r.pos + 3u < pend));     // (beyond the first 64: rnext was loaded too early)
           if (__ballot(in) != ~0ull)
             break;
-          if (j0 == rj0 && pb + GSUB < sl)
-            rnext = load_rec(0xffffffffu);                       // more than 64 records in the piece: rj is not final yet, see below
+          again = true;
           }
-        if (rnext.pos == 0xffffffffu && pb + GSUB < sl)
-          rnext = load_rec(rj + lane);                            // (also reloads for lanes past the last record: harmless)
+        if (again && pb + GSUB < sl)
+          rnext = load_rec(rj + lane);                            // (not by looking at rnext: that would wait for the load just issued)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         {
         const u32x4 pt = *(const u32x4*)(PB + 16u * lane);
@@ -1389,41 +1452,52 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
         const uint32_t cnt = 16u - (uint32_t)__popc(m16);
         const uint32_t incl = wave_scan_incl(cnt);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        const uint32_t p = (wpos + (incl - cnt)) & (WRING - 1u);
-        if (m16 == 0u && p + 19u <= WRING)
+        const uint32_t p = wpos + (incl - cnt);
+        if (m16 == 0u)
           lds_store16(obase + p, vec);
         else
           {
+          // a lane with unused bytes among its sixteen: the bytes before the first of them as a whole, the rest one by one
           uint32_t q = p;
 #pragma unroll
           for (int bb = 0; bb < 16; ++bb)
             if (!((m16 >> bb) & 1u))
               {
               O[q] = (uint8_t)(vec[bb >> 2] >> (8 * (bb & 3)));
-              q = (q + 1u) & (WRING - 1u);
+              ++q;
               }
           }
         wpos += total;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // whole vectors leave the ring (at most 65 are in it)
-        const uint32_t nvec = (wpos - rpos) >> 4;
+        // whole vectors leave (at most 65 are there), what is behind them moves to the front
+        const uint32_t nvec = wpos >> 4;
         for (uint32_t t = lane; t < nvec; t += 64u)
           {
-          const uint32_t q = rpos + 16u * t;
-          const u32x4 o = *(const u32x4*)(O + (q & (WRING - 1u)));
-          if (q >= A)
-            __builtin_nontemporal_store(o, (u32x4*)(rbase + q));
+          const u32x4 o = *(const u32x4*)(O + 16u * t);
+          if (t > 0u || A == 0u)
+            __builtin_nontemporal_store(o, (u32x4*)(rbase + 16u * t));
           else
-            for (uint32_t bb = A; bb < 16u; ++bb)                 // the first vector of the sub-chunk: its first A bytes are somebody else's
+            for (uint32_t bb = A; bb < 16u; ++bb)
               rbase[bb] = (uint8_t)(o[bb >> 2] >> (8u * (bb & 3u)));
           }
-        rpos += 16u * nvec;
+        if (nvec)
+          {
+          const uint32_t rest = wpos & 15u;
+          uint32_t tb = 0;
+          if (lane < rest)
+            tb = O[16u * nvec + lane];
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          if (lane < rest)
+            O[lane] = (uint8_t)tb;
+          rbase += 16u * nvec;
+          wpos = rest;
+          A = 0u;
+          }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
       // the bytes of the last, partial vector
-      const uint32_t q = rpos + lane;
-      if (lane < 16u && q < wpos && q >= A)
-        rbase[q] = O[q & (WRING - 1u)];
+      if (lane < 16u && lane < wpos && lane >= A)
+        rbase[lane] = O[lane];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
     // the next sub-chunk nobody has taken
