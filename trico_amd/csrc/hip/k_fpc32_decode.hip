@@ -88,92 +88,19 @@ __device__ __forceinline__ uint32_t lens_sum(uint32_t x)
 //   s[56:57] = {T1 entry of the current hash, 0}    s[58:59] = {cand, lm}: one s_cselect_b64 picks {stride, value} or {T1 entry, 0}
 //   s[60:67], s[68:75] residuals of the current / next eight values      s[84:99] the FCM table (s_movrels / s_movreld, M0 = hash)
 //   D: register with the mask word of value K, DN: of value K + 1
-#define CH4_XLOAD(K) "s_load_dwordx8 s[60 + (((" #K ") + 8) & 15) : 67 + (((" #K ") + 8) & 15)], s[78:79], 4 * ((" #K ") + 8)\n"
-#define CH4_NOX(K) ""
-#define CH4_STEP(K, D, DN, PIN, PINV, POUTS, POUTV, AO, AN, XL)       \
-  "s_bitcmp1_b32 " D ", (" #K ") & 31\n"                             \
-  "s_cselect_b64 s[58:59], " PIN ", s[56:57]\n"                      \
-  "s_bitcmp1_b32 %[g], (" #K ") & 31\n"                              \
-  "s_waitcnt lgkmcnt(0)\n"                                           \
-  "s_cselect_b32 %[q], %[t2], s58\n"                                 \
-  "s_add_u32 %[q], %[q], s59\n"                                      \
-  "s_xor_b32 " POUTV ", s[60 + ((" #K ") & 15)], %[q]\n"             \
-  "s_sub_u32 " POUTS ", " POUTV ", " PINV "\n"                       \
-  "s_store_dword " POUTS ", %[T2b], %[" AO "]\n"                     \
-  "s_and_b32 %[h], " POUTS ", 0xffc00000\n"                          \
-  "s_xor_b32 %[q], %[h], %[P]\n"                                     \
-  "s_lshr_b32 %[" AN "], %[q], 20\n"                                 \
-  "s_load_dword %[t2], %[T2b], %[" AN "]\n"                          \
-  XL(K)                                                               \
-  "s_movreld_b32 s84, " POUTV "\n"                                   \
-  "s_lshr_b32 m0, " POUTV ", 28\n"                                   \
-  "s_lshl_b32 %[P], %[h], 5\n"                                       \
-  "s_movrels_b32 s56, s84\n"                                         \
-  "s_cmp_lg_u32 %[" AN "], %[" AO "]\n"                              \
-  "s_cselect_b32 %[g], " DN ", 0\n"                                  \
-  "v_writelane_b32 %[outv], " POUTV ", " #K "\n"
-#define CH4_EVEN(K, D, DN, XL) CH4_STEP(K, D, DN, "s[52:53]", "s53", "s54", "s55", "a2a", "a2b", XL)
-#define CH4_ODD(K, D, DN, XL) CH4_STEP(K, D, DN, "s[54:55]", "s55", "s52", "s53", "a2b", "a2a", XL)
-#define CH4_OCT(B, D, DN, XL) CH4_EVEN(B + 0, D, D, XL) CH4_ODD(B + 1, D, D, CH4_NOX) CH4_EVEN(B + 2, D, D, CH4_NOX) CH4_ODD(B + 3, D, D, CH4_NOX) \
-                              CH4_EVEN(B + 4, D, D, CH4_NOX) CH4_ODD(B + 5, D, D, CH4_NOX) CH4_EVEN(B + 6, D, D, CH4_NOX) CH4_ODD(B + 7, D, DN, CH4_NOX)
-
-// Runs of exact hits.  When the parser has flagged a batch (64 values FCM-coded without residual, or 64 values DFCM-coded with
-// a zero residual) and its first two values have come out with one stride S - zero for the FCM kind; for the DFCM kind with a
-// stationary hash (the entry the next value needs is the one just stored) - then every later value of the batch is its
-// predecessor plus S, the DFCM entry of that hash stays S, and of the FCM table only the entry of the values' common top four
-// bits changes (to the last value), provided those bits are common: |S| < 2^25 and first and last of the 62 in one class.
-// The 62 values are then one multiply-add on the vector unit instead of 62 x 20 scalar instructions (a smooth coordinate of a
-// regular grid decodes at the parser's speed, ~12 ns per value); anything else falls through to the steps.
-// After odd step 1: s52 = stride, s53 = value 1, s54 = stride of value 0, a2a = current DFCM address, a2b = the one before.
-#define CH4_RUN \
-  "s_cmp_eq_u32 %[kind], 0\n"                   \
-  "s_cbranch_scc1 5f\n"                         \
-  "s_cmp_eq_u32 s52, s54\n"                     \
-  "s_cbranch_scc0 5f\n"                         \
-  "s_cmp_eq_u32 %[kind], 1\n"                   \
-  "s_cselect_b32 %[q], s52, 0\n"                \
-  "s_cmp_eq_u32 %[q], 0\n"                      \
-  "s_cbranch_scc0 5f\n"                         \
-  "s_cmp_eq_u32 %[kind], 2\n"                   \
-  "s_cselect_b32 %[q], %[a2b], %[a2a]\n"        \
-  "s_cmp_eq_u32 %[q], %[a2a]\n"                 \
-  "s_cbranch_scc0 5f\n"                         \
-  "s_abs_i32 %[q], s52\n"                       \
-  "s_cmp_lt_u32 %[q], 0x2000000\n"              \
-  "s_cbranch_scc0 5f\n"                         \
-  "s_mul_i32 %[q], s52, 61\n"                   \
-  "s_add_u32 %[q], %[q], s53\n"                 \
-  "s_xor_b32 %[h], %[q], s53\n"                 \
-  "s_lshr_b32 %[h], %[h], 28\n"                 \
-  "s_cmp_eq_u32 %[h], 0\n"                      \
-  "s_cbranch_scc0 5f\n"                         \
-  "s_mov_b64 exec, -4\n"                        \
-  "v_mul_lo_u32 %[vt], %[lanem1], s52\n"        \
-  "v_add_u32 %[outv], s53, %[vt]\n"             \
-  "s_mov_b64 exec, -1\n"                        \
-  "s_lshr_b32 m0, %[q], 28\n"                   \
-  "s_add_u32 s53, %[q], s52\n"                  \
-  "s_movreld_b32 s84, s53\n"                    \
-  "s_lshr_b32 m0, s53, 28\n"                    \
-  "s_store_dword s52, %[T2b], %[a2a]\n"         \
-  "s_movrels_b32 s56, s84\n"                    \
-  "s_waitcnt lgkmcnt(0)\n"                      \
-  "s_load_dword %[t2], %[T2b], %[a2a]\n"        \
-  "s_cmp_eq_u32 s52, s52\n"                     \
-  "s_branch 6f\n"                               \
-  "5:\n"
-#define CH4_OCT0(D, XL) CH4_EVEN(0, D, D, XL) CH4_ODD(1, D, D, CH4_NOX) CH4_RUN CH4_EVEN(2, D, D, CH4_NOX) CH4_ODD(3, D, D, CH4_NOX) \
-                        CH4_EVEN(4, D, D, CH4_NOX) CH4_ODD(5, D, D, CH4_NOX) CH4_EVEN(6, D, D, CH4_NOX) CH4_ODD(7, D, D, CH4_NOX)
+#include "chain5_bodies.inc"
 
 // Scratch of one stream in global memory (FPC32_DECODE_TABLE_BYTES), touched by this workgroup only and only through the
-// scalar cache: DFCM table (4 KiB), FCM table for the tail (64 B), at SCRATCH_X RING slots of 512 B (64 residuals, then the
-// mask of DFCM-coded values), then the two counters that couple the waves, each in a cache line of its own.
+// scalar cache: DFCM table (4 KiB), FCM table for the tail (64 B), at SCRATCH_X RING slots of 17 records of 32 bytes (16 quads
+// and the record that ends the batch), then the two counters that couple the waves and the address of the chain's code, each in
+// a cache line of its own.
 constexpr uint32_t SCRATCH_DWORDS = 2048, SCRATCH_T1 = 1024, SCRATCH_X = 1088;
 constexpr uint32_t RING = 4;                  // batches the parser may run ahead of the chain
-constexpr uint32_t SLOT_DWORDS = 128;
-constexpr uint32_t SCRATCH_PRODUCED = SCRATCH_X + RING * SLOT_DWORDS, SCRATCH_CONSUMED = SCRATCH_PRODUCED + 16;
-constexpr uint32_t SCRATCH_USED = SCRATCH_CONSUMED + 16;          // dwords zeroed at the start (a multiple of 16)
-static_assert(SCRATCH_PRODUCED * 4 == 0x1900 && SCRATCH_CONSUMED * 4 == 0x1940 && SCRATCH_USED <= SCRATCH_DWORDS, "offsets are spelled out in the chain");
+constexpr uint32_t REC_DWORDS = 8, SLOT_DWORDS = 18 * REC_DWORDS;
+constexpr uint32_t SCRATCH_PRODUCED = SCRATCH_X + RING * SLOT_DWORDS, SCRATCH_CONSUMED = SCRATCH_PRODUCED + 16, SCRATCH_CODE = SCRATCH_CONSUMED + 16;
+constexpr uint32_t SCRATCH_USED = SCRATCH_CODE + 16;              // dwords zeroed at the start (a multiple of 16)
+static_assert(SCRATCH_X * 4 == 0x1100 && SLOT_DWORDS * 4 == 0x240 && SCRATCH_PRODUCED * 4 == 0x1a00 && SCRATCH_CONSUMED * 4 == 0x1a40 &&
+              SCRATCH_CODE * 4 == 0x1a80 && SCRATCH_USED <= SCRATCH_DWORDS, "offsets are spelled out in the chain");
 constexpr uint32_t ABORT = 0xffffffffu;       // `produced` when the parser gives up: the chain stops
 
 struct ChainEnd { uint32_t last, a2, timed_out; };   // what the tail loop needs: last value, byte address of the current DFCM entry
@@ -185,111 +112,125 @@ struct ChainEnd { uint32_t last, a2, timed_out; };   // what the tail loop needs
 // ends with status FPC_STATUS_TIMEOUT instead of spinning for ever, and the host repeats the stream.
 constexpr uint32_t SPIN_LIMIT_CHAIN = 1u << 25, SPIN_LIMIT_PARSER = 1u << 23;
 
-// The whole chain of a stream: batches 0 .. nb-1 of 64 values.  Per batch: wait until the parser has published it (scalar load
-// of `produced`), load its mask and first eight residuals, 64 values, one vector store of the 64 values straight to their
-// place in the interleaved output (lane K holds value K), publish `consumed`.  One asm statement, so that the FCM table and the
-// rest of the state stay in their registers from the first value to the last.
-//   s[76:77] scratch / batch counter    s[78:79] ring slot of the batch    s[80:81] output address of the batch's value 0
-//   s82, s83 mask of DFCM-coded values
-__device__ __forceinline__ ChainEnd chain4_run(const uint32_t* T2b, uint32_t nb, uint32_t* out0, uint32_t voff, uint32_t out_step, uint32_t lanem1)
+// The whole chain of a stream: batches 0 .. nb-1 of 64 values, each 16 quads.  The parser writes a record per quad: its four
+// residuals, the address of the body that decodes its pattern of kinds (tools/gen_chain5.py), the bit of the lane its values go to and where
+// the next record is.  A body requests the next record first, decodes, and jumps to the address in it; the record behind the
+// sixteenth quad leads to the end of the batch: four vector stores of 16 lanes straight into the interleaved output (lane q
+// of register j holds value 4 q + j), `consumed` published, `produced` polled, the first record of the next batch loaded.
+// One asm statement, so that the FCM table and the rest of the state stay in their registers from the first value to the last.
+//   s46 the SCC between values, kept across the end of a batch    s76 scratch    s77 batch counter    s[80:81] output address of the batch's value 0
+__device__ __forceinline__ ChainEnd chain5_run(const uint32_t* T2b, uint32_t nb, uint32_t* out0, uint32_t va0, uint32_t va1, uint32_t va2,
+                                               uint32_t va3, uint32_t out_step, uint32_t lane4m1)
   {
-  const uint64_t xb = (uint64_t)(uintptr_t)(T2b + SCRATCH_X), ob = (uint64_t)(uintptr_t)out0;
-  const uint32_t xlo = (uint32_t)xb, xhi = (uint32_t)(xb >> 32), olo = (uint32_t)ob, ohi = (uint32_t)(ob >> 32);
-  uint32_t last, sprev, a2a, a2b, P, t2, fwd, outv, q, h, g, kind, vt, spin, tmo;
+  const uint64_t tb = (uint64_t)(uintptr_t)T2b, ob = (uint64_t)(uintptr_t)out0;
+  const uint32_t tlo = (uint32_t)tb, thi = (uint32_t)(tb >> 32), olo = (uint32_t)ob, ohi = (uint32_t)(ob >> 32);
+  uint32_t last, a2, o0, o1, o2, o3, vt, spin, tmo;
   asm volatile(
     "s_mov_b64 s[84:85], 0\n s_mov_b64 s[86:87], 0\n s_mov_b64 s[88:89], 0\n s_mov_b64 s[90:91], 0\n"
     "s_mov_b64 s[92:93], 0\n s_mov_b64 s[94:95], 0\n s_mov_b64 s[96:97], 0\n s_mov_b64 s[98:99], 0\n"
-    "s_mov_b64 s[52:53], 0\n s_mov_b64 s[56:57], 0\n s_mov_b32 m0, 0\n"
-    "s_mov_b32 %[a2a], 0\n s_mov_b32 %[P], 0\n s_mov_b32 %[t2], 0\n s_mov_b32 %[fwd], 1\n"
+    "s_mov_b64 s[52:53], 0\n s_mov_b64 s[54:55], 0\n s_mov_b32 s56, 0\n s_mov_b32 m0, 0\n"
+    "s_mov_b32 s42, 0\n s_mov_b32 s43, 0\n s_mov_b32 s44, 0\n s_mov_b32 s45, 0\n s_mov_b32 s46, 1\n"
+    "s_mov_b32 s36, %[tlo]\n s_mov_b32 s37, %[thi]\n"
     "s_mov_b32 s77, 0\n s_mov_b32 s80, %[olo]\n s_mov_b32 s81, %[ohi]\n"
     "s_mov_b32 %[spin], 0\n s_mov_b32 %[tmo], 0\n"
+    /* where the bodies are: the parser puts their addresses into the records */
+    "s_getpc_b64 s[38:39]\n"
+    ".Lc5_pc_%=:\n"
+    "s_add_u32 s38, s38, .Lc5_body_%= - .Lc5_pc_%=\n"
+    "s_addc_u32 s39, s39, 0\n"
+    "s_store_dwordx2 s[38:39], s[36:37], 0x1a80\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    "s_mov_b32 s40, 1\n"
+    "s_store_dword s40, s[36:37], 0x1a88\n"
     "s_cmp_lt_u32 s77, %[nb]\n"
-    "s_cbranch_scc0 3f\n"
-    "0:\n"
-    "s_load_dword s76, %[T2b], 0x1900\n"
-    "s_waitcnt lgkmcnt(0)\n"
-    "s_cmp_gt_u32 s76, s77\n"
-    "s_cbranch_scc1 1f\n"
-    /* bounded wait: a parser that does not publish for SPIN_LIMIT polls (seconds) will not publish at all */
-    "s_add_u32 %[spin], %[spin], 1\n"
-    "s_cmp_lt_u32 %[spin], %[limit]\n"
-    "s_cbranch_scc0 7f\n"
-    "s_sleep 1\n"
-    "s_branch 0b\n"
-    "7:\n"
-    "s_mov_b32 %[tmo], 1\n"
-    "s_mov_b32 s76, -1\n"
-    "s_store_dword s76, %[T2b], 0x1940\n"            /* consumed = ABORT: the parser stops too */
-    "s_branch 3f\n"
-    "1:\n"
-    "s_mov_b32 %[spin], 0\n"
-    "s_cmp_eq_u32 s76, -1\n"
-    "s_cbranch_scc1 3f\n"
-    "s_and_b32 s76, s77, 3\n"
-    "s_lshl_b32 s76, s76, 9\n"
-    "s_add_u32 s78, %[xlo], s76\n"
-    "s_addc_u32 s79, %[xhi], 0\n"
-    "s_load_dwordx2 s[82:83], s[78:79], 0x100\n"
-    "s_load_dword %[kind], s[78:79], 0x108\n"
-    "s_load_dwordx8 s[60:67], s[78:79], 0x0\n"
-    "s_cmp_eq_u32 %[fwd], 0\n"
-    "s_waitcnt lgkmcnt(0)\n"
-    "s_cselect_b32 %[g], s82, 0\n"
-    CH4_OCT0("s82", CH4_XLOAD) CH4_OCT(8, "s82", "s82", CH4_XLOAD) CH4_OCT(16, "s82", "s82", CH4_XLOAD) CH4_OCT(24, "s82", "s83", CH4_XLOAD)
-    CH4_OCT(32, "s83", "s83", CH4_XLOAD) CH4_OCT(40, "s83", "s83", CH4_XLOAD) CH4_OCT(48, "s83", "s83", CH4_XLOAD) CH4_OCT(56, "s83", "s83", CH4_NOX)
-    "6:\n"
-    "s_cselect_b32 %[fwd], 0, 1\n"                     /* SCC still says whether the last load address differed from the last store address */
-    "global_store_dword %[voff], %[outv], s[80:81]\n"
+    "s_cbranch_scc0 .Lc5_done_%=\n"
+    "s_branch .Lc5_poll_%=\n"
+    CH5_BODIES
+    ".Lc5_end_%=:\n"
+    "s_cselect_b32 s46, 1, 0\n"
+    "s_mov_b64 exec, 0xffff\n"
+    "global_store_dword %[va0], %[o0], s[80:81]\n"
+    "global_store_dword %[va1], %[o1], s[80:81]\n"
+    "global_store_dword %[va2], %[o2], s[80:81]\n"
+    "global_store_dword %[va3], %[o3], s[80:81]\n"
     "s_add_u32 s80, s80, %[ostep]\n"
     "s_addc_u32 s81, s81, 0\n"
     "s_add_u32 s77, s77, 1\n"
-    "s_store_dword s77, %[T2b], 0x1940\n"
+    "s_store_dword s77, s[36:37], 0x1a40\n"
     "s_cmp_lt_u32 s77, %[nb]\n"
-    "s_cbranch_scc1 0b\n"
-    "3:\n"
-    "s_mov_b32 %[sprev], s52\n"
-    "s_mov_b32 %[last], s53\n"
-    "s_store_dwordx4 s[84:87], %[T2b], 0x1000\n"
-    "s_store_dwordx4 s[88:91], %[T2b], 0x1010\n"
-    "s_store_dwordx4 s[92:95], %[T2b], 0x1020\n"
-    "s_store_dwordx4 s[96:99], %[T2b], 0x1030\n"
+    "s_cbranch_scc0 .Lc5_done_%=\n"
+    ".Lc5_poll_%=:\n"
+    "s_load_dword s76, s[36:37], 0x1a00\n"
     "s_waitcnt lgkmcnt(0)\n"
-    : [last] "=&s"(last), [sprev] "=&s"(sprev), [a2a] "=&s"(a2a), [a2b] "=&s"(a2b), [P] "=&s"(P), [t2] "=&s"(t2), [fwd] "=&s"(fwd),
-      [outv] "=&v"(outv), [q] "=&s"(q), [h] "=&s"(h), [g] "=&s"(g), [kind] "=&s"(kind), [vt] "=&v"(vt), [spin] "=&s"(spin), [tmo] "=&s"(tmo)
-    : [T2b] "s"(T2b), [xlo] "s"(xlo), [xhi] "s"(xhi), [olo] "s"(olo), [ohi] "s"(ohi), [voff] "v"(voff), [ostep] "s"(out_step), [nb] "s"(nb),
-      [lanem1] "v"(lanem1), [limit] "s"(SPIN_LIMIT_CHAIN)
-    : "scc", "memory", "m0", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
+    "s_cmp_gt_u32 s76, s77\n"
+    "s_cbranch_scc1 .Lc5_go_%=\n"
+    /* bounded wait: a parser that does not publish for SPIN_LIMIT polls (seconds) will not publish at all */
+    "s_add_u32 %[spin], %[spin], 1\n"
+    "s_cmp_lt_u32 %[spin], %[limit]\n"
+    "s_cbranch_scc0 .Lc5_tmo_%=\n"
+    "s_sleep 1\n"
+    "s_branch .Lc5_poll_%=\n"
+    ".Lc5_tmo_%=:\n"
+    "s_mov_b32 %[tmo], 1\n"
+    "s_mov_b32 s76, -1\n"
+    "s_store_dword s76, s[36:37], 0x1a40\n"            /* consumed = ABORT: the parser stops too */
+    "s_branch .Lc5_done_%=\n"
+    ".Lc5_go_%=:\n"
+    "s_mov_b32 %[spin], 0\n"
+    "s_cmp_eq_u32 s76, -1\n"
+    "s_cbranch_scc1 .Lc5_done_%=\n"
+    "s_and_b32 s76, s77, 3\n"
+    "s_mul_i32 s76, s76, 0x240\n"
+    "s_add_u32 s76, s76, 0x1100\n"
+    "s_load_dwordx8 s[60:67], s[36:37], s76\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    "s_cmp_lg_u32 s46, 0\n"
+    "s_setpc_b64 s[64:65]\n"
+    ".Lc5_done_%=:\n"
+    "s_mov_b64 exec, -1\n"
+    "s_mov_b32 %[last], s53\n"
+    "s_mov_b32 %[a2], s44\n"
+    "s_store_dwordx4 s[84:87], s[36:37], 0x1000\n"
+    "s_store_dwordx4 s[88:91], s[36:37], 0x1010\n"
+    "s_store_dwordx4 s[92:95], s[36:37], 0x1020\n"
+    "s_store_dwordx4 s[96:99], s[36:37], 0x1030\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    : [last] "=&s"(last), [a2] "=&s"(a2), [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [vt] "=&v"(vt), [spin] "=&s"(spin),
+      [tmo] "=&s"(tmo)
+    : [tlo] "s"(tlo), [thi] "s"(thi), [olo] "s"(olo), [ohi] "s"(ohi), [va0] "v"(va0), [va1] "v"(va1), [va2] "v"(va2), [va3] "v"(va3),
+      [ostep] "s"(out_step), [nb] "s"(nb), [lm] "v"(lane4m1), [limit] "s"(SPIN_LIMIT_CHAIN)
+    : "scc", "memory", "m0", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s52", "s53", "s54", "s55",
+      "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
       "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87",
       "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
-  (void)sprev;
-  return ChainEnd{ last, a2a, tmo };
+  return ChainEnd{ last, a2, tmo };
   }
 
-// parser wave: the 64 residuals of a batch (lane K = residual K) and the mask of its DFCM-coded values go to the ring slot with
-// scalar stores, through the scalar cache the chain reads; complete on return
-// the mask and kind of a batch whose 64 residuals are zero, into a slot that already holds 64 zero residuals
-__device__ __forceinline__ void chain4_put_flags(uint64_t dfcm, uint32_t kind, const uint32_t* slot)
+// parser wave: the 16 records of a batch go to the ring slot with scalar stores, through the scalar cache the chain reads; complete
+// on return.  xr = the residuals (lane K = value K); lane q of tlo / thi = address of quad q's body; off = byte offset of the
+// slot from the scratch base.
+__device__ __forceinline__ void chain5_put_batch(uint32_t xr, uint32_t tlo, uint32_t thi, const uint32_t* slot, uint32_t off)
   {
-  asm volatile("s_store_dwordx2 %[dfcm], %[slot], 0x100\n s_store_dword %[kind], %[slot], 0x108\n s_waitcnt lgkmcnt(0)\n"
-               :: [dfcm] "s"(dfcm), [kind] "s"(kind), [slot] "s"(slot) : "memory");
-  }
-
-__device__ __forceinline__ void chain4_put_batch(uint32_t xr, uint64_t dfcm, uint32_t kind, const uint32_t* slot)
-  {
-#define CH4_PUT4(J, R0, R1, R2, R3) \
-  "v_readlane_b32 s" #R0 ", %[xr], 4 * (" #J ")\n v_readlane_b32 s" #R1 ", %[xr], 4 * (" #J ") + 1\n" \
-  "v_readlane_b32 s" #R2 ", %[xr], 4 * (" #J ") + 2\n v_readlane_b32 s" #R3 ", %[xr], 4 * (" #J ") + 3\n" \
-  "s_nop 0\n s_store_dwordx4 s[" #R0 ":" #R3 "], %[slot], 16 * (" #J ")\n"
+#define CH5_PUT(Q, R0, R1, R2, R3, R4, R5, R6, R7) \
+  "v_readlane_b32 s" #R0 ", %[xr], 4 * (" #Q ")\n v_readlane_b32 s" #R1 ", %[xr], 4 * (" #Q ") + 1\n" \
+  "v_readlane_b32 s" #R2 ", %[xr], 4 * (" #Q ") + 2\n v_readlane_b32 s" #R3 ", %[xr], 4 * (" #Q ") + 3\n" \
+  "v_readlane_b32 s" #R4 ", %[tlo], " #Q "\n v_readlane_b32 s" #R5 ", %[thi], " #Q "\n" \
+  "s_mov_b32 s" #R6 ", 1 << (" #Q ")\n s_add_u32 s" #R7 ", %[off], 32 * ((" #Q ") + 1)\n" \
+  "s_store_dwordx4 s[" #R0 ":" #R3 "], %[slot], 32 * (" #Q ")\n s_store_dwordx4 s[" #R4 ":" #R7 "], %[slot], 32 * (" #Q ") + 16\n"
+#define CH5_PUT_E(Q) CH5_PUT(Q, 52, 53, 54, 55, 56, 57, 58, 59)
+#define CH5_PUT_O(Q) CH5_PUT(Q, 60, 61, 62, 63, 64, 65, 66, 67)
   asm volatile(
-    CH4_PUT4(0, 52, 53, 54, 55) CH4_PUT4(1, 56, 57, 58, 59) CH4_PUT4(2, 60, 61, 62, 63) CH4_PUT4(3, 64, 65, 66, 67)
-    CH4_PUT4(4, 52, 53, 54, 55) CH4_PUT4(5, 56, 57, 58, 59) CH4_PUT4(6, 60, 61, 62, 63) CH4_PUT4(7, 64, 65, 66, 67)
-    CH4_PUT4(8, 52, 53, 54, 55) CH4_PUT4(9, 56, 57, 58, 59) CH4_PUT4(10, 60, 61, 62, 63) CH4_PUT4(11, 64, 65, 66, 67)
-    CH4_PUT4(12, 52, 53, 54, 55) CH4_PUT4(13, 56, 57, 58, 59) CH4_PUT4(14, 60, 61, 62, 63) CH4_PUT4(15, 64, 65, 66, 67)
-    "s_store_dwordx2 %[dfcm], %[slot], 0x100\n"
-    "s_store_dword %[kind], %[slot], 0x108\n"
+    CH5_PUT_E(0) CH5_PUT_O(1) CH5_PUT_E(2) CH5_PUT_O(3) CH5_PUT_E(4) CH5_PUT_O(5) CH5_PUT_E(6) CH5_PUT_O(7)
+    CH5_PUT_E(8) CH5_PUT_O(9) CH5_PUT_E(10) CH5_PUT_O(11) CH5_PUT_E(12) CH5_PUT_O(13) CH5_PUT_E(14) CH5_PUT_O(15)
     "s_waitcnt lgkmcnt(0)\n"
-    :: [xr] "v"(xr), [dfcm] "s"(dfcm), [kind] "s"(kind), [slot] "s"(slot)
-    : "memory", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67");
+    :: [xr] "v"(xr), [tlo] "v"(tlo), [thi] "v"(thi), [slot] "s"(slot), [off] "s"(off)
+    : "scc", "memory", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67");
+  }
+
+// the record that ends a batch: only the address in it counts
+__device__ __forceinline__ void chain5_put_end(uint64_t target, const uint32_t* slot)
+  {
+  asm volatile("s_store_dwordx2 %[t], %[slot], 32 * 16 + 16\n s_waitcnt lgkmcnt(0)\n" :: [t] "s"(target), [slot] "s"(slot) : "memory");
   }
 
 // the counters that couple the two waves live in the scalar cache both of them go through
@@ -421,10 +362,24 @@ __device__ __forceinline__ void decode_pair(const Fpc32ChainJob& job, bool exist
       };
     refill(q);
     uint32_t t = 0;
-    uint32_t zero_slots = 0;                             // ring slots whose 64 residuals are all zero
     uint32_t failed = 0;                                 // 1: malformed payload, 2: the chain stopped answering
+    // where the chain's bodies are (it publishes that first thing), and the records that end the batches
     uint32_t spins = 0;
-    while (t < nb)
+    while (counter_load(T2g, SCRATCH_CODE + 2u) == 0u)
+      {
+      if (++spins > SPIN_LIMIT_PARSER)
+        {
+        failed = 2u;
+        break;
+        }
+      __builtin_amdgcn_s_sleep(4);
+      }
+    const uint64_t code_base = ((uint64_t)counter_load(T2g, SCRATCH_CODE + 1u) << 32) | counter_load(T2g, SCRATCH_CODE);
+    for (uint32_t sl = 0; sl < RING && !failed; ++sl)
+      chain5_put_end(code_base + (uint64_t)CH5_SLOT_END * (uint64_t)CH5_STRIDE, T2g + SCRATCH_X + SLOT_DWORDS * sl);
+    spins = 0;
+    uint32_t flagged_slots = 0;                          // two bits per ring slot: it holds the records of a flagged batch of that kind
+    while (t < nb && !failed)
       {
       const uint32_t cons = counter_load(T2g, SCRATCH_CONSUMED);
       if (cons == ABORT)                                 // the chain gave up waiting (it reports the timeout itself)
@@ -472,17 +427,21 @@ __device__ __forceinline__ void decode_pair(const Fpc32ChainJob& job, bool exist
       const uint32_t raw = __builtin_amdgcn_alignbyte(win[(rp >> 2) + 1u], win[rp >> 2], rp & 3u);
       const uint32_t xr = nbytes ? __builtin_bswap32(raw) >> (8u * (4u - nbytes)) : 0u;
       const uint64_t dfcm = __ballot(code > 4u);
-      // batches of 64 exact hits (the chain extrapolates them, see CH4_RUN): 1 = all FCM-coded without residual, 2 = all
-      // DFCM-coded with a zero residual byte
+      // batches of 64 exact hits (the chain extrapolates them, see run_check in tools/gen_chain5.py): 1 = all FCM-coded
+      // without residual, 2 = all DFCM-coded with a zero residual byte
       const uint32_t kind = __ballot(code != 0u) == 0ull ? 1u : (__ballot(code != 5u || xr != 0u) == 0ull ? 2u : 0u);
-      // (a slot that holds the zero residuals of an earlier flagged batch is not written again: on smooth streams the parser,
-      // not the chain, is what the stream waits for)
+      // the body of quad q (lanes 0..15): by the parity of q and the kinds of its four values; the first quad of a flagged
+      // batch goes to the body that tries the extrapolation
+      uint32_t slot_idx = (((uint32_t)lane & 1u) << 4) | ((uint32_t)(dfcm >> (4u * ((uint32_t)lane & 15u))) & 15u);
+      if (lane == 0 && kind != 0u)
+        slot_idx = kind == 1u ? (uint32_t)CH5_SLOT_RUN1 : (uint32_t)CH5_SLOT_RUN2;
+      const uint64_t target = code_base + (uint64_t)slot_idx * (uint64_t)CH5_STRIDE;
+      // (a slot that holds the records of an earlier flagged batch of the same kind is not written again - they are the same,
+      // residuals zero: on smooth streams the parser, not the chain, is what the stream waits for)
       const uint32_t sl = t % RING;
-      if (kind != 0u && ((zero_slots >> sl) & 1u))
-        chain4_put_flags(dfcm, kind, T2g + SCRATCH_X + SLOT_DWORDS * sl);
-      else
-        chain4_put_batch(xr, dfcm, kind, T2g + SCRATCH_X + SLOT_DWORDS * sl);
-      zero_slots = kind != 0u ? zero_slots | (1u << sl) : zero_slots & ~(1u << sl);
+      if (kind == 0u || ((flagged_slots >> (2u * sl)) & 3u) != kind)
+        chain5_put_batch(xr, (uint32_t)target, (uint32_t)(target >> 32), T2g + SCRATCH_X + SLOT_DWORDS * sl, 4u * (SCRATCH_X + SLOT_DWORDS * sl));
+      flagged_slots = (flagged_slots & ~(3u << (2u * sl))) | (kind << (2u * sl));
       ++t;
       counter_store(T2g, SCRATCH_PRODUCED, t);
       }
@@ -500,7 +459,8 @@ __device__ __forceinline__ void decode_pair(const Fpc32ChainJob& job, bool exist
     // the chain owns its SIMD's issue slots whenever it can issue: other kernels' waves (the sweeps of the LZ4 decoder, other
     // archives) may share the CU
     __builtin_amdgcn_s_setprio(3);
-    ce = chain4_run(T2g, nb, dst, 4u * (uint32_t)lane * (uint32_t)arity, 256u * (uint32_t)arity, (uint32_t)lane - 1u);
+    const uint32_t vb = 16u * (uint32_t)lane * (uint32_t)arity, vs = 4u * (uint32_t)arity;       // byte offset of value 4 lane (+ j) in its batch
+    ce = chain5_run(T2g, nb, dst, vb, vb + vs, vb + 2u * vs, vb + 3u * vs, 256u * (uint32_t)arity, 4u * (uint32_t)lane - 1u);
     __builtin_amdgcn_s_setprio(0);
     if (ce.timed_out && lane == 0)
       atomicOr(&L.bad, 2u);
