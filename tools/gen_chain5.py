@@ -6,11 +6,12 @@ the payload's headers, so the parser wave knows it in advance; it hands the chai
 the code that decodes exactly that pattern of four kinds (F = FCM-coded, D = DFCM-coded).  A body is straight-line code: an
 F value needs no DFCM entry, no wait and no forwarding test, and a value whose successor is F does not load one.
 
-Layout: 37 slots of STRIDE bytes behind a label aligned to STRIDE:
-   slot 16 * parity + nibble    body of a quad (parity = index of the quad in its batch & 1: which of the two record
-                                registers holds it), nibble bit j = value j is D
-   slot 32, 34                  first quad of a batch the parser flagged as 64 exact FCM / DFCM hits (see run_check; two slots each)
-   slot 36                      branch to the end of the batch
+Layout: 69 slots of STRIDE bytes behind a label aligned to STRIDE:
+   slot 32 * parity + kinds     body of a quad (parity = index of the quad in its batch & 1: which of the two record
+                                registers holds it), kinds bit j = value j is D, bit 4 = the first value of the next quad is
+                                (0 for the last quad of a batch)
+   slot 64, 66                  first quad of a batch the parser flagged as 64 exact FCM / DFCM hits (see run_check; two slots each)
+   slot 68                      branch to the end of the batch
 Registers (fixed; chain5_run lists them as clobbered):
    s[36:37] scratch base       s40, s41 temporaries        s42 P = (stride & 0xffc00000) << 5 of the previous value
    s43 loaded DFCM entry       s44 / s45 byte address of the current / previous DFCM entry (alternating)
@@ -116,7 +117,9 @@ def run_check(out, kind):
     out.append("s_cmp_lg_u32 s47, 0")
 
 
-def body(parity, kinds, run=0):
+def body(parity, kinds, after, run=0):
+    """after = kind of the first value of the next quad ("F" also for the last quad of a batch: the end of the batch loads the
+    DFCM entry itself)"""
     cur, nxt = REC[parity], REC[1 - parity]
     out = []
     pf = f"s_load_dwordx8 {nxt['regs']}, s[36:37], {cur['nxt']}"
@@ -124,11 +127,13 @@ def body(parity, kinds, run=0):
     # the lane from scalar registers)
     out.append(f"s_mov_b32 exec_lo, {cur['lane']}")
     for j in range(4):
-        nextk = kinds[j + 1] if j < 3 else "U"
+        nextk = kinds[j + 1] if j < 3 else after
         value(out, j, kinds[j], nextk, cur, pf if j == 0 else None)
         if run and j == 1:
             run_check(out, run)
-    # (value 3 always waits at its start: the record of the next quad, requested with value 0, is there)
+    # the record of the next quad, requested with value 0, must be there
+    if not any(t.startswith("s_waitcnt") for t in out[out.index(pf) + 1:]):
+        out.append("s_waitcnt lgkmcnt(0)")
     out.append(f"s_setpc_b64 {nxt['tgt']}")
     return out
 
@@ -136,14 +141,14 @@ def body(parity, kinds, run=0):
 def main():
     slots = []
     for parity in range(2):
-        for nib in range(16):
-            kinds = "".join("D" if (nib >> j) & 1 else "F" for j in range(4))
-            slots.append((f"quad {parity} {kinds}", body(parity, kinds)))
-    slots.append(("run of FCM hits", body(0, "FFFF", run=1)))
-    slots.append(("run of DFCM hits", body(0, "DDDD", run=2)))
+        for nib in range(32):
+            kinds = "".join("D" if (nib >> j) & 1 else "F" for j in range(5))
+            slots.append((f"quad {parity} {kinds[:4]} then {kinds[4]}", body(parity, kinds[:4], kinds[4])))
+    slots.append(("run of FCM hits", body(0, "FFFF", "F", run=1)))
+    slots.append(("run of DFCM hits", body(0, "DDDD", "D", run=2)))
     slots.append(("end of the batch", ["s_branch .Lc5_end_%="]))
-    lines = ["// generated by tools/gen_chain5.py - do not edit", "#define CH5_STRIDE %d" % STRIDE, "#define CH5_SLOT_RUN1 32",
-             "#define CH5_SLOT_RUN2 34", "#define CH5_SLOT_END 36", "#define CH5_BODIES \\"]
+    lines = ["// generated by tools/gen_chain5.py - do not edit", "#define CH5_STRIDE %d" % STRIDE, "#define CH5_SLOT_RUN1 64",
+             "#define CH5_SLOT_RUN2 66", "#define CH5_SLOT_END 68", "#define CH5_BODIES \\"]
     lines.append('  ".p2align 10\\n .Lc5_body_%=:\\n" \\')
     for name, text in slots:
         lines.append('  /* %s */ \\' % name)

@@ -147,6 +147,10 @@ __device__ __forceinline__ ChainEnd chain5_run(const uint32_t* T2b, uint32_t nb,
     "s_branch .Lc5_poll_%=\n"
     CH5_BODIES
     ".Lc5_end_%=:\n"
+    /* (the last quad of a batch does not know what follows it: the DFCM entry of the next value is requested here) */
+    "s_waitcnt lgkmcnt(0)\n"
+    "s_load_dword s43, s[36:37], s44\n"
+    "s_cmp_lg_u32 s44, s45\n"
     "s_cselect_b32 s46, 1, 0\n"
     "s_mov_b64 exec, 0xffff\n"
     "global_store_dword %[va0], %[o0], s[80:81]\n"
@@ -432,7 +436,8 @@ __device__ __forceinline__ void decode_pair(const Fpc32ChainJob& job, bool exist
       const uint32_t kind = __ballot(code != 0u) == 0ull ? 1u : (__ballot(code != 5u || xr != 0u) == 0ull ? 2u : 0u);
       // the body of quad q (lanes 0..15): by the parity of q and the kinds of its four values; the first quad of a flagged
       // batch goes to the body that tries the extrapolation
-      uint32_t slot_idx = (((uint32_t)lane & 1u) << 4) | ((uint32_t)(dfcm >> (4u * ((uint32_t)lane & 15u))) & 15u);
+      // (bit 4: the kind of the value behind the quad; the last quad of a batch takes the bodies that assume an F there)
+      uint32_t slot_idx = (((uint32_t)lane & 1u) << 5) | ((uint32_t)(dfcm >> (4u * ((uint32_t)lane & 15u))) & 31u);
       if (lane == 0 && kind != 0u)
         slot_idx = kind == 1u ? (uint32_t)CH5_SLOT_RUN1 : (uint32_t)CH5_SLOT_RUN2;
       const uint64_t target = code_base + (uint64_t)slot_idx * (uint64_t)CH5_STRIDE;
