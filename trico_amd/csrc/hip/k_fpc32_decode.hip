@@ -15,16 +15,18 @@
 //     v_readlane inside a scalar instruction stream                  ~21 cycles
 //   * wave 1 (parser) stages the payload through LDS, finds the 8 groups of the next 64 values with a short scalar walk
 //     over the 3-byte headers, lets all 64 lanes locate, align and byte-swap their residual at once, and hands the
-//     residuals and the mask of DFCM-coded values to wave 0 through a ring of four batches in scalar memory.
-//   * wave 0 (chain) runs the recurrence, fully unrolled and branch-free, on the SCALAR unit, with the DFCM table (1024
-//     entries) in global memory behind the scalar data cache and the FCM table (16 entries) in SGPRs: see below.  It is one
-//     asm statement from the first value to the last: it polls the parser's counter with a scalar load, stores the 64 values
-//     of a batch with one vector store straight into the interleaved output, and publishes its own counter with a scalar
-//     store — no LDS instruction, no barrier and no v_readlane on its path.
+//     residuals, grouped in quads with the address of the code for their kinds, to wave 0 through a ring of four batches in
+//     scalar memory.
+//   * wave 0 (chain) runs the recurrence on the SCALAR unit, in straight-line bodies of four values chosen by the kinds the
+//     parser found, with the DFCM table (1024 entries) in global memory behind the scalar data cache and the FCM table (16
+//     entries) in SGPRs: see below.  It is one asm statement from the first value to the last: it polls the parser's counter
+//     with a scalar load, stores the 64 values of a batch with four vector stores of 16 lanes straight into the interleaved
+//     output, and publishes its own counter with a scalar store — no LDS instruction, no barrier and no v_readlane on its path.
 // History: one wave, scalar chain with branches and both tables in registers: 165-225 cycles per value (69-93 ns); vector
 // chain with the tables in LDS: 146; scalar chain, one barrier per batch: 38-43 ns; LDS counters instead of the barrier and
 // the parser storing the values: 37-41 ns (~400 cycles of handshake, table save / restore and LDS traffic per batch); this
-// design: 35-37 ns per value whatever the stream.
+// design with one branch-free body for every value (round 3): 35-37 ns per value whatever the stream; bodies per pattern
+// of kinds (round 4): 30.4 ns on the noisiest stream of the benchmark mesh.
 // Streams with table exponents below the (4,10) the archive API writes, and stream tails (< 64 values), take the
 // reference-order loop of one lane at the end of the file.
 //
@@ -61,33 +63,35 @@ __device__ __forceinline__ uint32_t lens_sum(uint32_t x)
 // ignored, and dirty lines survive other kernels being dispatched (smem2.hip: 24 chains x 8M operations against the host
 // while 10^5 other kernels were launched).  So the tables go where the cheap instructions can reach them: a 4 KiB + 64 B
 // scratch per stream in global memory that only this wave touches, zeroed here with scalar stores and written back
-// (s_dcache_wb) before the kernel ends so that no dirty line outlives the buffer.  Per value, all on the scalar unit
-// (a2 = byte address of the current DFCM entry, P = (stride & 0xffc00000) << 5 of the previous value: the hash of the
-// strides lives in the top ten bits, where the shift by five drops the old bits; M0 = top four bits of the previous value):
-//     {cand, lm} = dfcm ? {previous stride, last} : {T1 entry, 0}      s_bitcmp1, s_cselect_b64   (while the load is in flight)
-//     q = (dfcm and not forwarded) ? loaded T2 entry : cand            s_bitcmp1, s_waitcnt, s_cselect
-//     v = x ^ (q + lm); s = v - last                                   s_add, s_xor, s_sub        (fpsc.c:308-311, 323)
-//     T2[a2] = s; a2' = ((s & 0xffc00000) ^ P) >> 20; load T2[a2']     s_store, s_and, s_xor, s_lshr, s_load   (fpsc.c:81-84, 324-326)
-//     T1[M0] = v; M0 = v >> 28; T1 entry = T1[M0]                      s_movreld, s_lshr, s_movrels   (fpsc.c:76-79, 312-314)
-//     P = (s & 0xffc00000) << 5; forwarded = (a2' == a2)               s_lshl, s_cmp_lg, s_cselect
-//     out lane K = v                                                   v_writelane
-// 20 instructions; the critical path (wait ... load) is 8 ALU instructions + the load = ~73 cycles, the rest issues under
-// the load.
-// One value.  Registers alternate between consecutive values (value / last, stride / previous stride, hash address /
-// previous hash address) so that nothing is copied.  The store of this value's stride under the old hash is issued as soon
-// as the stride exists, the T2 load of the new hash four instructions later; a scalar load issued after a scalar store to
-// the same address is NOT reliably ordered behind it when the line misses (smem2.hip under cache pressure; a parity test
-// caught it too), so when both addresses are equal the loaded word is ignored and the next value takes the stride from the
-// register instead (`g` = the DFCM mask of the coming value, or 0 if forwarding).  Every other store is complete before the
-// next value starts, because each value begins with s_waitcnt lgkmcnt(0) — which waits for the store as well as for the
-// load, so the store goes first (issued behind the load it cost the noisy stream 1 ns per value).
+// (s_dcache_wb) before the kernel ends so that no dirty line outlives the buffer.
+// Which of the two predictions a value takes is in the headers, so the parser knows it before the chain gets there: it
+// hands the values over in quads, each with the address of straight-line code for exactly its pattern of kinds (F = FCM-coded,
+// D = DFCM-coded) and the kind of the value behind it - 2 x 32 bodies of 512 bytes, generated by tools/gen_chain5.py
+// (chain5_bodies.inc, registers and layout documented there).  Per value, all on the scalar unit (a2 = byte address of the
+// current DFCM entry, P = (stride & 0xffc00000) << 5 of the previous value: the hash of the strides lives in the top ten
+// bits, where the shift by five drops the old bits; M0 = top four bits of the previous value):
+//     D: wait; q = forwarded ? previous stride : loaded T2 entry; v = x ^ (q + last)     s_waitcnt, s_cselect, s_add, s_xor
+//     F: v = x ^ T1 entry                                                                 s_xor               (fpsc.c:308-311)
+//     s = v - last; T2[a2] = s; a2' = ((s & 0xffc00000) ^ P) >> 20                        s_sub, s_store, s_and, s_xor, s_lshr   (fpsc.c:81-84, 323-326)
+//     T1[M0] = v; M0 = v >> 28; P = (s & 0xffc00000) << 5                                 s_movreld, s_lshr, s_lshl              (fpsc.c:76-79, 312-314)
+//     next is D: load T2[a2']; forwarded = (a2' == a2)      next is F: T1 entry = T1[M0]  s_load, s_cmp_lg  /  s_movrels
+//     lane of the quad in output register j = v                                           v_mov (EXEC = that lane)
+// 11 instructions for an F value before an F value (no wait: 44 cycles), 15 for a D value before a D value, whose critical
+// path (wait ... load) is the table load's latency + 9 instructions, ~80 cycles; per quad a record load, the EXEC move and
+// the jump (s_setpc_b64 to the address in the next record), ~35 cycles.  Round 3's chain ran the same 20 branch-free
+// instructions for every value (85 cycles, 35.5 ns on the benchmark mesh's z: half its values D, kinds switching at random);
+// this one 30.4 ns there.  Measured and dropped (profiles/r04_chain_variants.txt): bodies that do not know the kind behind the
+// quad (30.7); the values of a quad leaving through one s_store_dwordx4 into a ring the parser wave empties (34.9: the waits
+// cover the wide store, and the parser's loads share the scalar cache with the chain's).
+// A scalar load issued after a scalar store to the same address is NOT reliably ordered behind it when the line misses
+// (smem2.hip under cache pressure; a parity test caught it too), so when the address of the load equals the address of the
+// store just before it the loaded word is ignored and the next value takes the stride from the register instead (SCC carries
+// that from s_cmp_lg to the next value's s_cselect, also across the jump).  Every OLDER store must be complete before a
+// load is issued, and only lgkmcnt(0) means anything for scalar memory: every value that loads, or needs a loaded entry,
+// begins with s_waitcnt lgkmcnt(0); only an F value before an F value runs without one.
 // v_readlane costs ~21 cycles in a scalar instruction stream (tools/ubench/chain4.hip), so the residuals do not come from
-// a VGPR: the parser wave puts them into global memory with scalar stores (same scalar cache, same CU) and the chain
-// loads eight at a time with s_load_dwordx8.  Fixed registers (clobbered by the statement):
-//   s[52:53] = {stride, value} of the previous value on even steps, s[54:55] on odd steps
-//   s[56:57] = {T1 entry of the current hash, 0}    s[58:59] = {cand, lm}: one s_cselect_b64 picks {stride, value} or {T1 entry, 0}
-//   s[60:67], s[68:75] residuals of the current / next eight values      s[84:99] the FCM table (s_movrels / s_movreld, M0 = hash)
-//   D: register with the mask word of value K, DN: of value K + 1
+// a VGPR: the parser wave puts the records into global memory with scalar stores (same scalar cache, same CU) and every
+// body loads the record of the next quad with s_load_dwordx8 before it starts on its own.
 #include "chain5_bodies.inc"
 
 // Scratch of one stream in global memory (FPC32_DECODE_TABLE_BYTES), touched by this workgroup only and only through the
