@@ -191,6 +191,10 @@ def parse():
                          "streams and byte planes spread over the GPUs and assembled into one archive on rank 0 (strong scaling)")
     ap.add_argument("--exchange", default="torch", choices=["torch", "c"],
                     help="transport of the gather: torch.distributed (nccl = RCCL) or the RCCL entry of the C-ABI (trico_hip_comm_*)")
+    # the rank body on a host without GPUs (tests/test_bench_ranks_host.py): gloo over CPU tensors, and a stand-in for
+    # trico_amd.api.  Never a measurement: the line says so.
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)
+    ap.add_argument("--api", default="trico_amd.api", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -613,7 +617,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if local_rank >= torch.cuda.device_count() or world > torch.cuda.device_count():
+    host_only = args.backend == "gloo"
+    if not host_only and (local_rank >= torch.cuda.device_count() or world > torch.cuda.device_count()):
         # under a launcher: the same check as _spawn_ranks_if_needed, before the rendezvous
         sys.stderr.write("bench.py: rank %d of %d has no device of its own (%d visible): not started\n" % (rank, world, torch.cuda.device_count()))
         sys.exit(2)
@@ -621,11 +626,21 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if host_only:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if host_only:
+        dev = torch.device("cpu")
+        sync = lambda: None
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        sync = torch.cuda.synchronize
 
-    from trico_amd import api, meshgen
+    import importlib
+    api = importlib.import_module(args.api)
+    from trico_amd import meshgen
     from trico_amd.parallel import gather_archives, wrap_device_bytes, sharded_write, hip_unit_encoder, CComm
     L = api.lib()
     if not L.trico_hip_available():
@@ -646,7 +661,7 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     state = {}
     comm = None
@@ -656,7 +671,7 @@ def main():
             dist.broadcast_object_list(box, src=0)
             return box[0]
         comm = CComm(api, rank, world, share)
-    unit_encoder = hip_unit_encoder(api) if sharded else None
+    unit_encoder = (getattr(api, "unit_encoder", None) or hip_unit_encoder)(api) if sharded else None
 
     def step_sharded(check=False):
         """ONE mesh: every rank encodes its share of the 7 units (x, y, z, b1..b4), one exchange, rank 0 frames the archive and
@@ -664,14 +679,14 @@ def main():
         te0 = time.perf_counter()
         a = sharded_write(dist, api, [("vertices", d_v, nv), ("triangles", d_t, nt)], unit_encoder, root=0, device_archive=True,
                           gather=(lambda t: comm.gather(t, 0)) if comm is not None else None)
-        torch.cuda.synchronize()
+        sync()
         te1 = time.perf_counter()
         td1 = te1
         if rank == 0:
             size = a.get_size()
             r = api.Archive.open_for_reading(a.get_buffer_pointer(), size)
             assert r.read("vertices", d_v2) == 1 and r.read("triangles", d_t2) == 1, api.last_error()
-            torch.cuda.synchronize()
+            sync()
             td1 = time.perf_counter()
             if check:
                 blob = a.tobytes()
@@ -698,20 +713,20 @@ def main():
         a = api.Archive.open_for_writing(raw_bytes // 4, device=True)      # caller-chosen initial size: no regrowth
         assert a.write("vertices", d_v, nv) == 1, api.last_error()
         assert a.write("triangles", d_t, nt) == 1, api.last_error()
-        torch.cuda.synchronize()
+        sync()
         te1 = time.perf_counter()
         size = a.get_size()
         if dist is not None:
             local = wrap_device_bytes(a.get_buffer_pointer(), size, dev)
             gathered = comm.gather(local, 0) if comm is not None else gather_archives(dist, local, dst=0)
-            torch.cuda.synchronize()
+            sync()
             state["gathered_bytes"] = gathered
         tg1 = time.perf_counter()
         r = api.Archive.open_for_reading(a.get_buffer_pointer(), size)
         assert r is not None
         assert r.read("vertices", d_v2) == 1, api.last_error()
         assert r.read("triangles", d_t2) == 1, api.last_error()
-        torch.cuda.synchronize()
+        sync()
         td1 = time.perf_counter()
         if check:
             blob = a.tobytes()
@@ -802,7 +817,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(step_s * 1e3, 3),
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
+            "dtype": "u32", "data": "synthetic" if not host_only else "synthetic; HOST REHEARSAL of the rank body (gloo, stand-in coder): not a measurement",
             "config": {"workload": "%s(%d,%d): %d float xyz vertices + %d uint32 triangles per GPU (BASELINE configs[1]%s), "
                                    "device-resident raw arrays -> .trc archive in HBM -> decoded arrays in HBM"
                                    % (args.mesh, W, H, nv, nt, "" if world == 1 else "; one mesh per GPU, RCCL gather of archives to rank 0 (configs[3])"),

@@ -1,0 +1,41 @@
+"""CPU tier: bench.py's rank body with TWO ranks (the code path the 8-GPU scaling run takes: one process per rank, barrier +
+max-over-ranks timing, archives gathered on rank 0 / one mesh's streams spread over the ranks), on gloo with the oracle as the coder
+(tests/fake_hip_api.py).  What is checked: both ranks finish, rank 0 prints exactly one JSON line for n_gpus = 2, the archive it
+reports is the reference's golden archive of the mesh (sha256, tests/golden/hashes.json) in both sharding modes."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(shard):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--W", "1000", "--H", "1000", "--shard", shard, "--backend", "gloo", "--api", "tests.fake_hip_api", "--no-cpu-baseline"]
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("shard", ["meshes", "streams"])
+def test_rank_body_world2(shard, native_libs):
+    j = _run(shard)
+    assert j["n_gpus"] == 2 and j["steps"] == 1 and j["unit"] == "GB/s" and j["value"] > 0
+    assert "HOST REHEARSAL" in j["data"]
+    assert j["scaling"] == ("weak" if shard == "meshes" else "strong")
+    # rank 0's archive is the golden one of grid(1000, 1000): written whole by rank 0 ('meshes'), or assembled on rank 0 from
+    # payloads both ranks encoded ('streams')
+    assert j["config"]["parity"] == "sha256 == reference golden", j["config"]
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "hashes.json")))["grid_1000x1000"]
+    assert j["config"]["archive_bytes_rank0"] == golden["bytes"] if "bytes" in golden else True

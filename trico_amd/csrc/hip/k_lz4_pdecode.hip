@@ -19,8 +19,8 @@
 //     list worked off by whole workgroups, k_pd_jobs).  Pointer jumping (src[i] = src[src[i]]) resolves chains of matches in
 //     log2(longest chain) rounds without any ordering between threads (k_pd_jump), and a gather produces the plane
 //     (k_pd_gather).
-// Nothing waits on the host: the jump rounds are launched up front and return at once when the previous round changed
-// nothing.  Traffic: ~4 B written + 12 B per round and output byte.
+// Nothing waits on the host: the jump rounds are launched up front and return at once when the previous round left no
+// word open.  Traffic: ~4 B written + 12 B per round and output byte.
 // Round 3: (1) a match that overlaps itself (offset < length: LZ4's way of writing a periodic run, lz4.c:1840-1870) points every
 // byte at the FIRST period, src = op - off + (k mod off), instead of at the byte `off` before it: the run is resolved in one
 // round whatever its length (the two upper byte planes of a grid's indices are ONE run of 300 MB each: 28 rounds before).
@@ -510,8 +510,9 @@ __global__ void __launch_bounds__(256) k_pd_jobs(PdPlanes P, uint32_t job_cap, u
     }
   }
 
-// one round of pointer jumping; returns at once when the previous round changed nothing.  The last workgroup to finish closes
-// the round (done = nothing changed).
+// one round of pointer jumping; returns at once when the round before left no word open.  The last workgroup to finish closes
+// the round: done = every word it wrote is final (a round that only confirms that nothing changes any more is not needed: a word
+// is open exactly when PD_FINAL is not set in it).
 __global__ void __launch_bounds__(256) k_pd_jump(PdPlanes P, uint32_t n)
   {
   const PdPlane& pl = P.p[blockIdx.y];
@@ -519,7 +520,7 @@ __global__ void __launch_bounds__(256) k_pd_jump(PdPlanes P, uint32_t n)
   uint32_t* src = pl.src;
   if (pl.clen == 0u || ctl->done || ctl->error)
     return;
-  bool changed = false;
+  bool open = false;                               // a word this thread wrote is not final yet
   // four words per thread (the workspace is 256-byte aligned): 16-byte loads of the words, dword gathers only where a word
   // is not final yet.  Words are read and written while other threads jump them: any value seen is final or an earlier byte.
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -534,12 +535,10 @@ __global__ void __launch_bounds__(256) k_pd_jump(PdPlanes P, uint32_t n)
         {
         w[k] = __hip_atomic_load(&src[w[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         mine = true;
+        open = open || !(w[k] & PD_FINAL);
         }
     if (mine)
-      {
       *((u32x4*)src + i) = w;
-      changed = true;
-      }
     }
   for (uint32_t i = 4u * n4 + blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
     {
@@ -549,14 +548,14 @@ __global__ void __launch_bounds__(256) k_pd_jump(PdPlanes P, uint32_t n)
       // s < i: an earlier output byte; whatever it holds right now is final or a still earlier byte
       const uint32_t t = __hip_atomic_load(&src[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&src[i], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      changed = true;
+      open = open || !(t & PD_FINAL);
       }
     }
   __shared__ uint32_t any;
   if (threadIdx.x == 0)
     any = 0u;
   __syncthreads();
-  if (__ballot(changed) && (threadIdx.x & 63) == 0)
+  if (__ballot(open) && (threadIdx.x & 63) == 0)
     any = 1u;
   __syncthreads();
   if (threadIdx.x == 0)

@@ -6,7 +6,10 @@ import torch
 
 
 def wrap_device_bytes(ptr, nbytes, device):
-    """uint8 CUDA tensor aliasing `nbytes` at device address `ptr` (no copy); the owner keeps it alive."""
+    """uint8 tensor aliasing `nbytes` at address `ptr` of `device` (no copy); the owner keeps it alive."""
+    if torch.device(device).type == "cpu":
+        import ctypes
+        return torch.frombuffer((ctypes.c_uint8 * nbytes).from_address(int(ptr)), dtype=torch.uint8)
     class _Holder:
         pass
     h = _Holder()
