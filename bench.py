@@ -183,7 +183,7 @@ def parse():
     ap.add_argument("--H", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="full", help="WxH of the CPU baseline's mesh; 'full' = the GPU's own mesh")
-    ap.add_argument("--concurrent", default="8,32,64", help="archives decoded as one batch in the decode_concurrent block ('' : skip)")
+    ap.add_argument("--concurrent", default="8,16,32,64", help="archives decoded as one batch in the decode_concurrent block ('' : skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the walk mesh, PCIe-inclusive and concurrent-decode blocks")
     ap.add_argument("--quick", action="store_true", help="headline, roofline and the 1-thread CPU baseline only")
     ap.add_argument("--shard", default="meshes", choices=["meshes", "streams"],
@@ -849,13 +849,23 @@ def main():
                 out["config5_mixed"] = out["config3"].pop("config5_mixed")
                 out["encoder_variants"] = encoder_variants(W, H)
         if world == 1 and not args.no_cpu_baseline:
-            allK = tuple(k for k in Ks if k in (8, 32)) if not (args.no_extras or args.quick) else ()
+            allK = tuple(k for k in Ks if k in (8, 16, 32)) if not (args.no_extras or args.quick) else ()
             if args.cpu_sample == "full":
                 out["cpu_baseline"] = cpu_baseline(args.mesh, W, H, v, t, allK)
             else:
                 cw, ch = (int(x) for x in args.cpu_sample.split("x"))
                 cv, ct = gen(cw, ch)
                 out["cpu_baseline"] = cpu_baseline(args.mesh, cw, ch, cv, ct, allK)
+        # where the GPU wins: K archives decoded as one batch against the reference's coder on 7 K host threads of this box
+        if "decode_concurrent" in out and out.get("cpu_baseline", {}).get("all_cores"):
+            cpu_rows = {r["archives"]: r for r in out["cpu_baseline"]["all_cores"] if "decode_GBps" in r}
+            best = {}
+            for r in out["decode_concurrent"]["results"]:
+                if r.get("archives") in cpu_rows and r["decode_GBps"] > best.get(r["archives"], 0.0):
+                    best[r["archives"]] = r["decode_GBps"]
+            out["decode_concurrent"]["vs_cpu_all_cores"] = [
+                {"archives": K, "gpu_decode_GBps": g, "cpu_decode_GBps": cpu_rows[K]["decode_GBps"], "cpu_threads": cpu_rows[K]["threads"],
+                 "gpu_over_cpu": round(g / cpu_rows[K]["decode_GBps"], 3)} for K, g in sorted(best.items())]
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if unit_encoder is not None:
