@@ -42,7 +42,31 @@ struct Engine
   uint8_t* h_tab = nullptr; size_t h_tab_cap = 0;             // pinned: job tables up, status words down
   };
 
-Engine E;
+// One engine per device: streams, events, chain scratch and workspaces belong to the device that was current when they were made,
+// and so do the calls that may be combined into one batch (a process whose threads drive different GPUs decodes on each of them).
+constexpr int MAX_DEVICES = 32;
+Engine g_engines[MAX_DEVICES];
+
+int current_device_index()
+  {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES)
+    {
+    (void)hipGetLastError();
+    dev = 0;
+    }
+  return dev;
+  }
+
+// the engine of the calling thread's current device (every entry point below asks once and passes it on through this reference)
+thread_local Engine* t_engine = nullptr;
+#define E (*t_engine)
+struct EngineScope
+  {
+  Engine* prev;
+  EngineScope() : prev(t_engine) { t_engine = &g_engines[current_device_index()]; }
+  ~EngineScope() { t_engine = prev; }
+  };
 
 constexpr uint32_t STATUS_WORDS = 16;          // per job: [0] status, [4..9] payload sizes + flags of the self-check's re-encode
 
@@ -253,6 +277,7 @@ void trico_hip_release_workspaces(void)
   {
   if (!device_ready())
     return;
+  EngineScope scope;
   std::lock_guard<std::mutex> lock(E.mu);
   (void)hipDeviceSynchronize();
   DevBuf* bufs[] = { &E.jobs32, &E.jobs64, &E.status, &E.in, &E.parked, &E.vws32, &E.vws64, &E.lz4ws, &E.planes };
@@ -271,6 +296,7 @@ int trico_hip_decode_jobs_reserve(const trico_hip_decode_job* jobs, int count)
     return 0;
   if (count == 0)
     return 1;
+  EngineScope scope;
   Kind* kind = (Kind*)malloc(sizeof(Kind) * (size_t)count);
   if (!kind)
     return 0;
@@ -482,11 +508,16 @@ static int run_batch(trico_hip_decode_job* jobs, int count)
 // threads that arrive while a batch is running form the next one.
 namespace {
 struct Waiter { trico_hip_decode_job* jobs; int count; bool done; int result; Waiter* next; };
-std::mutex q_mu;
-std::condition_variable q_cv;
-Waiter* q_head = nullptr;
-Waiter* q_tail = nullptr;
-bool q_leading = false;
+// (one queue per device: only calls for the same device can share a batch)
+struct Queue
+  {
+  std::mutex mu;
+  std::condition_variable cv;
+  Waiter* head = nullptr;
+  Waiter* tail = nullptr;
+  bool leading = false;
+  };
+Queue g_queues[MAX_DEVICES];
 }
 
 int trico_hip_decode_jobs(trico_hip_decode_job* jobs, int count)
@@ -498,19 +529,21 @@ int trico_hip_decode_jobs(trico_hip_decode_job* jobs, int count)
   // whatever produced the payloads on this thread's stream comes first (the batch may be launched by another thread)
   if (!hip_ok(hipStreamSynchronize(current_stream()), "hipStreamSynchronize"))
     return 0;
+  EngineScope scope;
+  Queue& Q = g_queues[current_device_index()];
   Waiter me = { jobs, count, false, 0, nullptr };
-  std::unique_lock<std::mutex> lk(q_mu);
-  if (q_tail) q_tail->next = &me; else q_head = &me;
-  q_tail = &me;
-  while (q_leading && !me.done)
-    q_cv.wait(lk);
+  std::unique_lock<std::mutex> lk(Q.mu);
+  if (Q.tail) Q.tail->next = &me; else Q.head = &me;
+  Q.tail = &me;
+  while (Q.leading && !me.done)
+    Q.cv.wait(lk);
   if (me.done)
     {
     if (!me.result)
       set_error("trico_hip_decode_jobs: a stream of this call's jobs failed (decoded in a batch led by another thread)");
     return me.result;
     }
-  q_leading = true;
+  Q.leading = true;
   {
   // Threads started together should land in this batch: wait while calls keep arriving, for a time that is small against what the
   // batch itself will take (the longest float / double chain at ~35 ns per value decides that): at most 1 % of it, at most 10 ms.
@@ -523,15 +556,15 @@ int trico_hip_decode_jobs(trico_hip_decode_job* jobs, int count)
   const auto t_start = std::chrono::steady_clock::now();
   for (;;)
     {
-    const Waiter* seen = q_tail;
-    q_cv.wait_for(lk, std::chrono::microseconds(window / 4 + 10), [] { return false; });
+    const Waiter* seen = Q.tail;
+    Q.cv.wait_for(lk, std::chrono::microseconds(window / 4 + 10), [] { return false; });
     const long waited = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_start).count();
-    if (waited >= window || (q_tail == seen && waited >= window / 2))
+    if (waited >= window || (Q.tail == seen && waited >= window / 2))
       break;
     }
   }
-  Waiter* batch = q_head;
-  q_head = q_tail = nullptr;
+  Waiter* batch = Q.head;
+  Q.head = Q.tail = nullptr;
   lk.unlock();
   int total = 0;
   for (Waiter* w = batch; w; w = w->next)
@@ -582,8 +615,8 @@ int trico_hip_decode_jobs(trico_hip_decode_job* jobs, int count)
     w->done = true;
     w = nx;
     }
-  q_leading = false;
-  q_cv.notify_all();
+  Q.leading = false;
+  Q.cv.notify_all();
   return me.result;
   }
 

@@ -404,8 +404,12 @@ int trico_hip_walk_frames(const uint8_t* d_data, uint64_t size, uint64_t pos, co
   if (!device_ready() || !d_data || !ncomp_of_type || !out || cap < 1 || cap > 256)
     return -1;
   static std::mutex mu;
-  static uint8_t* d_buf = nullptr;            // 256 frame records + count + header bytes
+  static uint8_t* d_bufs[32] = { nullptr };   // per device: 256 frame records + count + header bytes
   std::lock_guard<std::mutex> lock(mu);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32)
+    dev = 0;
+  uint8_t*& d_buf = d_bufs[dev];
   const size_t rec = sizeof(trico_hip_frame_bytes) * 256;
   if (!d_buf && !hip_ok(hipMalloc((void**)&d_buf, rec + 64), "hipMalloc(frame records)"))
     return -1;
