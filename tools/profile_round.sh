@@ -1,4 +1,4 @@
-# Collects the profiles committed under profiles/ (round 3 layout).  usage (GPU box): bash tools/profile_round.sh <tag>
+# Collects the profiles committed under profiles/ (layout of rounds 3 and 4).  usage (GPU box): bash tools/profile_round.sh <tag>
 #   <tag>_bench_config2.json / _kernel_stats.txt      bench.py --quick under rocprofv3 --kernel-trace --stats
 #   <tag>_bench_config2_unprofiled.json               the full bench.py line, no profiler attached
 #   <tag>_fpc32_encode_kernel_stats.txt               the float-vertex encoder ALONE (tools/perf_fpc32.py grid): per-kernel durations
@@ -17,19 +17,26 @@ timeout -k 10 600 python $R/bench.py --steps 3 --warmup 1 > $O/${TAG}_bench_conf
 echo "== kernel trace of bench.py --quick"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python $R/bench.py --quick --steps 3 --warmup 1 > $O/${TAG}_bench_config2.json 2> $O/bench.err
 python $R/tools/prof_summary.py $O/bench > $O/${TAG}_bench_config2_kernel_stats.txt
-echo "== encoder alone: kernel trace"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/enc -- python $R/tools/perf_fpc32.py grid > $O/enc.log 2>&1
-{ echo "# rocprofv3 --kernel-trace --stats -- python tools/perf_fpc32.py grid: the float-vertex encoder alone on the 50 M config-2 vertices (6 encodes,"
+echo "== encoder alone: kernel trace, both meshes"
+{ for m in grid walk; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/enc_$m -- python $R/tools/perf_fpc32.py $m > $O/enc_$m.log 2>&1
+  echo "# rocprofv3 --kernel-trace --stats -- python tools/perf_fpc32.py $m: the float-vertex encoder alone on the 50 M config-2 vertices (6 encodes,"
   echo "# payloads gathered to a device buffer with ONE launch for the three components, as the archive writer does; no decoder, no self-check traffic beside it)"
-  grep "kernel span" $O/enc.log
-  python $R/tools/prof_summary.py $O/enc; } > $O/${TAG}_fpc32_encode_kernel_stats.txt
-echo "== PMC: HBM traffic of the float encoder (separate passes)"
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $R/tools/perf_fpc32.py grid > $O/pmc_$c.log 2>&1
-done
-{ echo "# rocprofv3 --pmc FETCH_SIZE (own pass) and --pmc WRITE_SIZE (own pass), tools/perf_fpc32.py grid (50M float xyz vertices), per dispatch, unit KB"
+  grep "kernel span" $O/enc_$m.log
+  python $R/tools/prof_summary.py $O/enc_$m
+  rm -rf $O/enc_$m
+done; } > $O/${TAG}_fpc32_encode_kernel_stats.txt
+echo "== PMC: HBM traffic of the float encoder (separate passes, both meshes)"
+{ echo "# rocprofv3 --pmc FETCH_SIZE (own pass) and --pmc WRITE_SIZE (own pass), tools/perf_fpc32.py {grid|walk} (50M float xyz vertices), per dispatch, unit KB"
   echo "# gfx950: FETCH_SIZE reports 1/2 of the bytes of streaming reads (MI355X_MICROARCH.md, HBM section) -> doubled in DESIGN.md and bench.py"
-  python $R/tools/pmc_summary.py $O/pmc_FETCH_SIZE; python $R/tools/pmc_summary.py $O/pmc_WRITE_SIZE; } > $O/${TAG}_fpc32_encode_hbm_traffic_pmc.txt
+  for m in grid walk; do
+    echo "## $m"
+    for c in FETCH_SIZE WRITE_SIZE; do
+      timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${c}_$m -- python $R/tools/perf_fpc32.py $m > $O/pmc_${c}_$m.log 2>&1
+      python $R/tools/pmc_summary.py $O/pmc_${c}_$m
+      rm -rf $O/pmc_${c}_$m
+    done
+  done; } > $O/${TAG}_fpc32_encode_hbm_traffic_pmc.txt
 echo "== PMC: SQ counters"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $O/pmc_sq1 -- python $R/tools/perf_fpc32.py grid > $O/pmc_sq1.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_sq2 -- python $R/tools/perf_fpc32.py grid > $O/pmc_sq2.log 2>&1
@@ -61,5 +68,5 @@ for f in glob.glob(sys.argv[1] + "/**/*hip_api_stats.csv", recursive=True):
             print("   %-40s calls %s" % (r["Name"], r["Calls"]))
 PY
   done; } > $O/${TAG}_device_archive_open_hip_api.txt
-rm -rf $O/bench $O/enc $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_sq1 $O/pmc_sq2 $O/lz4_grid $O/lz4_walk $O/hip_upload $O/hip_open
+rm -rf $O/bench $O/pmc_sq1 $O/pmc_sq2 $O/lz4_grid $O/lz4_walk $O/hip_upload $O/hip_open
 ls -la $O
