@@ -19,7 +19,7 @@ cpu_baseline = the reference itself (oracle/_ref, built from /root/reference) wh
 roofline_all / decode_model: every other stage of the step against the same HBM peak (algorithmic bytes of SURVEY 8(d) /
             live hipEvent spans), and what bounds the chain decoders: nanoseconds and cycles per value of each component chain.
 other_mesh / pcie_inclusive / decode_concurrent / config3: the same step on the walk mesh, through host pointers, BASELINE
-            configs[4]'s shape on one GPU (8 / 32 / 64 archives decoded as ONE batch, trico_hip_read_archives, with the hardware
+            configs[4]'s shape on one GPU (8 / 16 / 32 / 64 archives decoded as ONE batch, trico_hip_read_archives, with the hardware
             queue count unset, 1, 4 and 32), and BASELINE configs[2] (double vertices + normals + float uv, + u64 triangles so that the
             archive is the reference's golden) - N = 1 only, outside the timed region.  --quick skips them.
 `python bench.py --gpus N` starts its N ranks itself (torch.distributed.run, RCCL) when no launcher did.
@@ -506,8 +506,9 @@ def decode_model(api, d_v, d_t, nv, nt, raw_bytes):
     return {"ns_per_value": ns, "cycles_per_value": {k: round(v * clock_ghz, 1) for k, v in ns.items()}, "clock_GHz_assumed": clock_ghz,
             "chains": "one per component stream (fpsc.c:308-326: value i needs value i-1 through both tables); the step time is the slowest "
                       "chain's n x ns_per_value, whatever the GPU has left",
-            "bound": "issue + scalar-cache latency of ONE wave: 20 scalar instructions per value at 4 cycles each, 37-cycle table load on the "
-                     "dependent path (DESIGN.md 4.5); smooth streams skip batches of exact hits",
+            "bound": "issue + scalar-cache latency of ONE wave: straight-line bodies per pattern of kinds - 11 scalar instructions at 4 cycles "
+                     "for an FCM-coded value before an FCM-coded one, 15 + the table load's ~37-cycle latency on the dependent path for DFCM-coded "
+                     "ones, ~9 cycles per value to dispatch a quad (DESIGN.md 4.5); smooth streams skip batches of exact hits",
             "algorithmic_GBps_per_chain": {k: round(4.0 / v, 3) for k, v in ns.items()}}
 
 
