@@ -27,6 +27,7 @@ import os
 import sys
 
 STRIDE = 512
+STORE_AFTER_LOAD = os.environ.get("CH5_STORE_AFTER_LOAD", "0") == "1"    # experiment: the stride's store behind the next entry's load
 A = ("s52", "s53")           # {stride, value}
 B = ("s54", "s55")
 REC = (dict(x=["s60", "s61", "s62", "s63"], tgt="s[64:65]", lane="s66", nxt="s67", regs="s[60:67]"),
@@ -51,12 +52,15 @@ def value(out, j, kind, nextk, cur, prefetch):
     else:
         out.append(f"s_xor_b32 {OUT[1]}, {cur['x'][j]}, s56")
     out.append(f"s_sub_u32 {OUT[0]}, {OUT[1]}, {IN[1]}")
-    out.append(f"s_store_dword {OUT[0]}, s[36:37], {AO}")
+    if not (load and STORE_AFTER_LOAD):
+        out.append(f"s_store_dword {OUT[0]}, s[36:37], {AO}")
     out.append(f"s_and_b32 s41, {OUT[0]}, 0xffc00000")
     out.append(f"s_xor_b32 s40, s41, s42")
     out.append(f"s_lshr_b32 {AN}, s40, 20")
     if load:
         out.append(f"s_load_dword s43, s[36:37], {AN}")
+        if STORE_AFTER_LOAD:
+            out.append(f"s_store_dword {OUT[0]}, s[36:37], {AO}")
     out.append(f"s_movreld_b32 s84, {OUT[1]}")
     out.append(f"s_lshr_b32 m0, {OUT[1]}, 28")
     out.append(f"s_lshl_b32 s42, s41, 5")
