@@ -2,7 +2,8 @@ set -e
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r4i
 mkdir -p $O
-cd /tmp; export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $O/pmc -- python $R/tools/perf_config3.py 2000 1000 > $O/pmc.log 2>&1 || { tail -30 $O/pmc.log; exit 1; }
-python $R/tools/pmc_summary.py $O/pmc | grep -A4 "k_fpc64_decode"
-rm -rf $O/pmc
+cd $R
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_lowlevel.py tests/test_gpu_batch.py tests/test_gpu_selfcheck.py -m gpu -x -q > $O/pytest.log 2>&1 || { tail -60 $O/pytest.log; exit 1; }
+tail -2 $O/pytest.log
+timeout -k 10 300 python tools/perf_config3.py > $O/c3.log 2>&1 || { tail -30 $O/c3.log; exit 1; }
+tail -1 $O/c3.log

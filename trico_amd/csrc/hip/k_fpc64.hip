@@ -265,26 +265,43 @@ __device__ __forceinline__ uint32_t nib_len(uint32_t c) { return c <= 8u ? c : c
 // They are coupled through a ring of RING64 batches and two counters in the stream's scratch, all of it scalar memory
 // (k_fpc32_decode.hip has the float version of the same design and what was measured about scalar loads and stores).
 constexpr uint32_t RING64 = 4;                                   // batches the parser may run ahead
-constexpr uint32_t SLOT64_DWORDS = 256;                          // ring slot: 64 residuals (512 B), then the mask of DFCM-coded values
+constexpr uint32_t REC64_DWORDS = 16, SLOT64_DWORDS = 18 * REC64_DWORDS;      // ring slot: 16 quad records of 64 bytes and the one that ends the batch
 constexpr uint32_t SCR64_DWORDS = 2048;                          // scratch per component (FPC64_DECODE_SCRATCH_BYTES)
-constexpr uint32_t SCR64_PRODUCED = RING64 * SLOT64_DWORDS, SCR64_CONSUMED = SCR64_PRODUCED + 16, SCR64_USED = SCR64_CONSUMED + 16;
-static_assert(SCR64_PRODUCED * 4 == 0x1000 && SCR64_CONSUMED * 4 == 0x1040 && SCR64_USED <= SCR64_DWORDS, "offsets are spelled out in the chain");
+constexpr uint32_t SCR64_PRODUCED = RING64 * SLOT64_DWORDS, SCR64_CONSUMED = SCR64_PRODUCED + 16, SCR64_CODE = SCR64_CONSUMED + 16;
+constexpr uint32_t SCR64_USED = SCR64_CODE + 16;
+static_assert(SLOT64_DWORDS * 4 == 0x480 && SCR64_PRODUCED * 4 == 0x1200 && SCR64_CONSUMED * 4 == 0x1240 && SCR64_CODE * 4 == 0x1280 &&
+              SCR64_USED <= SCR64_DWORDS, "offsets are spelled out in the chain");
 constexpr uint32_t ABORT64 = 0xffffffffu;                        // `produced` when the parser gives up
 
-// lane l's 64-bit word -> dwords 2l, 2l + 1 of `slot` (512 bytes) and the mask behind them, with scalar stores; complete on return
-__device__ __forceinline__ void put_batch64(u64 w, uint64_t dfcm, const uint32_t* slot)
+// The 16 quad records of a batch -> ring slot, with scalar stores; complete on return.  w = the residuals (lane K = value K); lane q
+// of tlo / thi = address of quad q's body; off = byte offset of the slot from the scratch base; first_d = the batch's first value is
+// DFCM-coded (the chain requests that value's table entry itself).
+// Record: dwords 0-7 four residuals, 8-9 address of the body, 10 bit of the quad's lane, 11 offset of the next record, 12 first_d.
+__device__ __forceinline__ void put_quads64(u64 w, uint32_t tlo, uint32_t thi, const uint32_t* slot, uint32_t off, uint32_t first_d)
   {
   const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
-#define P64_PUT2(J, R0, R1, R2, R3) \
-  "v_readlane_b32 s" #R0 ", %[lo], 2 * (" #J ")\n v_readlane_b32 s" #R1 ", %[hi], 2 * (" #J ")\n" \
-  "v_readlane_b32 s" #R2 ", %[lo], 2 * (" #J ") + 1\n v_readlane_b32 s" #R3 ", %[hi], 2 * (" #J ") + 1\n" \
-  "s_nop 0\n s_store_dwordx4 s[" #R0 ":" #R3 "], %[slot], 16 * (" #J ")\n"
-#define P64_4(J) P64_PUT2(J, 52, 53, 54, 55) P64_PUT2(J + 1, 56, 57, 58, 59) P64_PUT2(J + 2, 60, 61, 62, 63) P64_PUT2(J + 3, 64, 65, 66, 67)
-  asm volatile(P64_4(0) P64_4(4) P64_4(8) P64_4(12) P64_4(16) P64_4(20) P64_4(24) P64_4(28)
-               "s_store_dwordx2 %[dfcm], %[slot], 0x200\n"
+#define P64_Q(Q, R) \
+  "v_readlane_b32 s[" #R "], %[lo], 4 * (" #Q ")\n v_readlane_b32 s[" #R " + 1], %[hi], 4 * (" #Q ")\n" \
+  "v_readlane_b32 s[" #R " + 2], %[lo], 4 * (" #Q ") + 1\n v_readlane_b32 s[" #R " + 3], %[hi], 4 * (" #Q ") + 1\n" \
+  "v_readlane_b32 s[" #R " + 4], %[lo], 4 * (" #Q ") + 2\n v_readlane_b32 s[" #R " + 5], %[hi], 4 * (" #Q ") + 2\n" \
+  "v_readlane_b32 s[" #R " + 6], %[lo], 4 * (" #Q ") + 3\n v_readlane_b32 s[" #R " + 7], %[hi], 4 * (" #Q ") + 3\n" \
+  "v_readlane_b32 s[" #R " + 8], %[tlo], " #Q "\n v_readlane_b32 s[" #R " + 9], %[thi], " #Q "\n" \
+  "s_mov_b32 s[" #R " + 10], 1 << (" #Q ")\n s_add_u32 s[" #R " + 11], %[off], 64 * ((" #Q ") + 1)\n" \
+  "s_store_dwordx4 s[" #R ":" #R " + 3], %[slot], 64 * (" #Q ")\n s_store_dwordx4 s[" #R " + 4:" #R " + 7], %[slot], 64 * (" #Q ") + 16\n" \
+  "s_store_dwordx4 s[" #R " + 8:" #R " + 11], %[slot], 64 * (" #Q ") + 32\n"
+  asm volatile("s_store_dword %[fd], %[slot], 48\n"
+               P64_Q(0, 52) P64_Q(1, 64) P64_Q(2, 52) P64_Q(3, 64) P64_Q(4, 52) P64_Q(5, 64) P64_Q(6, 52) P64_Q(7, 64)
+               P64_Q(8, 52) P64_Q(9, 64) P64_Q(10, 52) P64_Q(11, 64) P64_Q(12, 52) P64_Q(13, 64) P64_Q(14, 52) P64_Q(15, 64)
                "s_waitcnt lgkmcnt(0)\n"
-               :: [lo] "v"(lo), [hi] "v"(hi), [dfcm] "s"(dfcm), [slot] "s"(slot)
-               : "memory", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67");
+               :: [lo] "v"(lo), [hi] "v"(hi), [tlo] "v"(tlo), [thi] "v"(thi), [slot] "s"(slot), [off] "s"(off), [fd] "s"(first_d)
+               : "scc", "memory", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
+                 "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75");
+  }
+
+// the record that ends a batch: only the address in it counts
+__device__ __forceinline__ void put_end64(uint64_t target, const uint32_t* slot)
+  {
+  asm volatile("s_store_dwordx2 %[t], %[slot], 64 * 16 + 32\n s_waitcnt lgkmcnt(0)\n" :: [t] "s"(target), [slot] "s"(slot) : "memory");
   }
 
 __device__ __forceinline__ uint32_t counter_load64(const uint32_t* base, uint32_t dword)
@@ -302,144 +319,121 @@ __device__ __forceinline__ void counter_store64(const uint32_t* base, uint32_t d
 // Per value ONE table entry is needed: the DFCM entry if the value is DFCM-coded, else the FCM entry (fpsc.c:977-978); both
 // tables are written for every value (fpsc.c:980-995).  With the API's exponents (20, 20) the FCM hash is the top 20 bits of the
 // previous value and the DFCM hash ((h2 << 10) ^ top 20 bits of the stride) & 0xfffff; both are kept as byte offsets (<< 3).
-// One value, all on the scalar unit, no branch (O = registers of the previous value, N = of this one; they alternate):
-//     lm = dfcm ? last : 0                                       s_bitcmp1_b64, s_cselect_b64
-//     e = forwarded ? value / stride just stored : loaded entry  s_cmp_lg, s_waitcnt, s_cselect_b64
-//     v = x ^ (e + lm); s = v - last                             s_add, s_addc, s_xor_b64, s_sub, s_subb      (fpsc.c:977-981)
-//     T1[o1] = v; T2[o2] = s                                     2 s_store_dwordx2                           (fpsc.c:982-995)
-//     o1' = (v.hi >> 9) & 0x7ffff8; o2' = ((o2 << 10) ^ (s.hi >> 9)) & 0x7ffff8                 2 + 4 instructions
-//     the entry the NEXT value needs (its kind is in the mask): table, offset, what was stored there if the hash did not
-//     change; load it                                            s_bitcmp1_b64, 2 s_cselect_b32, 2 s_cselect_b64, s_load_dwordx2
-//     forwarded' = (that offset == the offset just stored to)    s_cmp_eq, s_cselect      (a scalar load is not ordered behind a
-//                                                                scalar store to the same address that is still in flight)
-//     out lane K = v                                             2 v_writelane
-// 30 instructions (the compiled C++ chain of round 2a: ~35 and three branches of 26 cycles: 82-93 ns per value on smooth
-// streams, 166 on noisy ones; this one: 54 and 112).  On noisy doubles the DFCM entry is a miss into an 8 MiB table on top of that.
-// Fixed registers:  s[36:39] / s[40:43] {stride, value} of even / odd values   s[44:45] loaded entry   s[46:47] forwarded entry
-//   s[48:49] lm   s[50:51] prediction   s52 / s53 FCM offset (even / odd)   s54 / s55 DFCM offset   s56 forwarded   s57, s58 scratch
-//   s59 offset of the load   s[60:61] output address of the batch   s[62:63] table of the load   s[64:79] / s[80:95] residuals of
-//   the current / next eight values   s96 scratch   s97 batch counter   s[98:99] ring slot
-#define C64_X(K) "s[64 + 16 * (((" #K ") >> 3) & 1) + 2 * ((" #K ") & 7) : 65 + 16 * (((" #K ") >> 3) & 1) + 2 * ((" #K ") & 7)]"
-#define C64_XLOAD(K) "s_load_dwordx16 s[64 + 16 * (((((" #K ") >> 3) + 1)) & 1) : 79 + 16 * (((((" #K ") >> 3) + 1)) & 1)], s[98:99], 64 * (((" #K ") >> 3) + 1)\n"
-#define C64_NOX(K) ""
-#define C64_NEXT(K, NS, NV, O1O, O1N, O2O, O2N) \
-  "s_bitcmp1_b64 %[dm], (" #K ") + 1\n"                             \
-  "s_cselect_b32 s59, " O2N ", " O1N "\n"                           \
-  "s_cselect_b32 %[offo], " O2O ", " O1O "\n"                       \
-  "s_cselect_b64 s[62:63], %[T2], %[T1]\n"                          \
-  "s_cselect_b64 s[46:47], " NS ", " NV "\n"                        \
-  "s_load_dwordx2 s[44:45], s[62:63], s59\n"                        \
-  "s_cmp_eq_u32 s59, %[offo]\n"                                     \
-  "s_cselect_b32 s56, 1, 0\n"
-#define C64_LAST(K, NS, NV, O1O, O1N, O2O, O2N) ""
-#define C64_STEP(K, OV, OVLO, OVHI, NS, NSLO, NSHI, NV, NVLO, NVHI, O1O, O1N, O2O, O2N, XL, NEXT) \
-  "s_bitcmp1_b64 %[dm], (" #K ")\n"                                 \
-  "s_cselect_b64 s[48:49], " OV ", 0\n"                             \
-  "s_cmp_lg_u32 s56, 0\n"                                           \
-  "s_waitcnt lgkmcnt(0)\n"                                          \
-  "s_cselect_b64 s[50:51], s[46:47], s[44:45]\n"                    \
-  "s_add_u32 s50, s50, s48\n"                                       \
-  "s_addc_u32 s51, s51, s49\n"                                      \
-  "s_xor_b64 " NV ", " C64_X(K) ", s[50:51]\n"                      \
-  "s_sub_u32 " NSLO ", " NVLO ", " OVLO "\n"                        \
-  "s_subb_u32 " NSHI ", " NVHI ", " OVHI "\n"                       \
-  "s_store_dwordx2 " NV ", %[T1], " O1O "\n"                        \
-  "s_store_dwordx2 " NS ", %[T2], " O2O "\n"                        \
-  "s_lshr_b32 s57, " NVHI ", 9\n"                                   \
-  "s_and_b32 " O1N ", s57, 0x7ffff8\n"                              \
-  "s_lshl_b32 s58, " O2O ", 10\n"                                   \
-  "s_lshr_b32 s57, " NSHI ", 9\n"                                   \
-  "s_xor_b32 s58, s58, s57\n"                                       \
-  "s_and_b32 " O2N ", s58, 0x7ffff8\n"                              \
-  NEXT(K, NS, NV, O1O, O1N, O2O, O2N)                               \
-  XL(K)                                                             \
-  "v_writelane_b32 %[vlo], " NVLO ", " #K "\n"                      \
-  "v_writelane_b32 %[vhi], " NVHI ", " #K "\n"
-#define C64_EVEN(K, XL, NEXT) C64_STEP(K, "s[38:39]", "s38", "s39", "s[40:41]", "s40", "s41", "s[42:43]", "s42", "s43", "s52", "s53", "s54", "s55", XL, NEXT)
-#define C64_ODD(K, XL, NEXT) C64_STEP(K, "s[42:43]", "s42", "s43", "s[36:37]", "s36", "s37", "s[38:39]", "s38", "s39", "s53", "s52", "s55", "s54", XL, NEXT)
-#define C64_OCT(B, XL) C64_EVEN(B + 0, XL, C64_NEXT) C64_ODD(B + 1, C64_NOX, C64_NEXT) C64_EVEN(B + 2, C64_NOX, C64_NEXT) C64_ODD(B + 3, C64_NOX, C64_NEXT) \
-                       C64_EVEN(B + 4, C64_NOX, C64_NEXT) C64_ODD(B + 5, C64_NOX, C64_NEXT) C64_EVEN(B + 6, C64_NOX, C64_NEXT) C64_ODD(B + 7, C64_NOX, C64_NEXT)
-#define C64_OCT_LAST(B) C64_EVEN(B + 0, C64_NOX, C64_NEXT) C64_ODD(B + 1, C64_NOX, C64_NEXT) C64_EVEN(B + 2, C64_NOX, C64_NEXT) C64_ODD(B + 3, C64_NOX, C64_NEXT) \
-                        C64_EVEN(B + 4, C64_NOX, C64_NEXT) C64_ODD(B + 5, C64_NOX, C64_NEXT) C64_EVEN(B + 6, C64_NOX, C64_NEXT) C64_ODD(B + 7, C64_NOX, C64_LAST)
+// Round 2's chain ran the same 30 branch-free scalar instructions for every value: the entry of the next value was requested
+// behind both hashes, both stores and five selects (54 ns per value on smooth streams, 112 on noisy ones).  Since round 4 the
+// parser hands the values over in quads with the address of straight-line code for their pattern of kinds and the kind of the
+// value behind them (tools/gen_chain64.py -> chain64_bodies.inc; the float chain's construction, k_fpc32_decode.hip):
+//     wait; e = forwarded ? what the value before stored : loaded entry          s_waitcnt, s_cmp_lg, s_cselect_b64
+//     D: v = x ^ (e + last)     F: v = x ^ e                                      (s_add, s_addc,) s_xor_b64     (fpsc.c:977-981)
+//     next is F: o1' = (v.hi >> 9) & 0x7ffff8; load T1[o1']; forwarded' = (o1' == o1)      2 + 1 + 2 instructions behind v
+//     next is D: s = v - last; o2' = ((o2 << 10) ^ (s.hi >> 9)) & 0x7ffff8; load T2[o2']; forwarded' = (o2' == o2)
+//     then the rest: s, T1[o1] = v, T2[o2] = s, the other hash                    s_store_dwordx2 x 2, ...      (fpsc.c:982-995)
+//     lane of the quad in output register pair j = v                              2 v_mov (EXEC = that lane)
+// 21-24 instructions per value, the load 5-9 instructions behind the value instead of ~20.  A scalar load is not ordered behind a
+// scalar store to the same address that is still in flight: the entry a value needs is taken from the register when the value
+// before stored to the same offset (`forwarded`), and every value begins with s_waitcnt lgkmcnt(0), which completes all older stores.
+// On noisy doubles the DFCM entry is a miss into an 8 MiB table on top of that.
+#include "chain64_bodies.inc"
 
 // The whole chain of a stream: batches 0 .. nb-1 of 64 values (the last one may hold fewer: `last_mask` has a bit per value of
-// it; the slots beyond run too, nothing reads the tables or the state after them).  Per batch: wait until the parser has
-// published it, load its mask and first eight residuals, request the entry of its first value (nothing of the batch before is
-// still in flight then), 64 values, two vector stores of the 64 values straight to their place in the interleaved output,
-// publish `consumed`.
+// it; the quads beyond run too, nothing reads the tables or the state after them).  Per batch: wait until the parser has
+// published it, load its first record, request the entry of its first value (nothing of the batch before is still in flight
+// then), 16 quads, eight vector stores of 16 lanes straight to their place in the interleaved output (lane q of register pair j
+// holds value 4 q + j), publish `consumed`.
+//   s59 / s[62:63] offset / table of the entry a batch begins with   s[60:61] output address of the batch   s96 scratch   s97 batch counter
 constexpr uint32_t SPIN64_LIMIT_CHAIN = 1u << 25, SPIN64_LIMIT_PARSER = 1u << 23;
 
 // returns 1 if the wait for the parser ran into its bound
 __device__ __forceinline__ uint32_t chain64_run(const u64* T1, const u64* T2, const uint32_t* ring, uint32_t nb, uint64_t last_mask, u64* out0,
-                                            uint32_t voff, uint32_t out_step)
+                                            uint32_t lane, uint32_t arity, uint32_t out_step)
   {
-  const uint64_t xb = (uint64_t)(uintptr_t)ring, ob = (uint64_t)(uintptr_t)out0;
-  const uint32_t xlo = (uint32_t)xb, xhi = (uint32_t)(xb >> 32), olo = (uint32_t)ob, ohi = (uint32_t)(ob >> 32);
-  uint32_t vlo, vhi, offo, spin, tmo;
-  uint64_t dm;
+  const uint64_t ob = (uint64_t)(uintptr_t)out0;
+  const uint32_t olo = (uint32_t)ob, ohi = (uint32_t)(ob >> 32);
+  // value 4 q + j of a batch: byte offset in the output, and which values of the last batch exist
+  const uint32_t va0 = 32u * lane * arity, va1 = va0 + 8u * arity, va2 = va0 + 16u * arity, va3 = va0 + 24u * arity;
+  uint32_t m[4] = { 0, 0, 0, 0 };
+  for (uint32_t q = 0; q < 16u; ++q)
+    for (uint32_t j = 0; j < 4u; ++j)
+      m[j] |= (uint32_t)((last_mask >> (4u * q + j)) & 1ull) << q;
+  uint32_t o0lo, o0hi, o1lo, o1hi, o2lo, o2hi, o3lo, o3hi, spin, tmo;
   asm volatile(
     "s_mov_b64 s[36:37], 0\n s_mov_b64 s[38:39], 0\n s_mov_b64 s[40:41], 0\n s_mov_b64 s[42:43], 0\n"
-    "s_mov_b64 s[44:45], 0\n s_mov_b64 s[46:47], 0\n"
+    "s_mov_b64 s[44:45], 0\n"
     "s_mov_b32 s52, 0\n s_mov_b32 s53, 0\n s_mov_b32 s54, 0\n s_mov_b32 s55, 0\n s_mov_b32 s56, 0\n"
-    "s_mov_b32 s97, 0\n s_mov_b32 s60, %[olo]\n s_mov_b32 s61, %[ohi]\n"
+    "s_mov_b64 s[46:47], %[T1]\n s_mov_b64 s[48:49], %[T2]\n s_mov_b64 s[98:99], %[ringp]\n"
+    "s_mov_b32 s97, 0\n s_mov_b32 s60, %[olo]\n s_mov_b32 s61, %[ohi]\n s_mov_b32 exec_hi, 0\n"
     "s_mov_b32 %[spin], 0\n s_mov_b32 %[tmo], 0\n"
+    /* where the bodies are: the parser puts their addresses into the records */
+    "s_getpc_b64 s[62:63]\n"
+    ".Lc64_pc_%=:\n"
+    "s_add_u32 s62, s62, .Lc64_body_%= - .Lc64_pc_%=\n"
+    "s_addc_u32 s63, s63, 0\n"
+    "s_store_dwordx2 s[62:63], s[98:99], 0x1280\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    "s_mov_b32 s96, 1\n"
+    "s_store_dword s96, s[98:99], 0x1288\n"
     "s_cmp_lt_u32 s97, %[nb]\n"
-    "s_cbranch_scc0 3f\n"
-    "0:\n"
-    "s_load_dword s96, %[ringp], 0x1000\n"
+    "s_cbranch_scc0 .Lc64_done_%=\n"
+    "s_branch .Lc64_poll_%=\n"
+    CH64_BODIES
+    ".Lc64_end_%=:\n"
+    "s_add_u32 s97, s97, 1\n"
+    "s_cmp_eq_u32 s97, %[nb]\n"                        /* the last batch may hold fewer than 64 values */
+    "s_cselect_b32 s57, %[m0], 0xffff\n s_mov_b32 exec_lo, s57\n"
+    "global_store_dword %[va0], %[o0lo], s[60:61]\n global_store_dword %[va0], %[o0hi], s[60:61] offset:4\n"
+    "s_cselect_b32 s57, %[m1], 0xffff\n s_mov_b32 exec_lo, s57\n"
+    "global_store_dword %[va1], %[o1lo], s[60:61]\n global_store_dword %[va1], %[o1hi], s[60:61] offset:4\n"
+    "s_cselect_b32 s57, %[m2], 0xffff\n s_mov_b32 exec_lo, s57\n"
+    "global_store_dword %[va2], %[o2lo], s[60:61]\n global_store_dword %[va2], %[o2hi], s[60:61] offset:4\n"
+    "s_cselect_b32 s57, %[m3], 0xffff\n s_mov_b32 exec_lo, s57\n"
+    "global_store_dword %[va3], %[o3lo], s[60:61]\n global_store_dword %[va3], %[o3hi], s[60:61] offset:4\n"
+    "s_add_u32 s60, s60, %[ostep]\n"
+    "s_addc_u32 s61, s61, 0\n"
+    "s_store_dword s97, s[98:99], 0x1240\n"
+    "s_cmp_lt_u32 s97, %[nb]\n"
+    "s_cbranch_scc0 .Lc64_done_%=\n"
+    ".Lc64_poll_%=:\n"
+    "s_load_dword s96, s[98:99], 0x1200\n"
     "s_waitcnt lgkmcnt(0)\n"
     "s_cmp_gt_u32 s96, s97\n"
-    "s_cbranch_scc1 1f\n"
+    "s_cbranch_scc1 .Lc64_go_%=\n"
     /* bounded wait (see SPIN_LIMIT_CHAIN in k_fpc32_decode.hip): seconds without a published batch = the waves lost each other */
     "s_add_u32 %[spin], %[spin], 1\n"
     "s_cmp_lt_u32 %[spin], %[limit]\n"
-    "s_cbranch_scc0 7f\n"
+    "s_cbranch_scc0 .Lc64_tmo_%=\n"
     "s_sleep 1\n"
-    "s_branch 0b\n"
-    "7:\n"
+    "s_branch .Lc64_poll_%=\n"
+    ".Lc64_tmo_%=:\n"
     "s_mov_b32 %[tmo], 1\n"
     "s_mov_b32 s96, -1\n"
-    "s_store_dword s96, %[ringp], 0x1040\n"          /* consumed = ABORT: the parser stops too */
-    "s_branch 3f\n"
-    "1:\n"
+    "s_store_dword s96, s[98:99], 0x1240\n"          /* consumed = ABORT: the parser stops too */
+    "s_branch .Lc64_done_%=\n"
+    ".Lc64_go_%=:\n"
     "s_mov_b32 %[spin], 0\n"
     "s_cmp_eq_u32 s96, -1\n"
-    "s_cbranch_scc1 3f\n"
+    "s_cbranch_scc1 .Lc64_done_%=\n"
     "s_and_b32 s96, s97, 3\n"
-    "s_lshl_b32 s96, s96, 10\n"
-    "s_add_u32 s98, %[xlo], s96\n"
-    "s_addc_u32 s99, %[xhi], 0\n"
-    "s_load_dwordx2 %[dm], s[98:99], 0x200\n"
-    "s_load_dwordx16 s[64:79], s[98:99], 0x0\n"
+    "s_mul_i32 s96, s96, 0x480\n"
+    "s_load_dwordx16 s[64:79], s[98:99], s96\n"
     "s_waitcnt lgkmcnt(0)\n"
     /* the entry of the batch's first value: the stores of the batch before are complete (the poll waited for them) */
-    "s_bitcmp1_b64 %[dm], 0\n"
+    "s_cmp_lg_u32 s76, 0\n"
     "s_cselect_b32 s59, s54, s52\n"
-    "s_cselect_b64 s[62:63], %[T2], %[T1]\n"
+    "s_cselect_b64 s[62:63], s[48:49], s[46:47]\n"
     "s_load_dwordx2 s[44:45], s[62:63], s59\n"
     "s_mov_b32 s56, 0\n"
-    C64_OCT(0, C64_XLOAD) C64_OCT(8, C64_XLOAD) C64_OCT(16, C64_XLOAD) C64_OCT(24, C64_XLOAD)
-    C64_OCT(32, C64_XLOAD) C64_OCT(40, C64_XLOAD) C64_OCT(48, C64_XLOAD) C64_OCT_LAST(56)
-    "s_add_u32 s97, s97, 1\n"
-    "s_cmp_eq_u32 s97, %[nb]\n"
-    "s_cselect_b64 exec, %[lastm], -1\n"
-    "global_store_dword %[voff], %[vlo], s[60:61]\n"
-    "global_store_dword %[voff], %[vhi], s[60:61] offset:4\n"
+    "s_setpc_b64 s[72:73]\n"
+    ".Lc64_done_%=:\n"
     "s_mov_b64 exec, -1\n"
-    "s_add_u32 s60, s60, %[ostep]\n"
-    "s_addc_u32 s61, s61, 0\n"
-    "s_store_dword s97, %[ringp], 0x1040\n"
-    "s_cmp_lt_u32 s97, %[nb]\n"
-    "s_cbranch_scc1 0b\n"
-    "3:\n"
     "s_waitcnt lgkmcnt(0)\n"
-    : [vlo] "=&v"(vlo), [vhi] "=&v"(vhi), [offo] "=&s"(offo), [dm] "=&s"(dm), [spin] "=&s"(spin), [tmo] "=&s"(tmo)
-    : [T1] "s"(T1), [T2] "s"(T2), [ringp] "s"(ring), [xlo] "s"(xlo), [xhi] "s"(xhi), [olo] "s"(olo), [ohi] "s"(ohi), [voff] "v"(voff),
-      [ostep] "s"(out_step), [nb] "s"(nb), [lastm] "s"(last_mask), [limit] "s"(SPIN64_LIMIT_CHAIN)
-    : "scc", "memory", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
-      "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
-      "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",
-      "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+    : [o0lo] "=&v"(o0lo), [o0hi] "=&v"(o0hi), [o1lo] "=&v"(o1lo), [o1hi] "=&v"(o1hi), [o2lo] "=&v"(o2lo), [o2hi] "=&v"(o2hi),
+      [o3lo] "=&v"(o3lo), [o3hi] "=&v"(o3hi), [spin] "=&s"(spin), [tmo] "=&s"(tmo)
+    : [T1] "s"(T1), [T2] "s"(T2), [ringp] "s"(ring), [olo] "s"(olo), [ohi] "s"(ohi), [va0] "v"(va0), [va1] "v"(va1), [va2] "v"(va2), [va3] "v"(va3),
+      [m0] "s"(m[0]), [m1] "s"(m[1]), [m2] "s"(m[2]), [m3] "s"(m[3]), [ostep] "s"(out_step), [nb] "s"(nb), [limit] "s"(SPIN64_LIMIT_CHAIN)
+    : "scc", "memory", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47",
+      "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68",
+      "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89",
+      "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
   return tmo;
   }
 
@@ -505,7 +499,21 @@ __device__ __forceinline__ void decode64_pair(const Fpc64ChainJob& job, u64* __r
     uint32_t t = 0;
     uint32_t failed = 0;                                 // 1: malformed payload, 2: the chain stopped answering
     uint32_t spins = 0;
-    while (t < nb)
+    // where the chain's bodies are (it publishes that first thing, behind the zeroing of its tables), and the records that end the batches
+    while (counter_load64(ring, SCR64_CODE + 2u) == 0u)
+      {
+      if (++spins > SPIN64_LIMIT_PARSER)
+        {
+        failed = 2u;
+        break;
+        }
+      __builtin_amdgcn_s_sleep(4);
+      }
+    const uint64_t code_base = ((uint64_t)counter_load64(ring, SCR64_CODE + 1u) << 32) | counter_load64(ring, SCR64_CODE);
+    for (uint32_t sl = 0; sl < RING64 && !failed; ++sl)
+      put_end64(code_base + (uint64_t)CH64_SLOT_END * (uint64_t)CH64_STRIDE, ring + SLOT64_DWORDS * sl);
+    spins = 0;
+    while (t < nb && !failed)
       {
       const uint32_t cons = counter_load64(ring, SCR64_CONSUMED);
       if (cons == ABORT64)                               // the chain gave up waiting (it reports the timeout itself)
@@ -555,7 +563,12 @@ __device__ __forceinline__ void decode64_pair(const Fpc64ChainJob& job, u64* __r
       const u64 be = ((u64)__builtin_bswap32(lo) << 32) | __builtin_bswap32(hi);      // first stream byte on top
       const u64 xr = nbytes ? be >> (8u * (8u - nbytes)) : 0ull;
       const uint64_t dfcm = __ballot(code > 8u);
-      put_batch64(xr, dfcm, ring + SLOT64_DWORDS * (t % RING64));
+      // the body of quad q (lanes 0..15): by the parity of q, the kinds of its four values and the kind of the value behind it
+      // (the last quad of a batch takes the bodies that assume an F there: the chain requests the first entry of a batch itself)
+      const uint32_t slot_idx = (((uint32_t)lane & 1u) << 5) | ((uint32_t)(dfcm >> (4u * ((uint32_t)lane & 15u))) & 31u);
+      const uint64_t target = code_base + (uint64_t)slot_idx * (uint64_t)CH64_STRIDE;
+      const uint32_t sl = t % RING64;
+      put_quads64(xr, (uint32_t)target, (uint32_t)(target >> 32), ring + SLOT64_DWORDS * sl, 4u * SLOT64_DWORDS * sl, (uint32_t)(dfcm & 1ull));
       ++t;
       counter_store64(ring, SCR64_PRODUCED, t);
       }
@@ -581,7 +594,7 @@ __device__ __forceinline__ void decode64_pair(const Fpc64ChainJob& job, u64* __r
     __builtin_amdgcn_s_setprio(3);                        // the chain owns its SIMD's issue slots whenever it can issue
     const uint32_t nlast = n - 64u * (nb - 1u);           // values of the last batch, 1 .. 64
     const uint64_t last_mask = nlast >= 64u ? ~0ull : (1ull << nlast) - 1ull;
-    const uint32_t tmo = chain64_run(T1, T2, ring, nb, last_mask, dst, 8u * (uint32_t)lane * (uint32_t)arity, 512u * (uint32_t)arity);
+    const uint32_t tmo = chain64_run(T1, T2, ring, nb, last_mask, dst, (uint32_t)lane, (uint32_t)arity, 512u * (uint32_t)arity);
     __builtin_amdgcn_s_setprio(0);
     if (tmo && lane == 0)
       atomicOr(&sh_bad, 2u);
