@@ -52,6 +52,10 @@ def value(out, j, kind, nextk, cur, prefetch):
     h1 = [f"s_lshr_b32 s57, {OUT['vhi']}, 9", f"s_and_b32 {O1N}, s57, 0x7ffff8"]        # top 20 bits of the value, as a byte offset
     h2 = [f"s_lshl_b32 s58, {O2O}, 10", f"s_lshr_b32 s57, {OUT['shi']}, 9", "s_xor_b32 s58, s58, s57", f"s_and_b32 {O2N}, s58, 0x7ffff8"]
     stores = [f"s_store_dwordx2 {OUT['v']}, s[46:47], {O1O}", f"s_store_dwordx2 {OUT['s']}, s[48:49], {O2O}"]   # fpsc.c:982-995
+    if os.environ.get("CH64_EXPERIMENT") == "no_t2_store":      # timing experiment only: wrong values
+        stores = stores[:1]
+    if os.environ.get("CH64_EXPERIMENT") == "no_stores":
+        stores = []
     if nextk == "F":
         out += h1
         out.append(f"s_load_dwordx2 s[44:45], s[46:47], {O1N}")

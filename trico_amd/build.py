@@ -28,7 +28,7 @@ EXTRA = os.environ.get("TRICO_HIPCC_FLAGS", "").split()      # experiments: extr
 
 HOST_C = ["host/archive.c", "host/lowlevel.c"]
 HIP_SRC = sorted(f for f in os.listdir(os.path.join(CSRC, "hip")) if f.endswith(".hip"))
-HIP_HDR = sorted(f for f in os.listdir(os.path.join(CSRC, "hip")) if f.endswith(".hpp"))
+HIP_HDR = sorted(f for f in os.listdir(os.path.join(CSRC, "hip")) if f.endswith((".hpp", ".inc")))      # (.inc: generated chain bodies)
 
 LIBTRICO = os.path.join(LIBDIR, "libtrico.so")
 LIBTRICO_A = os.path.join(LIBDIR, "libtrico.a")
