@@ -27,6 +27,7 @@ import os
 import sys
 
 STRIDE = 512
+NO_FD_WAIT = os.environ.get("CH5_NO_FD_WAIT", "0") == "1"    # timing experiment only: UNSAFE (a load may pass an older store)
 STORE_AFTER_LOAD = os.environ.get("CH5_STORE_AFTER_LOAD", "0") == "1"    # experiment: the stride's store behind the next entry's load
 A = ("s52", "s53")           # {stride, value}
 B = ("s54", "s55")
@@ -41,7 +42,7 @@ def value(out, j, kind, nextk, cur, prefetch):
     load = nextk in "DU"
     # every store older than this value's own must be complete before a load is issued (only lgkmcnt(0) means anything for scalar
     # memory), and a D value needs its entry: both wait here
-    if kind == "D" or load:
+    if kind == "D" or (load and not NO_FD_WAIT):
         out.append("s_waitcnt lgkmcnt(0)")
     if prefetch:
         out.append(prefetch)
