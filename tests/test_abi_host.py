@@ -3,6 +3,7 @@ container logic (header, peeks, sequencing, skip) behaves like the reference —
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -216,3 +217,15 @@ def test_bench_refuses_more_ranks_than_devices():
                          env=env)
     assert out.returncode != 0 and "no device of its own" in out.stderr, out.stdout + out.stderr
     assert time.time() - t0 < 100
+
+
+def test_generated_chain_bodies_are_current(tmp_path):
+    """trico_amd/csrc/hip/chain5_bodies.inc and chain64_bodies.inc are generated (tools/gen_chain5.py, gen_chain64.py) and committed:
+    what is in the tree must be what the generators write today, with no experiment switch set."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("CH5_", "CH64_"))}
+    for gen, inc in (("gen_chain5.py", "chain5_bodies.inc"), ("gen_chain64.py", "chain64_bodies.inc")):
+        out = tmp_path / inc
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen)], check=True, env=dict(env, TRICO_GEN_OUT=str(out)),
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        assert out.read_text() == open(os.path.join(ROOT, "trico_amd", "csrc", "hip", inc)).read(), inc

@@ -161,7 +161,7 @@ def main():
             lines.append('  "%s\\n" \\' % t)
         lines.append('  ".p2align %d\\n" \\' % (10 if "run" in name else 9))
     lines.append('  ""')
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "trico_amd", "csrc", "hip", "chain5_bodies.inc")
+    path = os.environ.get("TRICO_GEN_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "trico_amd", "csrc", "hip", "chain5_bodies.inc")
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")
     n = max(len(t) for _, t in slots)

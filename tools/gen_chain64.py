@@ -110,7 +110,7 @@ def main():
             lines.append('  "%s\\n" \\' % t)
         lines.append('  ".p2align 9\\n" \\')
     lines.append('  ""')
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "trico_amd", "csrc", "hip", "chain64_bodies.inc")
+    path = os.environ.get("TRICO_GEN_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "trico_amd", "csrc", "hip", "chain64_bodies.inc")
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")
     print("wrote", os.path.normpath(path), "- largest body", worst, "bytes", file=sys.stderr)

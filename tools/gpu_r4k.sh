@@ -1,6 +1,8 @@
 set -e
 R=$GRAFT_REPO_ROOT
 cd $R
-echo "## kept"; timeout -k 10 200 python tools/perf_float_decode_nocheck.py 2>&1 | tail -3
-echo "## no wait in F values before a D value (unsafe)"
-TRICO_AMD_LIB=$R/tools/_exp/libtrico_no_fd_wait.so timeout -k 10 200 python tools/perf_float_decode_nocheck.py 2>&1 | tail -3
+for g in "default" "524288 98304" "655360 98304" "786432 98304" "655360 131072" "1048576 98304"; do
+  echo "== geometry $g"
+  if [ "$g" = "default" ]; then unset TRICO_LZ4_CHUNK TRICO_LZ4_WARM; else set -- $g; export TRICO_LZ4_CHUNK=$1 TRICO_LZ4_WARM=$2; fi
+  timeout -k 10 200 python tools/perf_lz4.py walk 2>&1 | grep -E "encode iter 2|decode iter 1"
+done
