@@ -1,8 +1,13 @@
 set -e
 R=$GRAFT_REPO_ROOT
-cd $R
-for g in "default" "524288 98304" "655360 98304" "786432 98304" "655360 131072" "1048576 98304"; do
-  echo "== geometry $g"
-  if [ "$g" = "default" ]; then unset TRICO_LZ4_CHUNK TRICO_LZ4_WARM; else set -- $g; export TRICO_LZ4_CHUNK=$1 TRICO_LZ4_WARM=$2; fi
-  timeout -k 10 200 python tools/perf_lz4.py walk 2>&1 | grep -E "encode iter 2|decode iter 1"
+O=$R/gpurun_out/r4k
+mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+for t in 256 128 512; do
+  if [ $t = 256 ]; then unset TRICO_AMD_LIB; else export TRICO_AMD_LIB=$R/tools/_exp/libtrico_gt$t.so; fi
+  for m in grid walk; do
+    timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/enc -- python $R/tools/perf_fpc32.py $m > $O/enc.log 2>&1
+    echo "## threads $t $m"; grep "kernel span" $O/enc.log; python $R/tools/prof_summary.py $O/enc | grep "gather"
+    rm -rf $O/enc
+  done
 done
