@@ -1,6 +1,6 @@
 set -e
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r4i
+O=$R/gpurun_out/dbl_loop
 mkdir -p $O
 cd $R
 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_lowlevel.py tests/test_gpu_batch.py tests/test_gpu_selfcheck.py -m gpu -x -q > $O/pytest.log 2>&1 || { tail -60 $O/pytest.log; exit 1; }

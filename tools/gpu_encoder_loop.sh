@@ -1,7 +1,7 @@
 # parity + timings + HBM traffic for lag variants
 set -e
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r4f
+O=$R/gpurun_out/enc_loop
 mkdir -p $O
 cd $R
 timeout -k 10 400 python -m pytest tests/test_gpu_onesweep.py tests/test_gpu_parity.py -m gpu -x -q > $O/pytest.log 2>&1 || { tail -60 $O/pytest.log; exit 1; }

@@ -1,4 +1,4 @@
-# float encoder variants; usage: gpurun -- bash tools/run_enc_var.sh grid "TRICO_FPC32_TILE=3" "TRICO_FPC32_WAVES=5376" ...
+# float encoder variants; usage: gpurun -- bash tools/run_enc_var.sh grid "TRICO_FPC32_SWEEPS=2" "TRICO_FPC32_WAVES=5376" ...
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 kind=$1; shift
