@@ -91,7 +91,13 @@ def _pmc_file_traffic(path):
     gfx950 rule of MI355X_MICROARCH.md, validated for this kernel's reads in profiles/r02_ubench_fetch_size.txt)."""
     import re
     kernel, disp, fetch, write = None, {}, {}, {}
+    section = "grid"                                   # (round 4's files hold a "## grid" and a "## walk" section; older ones the grid only)
     for line in open(path):
+        if line.startswith("## "):
+            section = line[3:].strip()
+            continue
+        if section != "grid":
+            continue
         m = re.match(r"^(\S+) dispatches (\d+)", line)
         if m:
             kernel = m.group(1)
