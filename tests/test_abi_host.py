@@ -175,6 +175,35 @@ def test_cmake_package_builds_a_consumer(native_libs, tmp_path):
     assert r.returncode == 0 and r.stdout.strip() == "8", r.stdout + r.stderr        # the empty archive: magic + version
 
 
+def test_cmake_package_static_flavour(native_libs, tmp_path):
+    """The same package with TRICO_SHARED off (the reference's default, trico/CMakeLists.txt:27-34): the plain target name `trico` then
+    means libtrico.a (+ the HIP and C++ runtimes it needs); the consumer links with the C compiler and runs the host-only calls."""
+    import shutil
+    import subprocess
+    cmake = shutil.which("cmake")
+    if not cmake:
+        pytest.skip("no cmake")
+    src = tmp_path / "src"
+    src.mkdir()
+    (src / "main.c").write_text(
+        "#include <trico/trico.h>\n#include <stdio.h>\n"
+        "int main(void)\n{\n  void* a = trico_open_archive_for_writing(64);\n  if (!a) return 1;\n"
+        "  printf(\"%llu\\n\", (unsigned long long)trico_get_size(a));\n  trico_close_archive(a);\n  return 0;\n}\n")
+    (src / "CMakeLists.txt").write_text(
+        "cmake_minimum_required(VERSION 3.10)\nproject(consumer C CXX)\nset(TRICO_SHARED OFF)\n"
+        "find_package(trico CONFIG REQUIRED PATHS \"%s\" NO_DEFAULT_PATH)\n"
+        "add_executable(consumer main.c)\ntarget_link_libraries(consumer PRIVATE trico)\n" % os.path.join(ROOT, "cmake"))
+    bld = tmp_path / "bld"
+    r = subprocess.run([cmake, "-S", str(src), "-B", str(bld)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([cmake, "--build", str(bld)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run(["ldd", str(bld / "consumer")], capture_output=True, text=True)
+    assert "libtrico.so" not in r.stdout, r.stdout
+    r = subprocess.run([str(bld / "consumer")], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "8", r.stdout + r.stderr
+
+
 def test_static_library_links_a_consumer(native_libs, tmp_path):
     """The reference's default flavour is a static library (reference CMakeLists.txt:19-20, trico/CMakeLists.txt:27-34:
     TRICO_SHARED=no): trico_amd/lib/libtrico.a holds the same objects as libtrico.so.  A C program links against it (hipcc as the
