@@ -1,0 +1,63 @@
+"""Reads the per-wave timelines a -DTRICO_SWEEP_DIAG build of k_fpc32_sweep wrote (TRICO_SWEEP_DIAG_FILE) and says where the time goes."""
+import sys
+import numpy as np
+
+raw = np.fromfile(sys.argv[1], dtype=np.uint64)
+S, G, arity, L = [int(x) for x in raw[:4]]
+r = raw[4:].reshape(-1, 8)[: (S + G) * arity]
+hw = r[:, 0].astype(np.int64)
+xcc = r[:, 1].astype(np.int64) & 15
+t0 = r[:, 2].min()
+start, l0, l1, end = [(r[:, k].astype(np.int64) - int(t0)) / 100.0 for k in (2, 3, 4, 5)]
+main = np.arange(S * arity)
+comp = main % arity
+simd = (hw >> 4) & 3
+cu = (hw >> 8) & 15
+sh = (hw >> 12) & 1
+se = (hw >> 13) & 7
+print("S %d guard %d arity %d L %d; starts %.2f .. %.2f us; ends %.2f .. %.2f us (main), guard ends up to %.2f" % (
+    S, G, arity, L, start.min(), start.max(), end[main].min(), end[main].max(), end[S * arity:].max() if G else 0))
+for c in range(arity):
+    m = main[comp == c]
+    d = l1[m] - l0[m]
+    print("component %d: loop time us min %.1f p10 %.1f median %.1f p90 %.1f max %.1f; prologue median %.1f us; epilogue median %.1f us" % (
+        c, d.min(), np.percentile(d, 10), np.median(d), np.percentile(d, 90), d.max(), np.median(l0[m] - start[m]), np.median(end[m] - l1[m])))
+# by place
+unit = xcc * 1000000 + se * 10000 + sh * 1000 + cu * 10 + simd
+print("distinct XCC %d, SE %s, SH %s, CU ids %s" % (len(set(xcc[main])), sorted(set(se[main])), sorted(set(sh[main])), sorted(set(cu[main]))))
+cuid = xcc * 1000 + se * 100 + sh * 50 + cu
+wg_end = end[main].reshape(S, arity).max(axis=1)
+wg_cu = cuid[main].reshape(S, arity)[:, 0]
+per_cu = {}
+for e, u in zip(wg_end, wg_cu):
+    per_cu.setdefault(int(u), []).append(e)
+cnt = np.array([len(v) for v in per_cu.values()])
+last = np.array([max(v) for v in per_cu.values()])
+print("compute units used %d; workgroups per unit min %d max %d; last end per unit: min %.1f median %.1f max %.1f us" % (len(per_cu), cnt.min(), cnt.max(), last.min(), np.median(last), last.max()))
+for x in sorted(set(xcc[main])):
+    m = main[xcc[main] == x]
+    print("  XCC %d: waves %d, loop time median %.1f us, end median %.1f max %.1f" % (x, len(m), np.median((l1 - l0)[m]), np.median(end[m]), end[m].max()))
+# waves per SIMD of the slow component
+slow = arity - 1
+key = cuid * 4 + simd
+zc = {}
+for i in main[comp == slow]:
+    zc.setdefault(int(key[i]), []).append(l1[i] - l0[i])
+by = {}
+for k, v in zc.items():
+    by.setdefault(len(v), []).extend(v)
+for k in sorted(by):
+    print("  SIMDs holding %d waves of component %d: %d waves, loop time median %.1f us" % (k, slow, len(by[k]), np.median(by[k])))
+allc = {}
+for i in main:
+    allc.setdefault(int(key[i]), []).append(l1[i] - l0[i])
+by = {}
+for k, v in allc.items():
+    by.setdefault(len(v), []).extend(v)
+for k in sorted(by):
+    print("  SIMDs holding %d waves: %d waves, loop time median %.1f us" % (k, len(by[k]), np.median(by[k])))
+# along the stream
+gi = (main // arity)
+for lo in range(0, S, max(1, S // 8)):
+    m = main[(gi >= lo) & (gi < lo + max(1, S // 8))]
+    print("  segments %5d..: loop time median %.1f us, end median %.1f" % (lo, np.median((l1 - l0)[m]), np.median(end[m])))

@@ -25,32 +25,33 @@ constexpr uint32_t SENT = 0x7fc0dead;
 // the host with the sizes (k_fpc32_offsets)
 constexpr uint32_t FLAG_ORDER = FPC32_FLAG_ORDER, FLAG_SENTINEL = FPC32_FLAG_SENTINEL;
 
-// Record of a deferred value (k_fpc32_sweep -> k_fpc32_fixup -> k_fpc32_gather):
-//   w0 slot offset of the value's four reserved bytes      w1 dh | gi << 8 | ft1 << 12 | ft2 << 13 | k2 << 20
+// Record of a deferred value (k_fpc32_sweep -> k_fpc32_fixup -> k_fpc32_gather), RECW words:
+//   w0 slot offset of the value's four reserved bytes | gi << 24 | ft1 << 28 | ft2 << 29
+//   w1 slot offset of the three header bytes of the value's group
 //   w2 the value   w3 its predecessor   w4 the prediction that IS known (one open class), else 0
-//   w6 residual, w7 length | code << 4  (written by the fix-up)
-// dh = distance from the group's header to the four bytes (3..31), gi = index in the group, k2 = DFCM class (the FCM class is
-// the top four bits of w3); ft1 / ft2 = the FCM / DFCM prediction is the one the segment does not know.
+//   w5 4 * DFCM class of the value      w6 residual, w7 length | code << 4  (written by the fix-up)
+// gi = index in the group; ft1 / ft2 = the FCM / DFCM prediction is the one the segment does not know (the FCM class is the top
+// four bits of w3).  Slot offsets stay below 2^24: a segment's slot is 4.4 bytes per value of at most n / 2544 values.
+constexpr uint32_t REC_POS = 0x00ffffffu, REC_GI_SHIFT = 24, REC_FT1 = 1u << 28, REC_FT2 = 1u << 29;
+constexpr uint32_t REC_CMPW = 6;  // words the sweep writes (what the write-side guard compares)
 
 struct Plan
   {
   uint32_t L, S, segcap, nch;
   size_t rows, slot_stride;
-  size_t off_summ, off_inc, off_chmax, off_nrec, off_recs, off_segbytes, off_rawbytes, off_segoff, off_gslots, off_grecs, off_gmeta, off_slots, total;
+  size_t off_summ, off_inc, off_chmax, off_nrec, off_recs, off_segbytes, off_rawbytes, off_segoff, off_gslots, off_grecs, off_gmeta, off_diag, off_slots, total;
   };
+
+// Workgroups of k_fpc32_sweep (one wave per component) the current device holds at once (k_fpc32_sweep.hip).  The sweep wants its whole
+// grid resident in ONE round: a workgroup that has to wait for a free place starts when the first ones are done and ends a segment's
+// time later (measured with TRICO_SWEEP_DIAG in round 5: 10 % of the workgroups in a second round were 40 % of the kernel's time).
+int fpc32_sweep_resident_workgroups(int arity);
 
 inline Plan make_plan(uint32_t n, int arity)
   {
-  static int waves = 0;
-  if (!waves)
-    {
-    const char* e = getenv("TRICO_FPC32_WAVES");      // tuning knob: waves per sweep (30 per CU x 256 CUs)
-    waves = e ? atoi(e) : 7680;
-    if (waves < 3) waves = 3;
-    }
   Plan p;
   // (the guard's workgroups take part in the sweep's launch: leave them room, so that the whole grid is resident at once)
-  uint32_t target = (uint32_t)waves / (uint32_t)arity;
+  uint32_t target = (uint32_t)fpc32_sweep_resident_workgroups(arity);
   if (target > 8u * GUARD_WGS)
     target -= GUARD_WGS;
   uint64_t L = ((uint64_t)n + target - 1) / target;
@@ -75,6 +76,7 @@ inline Plan make_plan(uint32_t n, int arity)
   p.off_gslots = o;    o += align_up((size_t)GUARD_WGS * arity * GUARD_SLOT, 256);
   p.off_grecs = o;     o += align_up((size_t)GUARD_WGS * arity * RCAP * RECW * 4, 256);
   p.off_gmeta = o;     o += align_up((size_t)GUARD_WGS * 3 * 16, 256);
+  p.off_diag = o;      o += 512;                 // diagnostic builds (-DTRICO_SWEEP_DIAG): clocks of one wave per component
   p.off_slots = o;     o += p.slot_stride * arity;
   p.total = o + 256;
   return p;

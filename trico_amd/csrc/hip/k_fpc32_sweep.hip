@@ -35,15 +35,13 @@ namespace fpc32 {
 
 namespace {
 
-#ifndef TRICO_PF
-#define TRICO_PF 6
-#endif
-constexpr int PF = TRICO_PF;                      // steps (of 64 values) whose loads are kept in flight per wave
-constexpr int STAGE_LIVE = 544;                   // < 256 unflushed + <= 280 of the step, rounded
-constexpr int STAGE = STAGE_LIVE + 256;           // + 4 dump bytes per lane
-constexpr int LDSW = 1248;                        // per-wave LDS words: TAB + STAGE / 4 = 1240, rounded so that every wave's table starts
-                                                  // at a multiple of 64 bytes (4,992 B: 10 workgroups of 3 waves per CU)
-static_assert(LDSW >= TAB + STAGE / 4 && (LDSW * 4) % 64 == 0, "LDS layout of a wave");
+constexpr int PF = 6;                             // steps (of 64 values) whose loads a wave keeps in flight (sweep_blocks_asm is written for 6)
+constexpr int FLB = 512;                          // the staging area leaves in blocks of this many bytes (8 per lane)
+constexpr int STAGE_LIVE = FLB + 280;             // < 512 unflushed + <= 280 of the step
+constexpr int STAGE = STAGE_LIVE + 256;           // + 4 dump bytes per lane (compiled step only)
+constexpr int LDSW = 1312;                        // per-wave LDS words: TAB + STAGE / 4 = 1302, rounded so that every wave's table starts
+                                                  // at a multiple of 64 bytes (5,248 B: 10 workgroups of 3 waves per CU)
+static_assert(LDSW >= TAB + STAGE / 4 && (LDSW * 4) % 64 == 0 && (TAB * 4) % 8 == 0, "LDS layout of a wave");
 
 constexpr uint32_t GUARD_STEPS = 64;              // steps of a sampled segment the guard codes again
 constexpr uint32_t GUARD_CAP = GUARD_SLOT;        // bytes they can produce (a step: 24 header + 256 residual bytes), rounded
@@ -59,17 +57,14 @@ struct LaneK                                      // per-lane constants
   bool lead;
   };
 
-struct Sweep                                      // running state of a wave
+struct Sweep                                      // running state of a wave between steps
   {
   uint32_t vp, sp, s1p, a1p, a2p;                 // per lane, of the previous step: value, stride, stride of the lane below, table addresses
-  uint32_t pend1, pend2;                          // 1: the table writes of the previous step's last value are still pending
+  uint32_t pend1, pend2;                          // 1: the table writes of the previous step's last value are still pending (compiled step only)
   uint32_t posl, flushed;                         // bytes staged in LDS / bytes already in the slot
-  uint32_t fl_nb, fl_off;                         // flush in flight (1, else 0): a 256-byte block and its offset in the slot
-  uint32_t fw0, ft;                               // ... per lane: its word of the block and of what moves to the front
   uint32_t nrec;                                  // records written so far
   uint32_t flags;                                 // FLAG_* raised by this wave
-  uint64_t sent;                                  // lanes that stored the sentinel as a payload, in any step (code_step_asm)
-  uint32_t ustate, ustride;                       // 24 / 88: the previous step was a constant one of that size (see step_uniform_asm); its stride
+  uint64_t sent;                                  // lanes that stored the sentinel as a payload, in any step of sweep_blocks_asm
   };
 
 constexpr uint32_t DUMP = STAGE_LIVE + 1;          // a lane's four dump bytes: stage + DUMP - 1 + 4 * lane
@@ -82,49 +77,36 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint64_t bytes)
   {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : (uint32_t)bytes), 0x00020000);
   }
-
-// second half of a flush (see flush_begin): the word read from the staging area a step ago goes to the slot, the unflushed rest
-// moves to the front.  Must run before the next byte is staged.
-__device__ __forceinline__ void flush_end(Sweep& sw, uint8_t* __restrict__ stage, rsrc_t slot, const LaneK& lk)
+// the same descriptor as four words in scalar registers (what sweep_blocks_asm takes as an operand)
+__device__ __forceinline__ u32x4 make_desc(const void* base, uint64_t bytes)
   {
-  if (sw.fl_nb)
-    {
-    // (streaming stores: the slot is read again only by the gather, and the lines should not push the input out of the L2)
-    __builtin_amdgcn_raw_buffer_store_b32(sw.fw0, slot, lk.lane4, sw.fl_off, 2);
-    ((uint32_t*)stage)[lk.lane] = sw.ft;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    sw.fl_nb = 0u;
-    }
+  const uint64_t b = (uint64_t)(uintptr_t)base;
+  u32x4 d;
+  d[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+  d[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(b >> 32) & 0xffffu));
+  d[2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(bytes > 0xffffffffull ? 0xffffffffu : (uint32_t)bytes));
+  d[3] = 0x00020000u;
+  return d;
   }
 
-// first half of a flush: a full 256-byte block goes to the slot as aligned dwords, the rest moves to the front of the staging area.
-// Only the LDS reads are issued here - in every step, wanted or not: two reads cost no vector instruction, a choice would - and
-// their data is used by flush_end() in the next step, right before its first byte is staged (LDS operations of a wave execute in
-// order), so the wave never waits for the round trip.  Two full blocks at once (a step of more than 256 bytes on top of nearly 256)
-// are rare: the first one leaves on the spot.
-__device__ __forceinline__ void flush_begin(Sweep& sw, uint8_t* __restrict__ stage, rsrc_t slot, const LaneK& lk)
+// A full block of the staging area (512 bytes, 8 per lane) goes to the slot, what is behind it (< 280 bytes) moves to the front.
+// The compiled step does this on the spot; sweep_blocks_asm issues the LDS reads at the end of a step and uses them in the next.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void flush_sync(Sweep& sw, uint8_t* __restrict__ stage, rsrc_t slot, const LaneK& lk)
   {
-  uint32_t* stw = (uint32_t*)stage;
-  if (sw.posl >= 512u)
+  if (sw.posl >= (uint32_t)FLB)
     {
-    __builtin_amdgcn_raw_buffer_store_b32(stw[lk.lane], slot, lk.lane4, sw.flushed, 2);
-    const uint32_t w1 = stw[64u + lk.lane], w2 = stw[128u + lk.lane];
+    uint32_t* stw = (uint32_t*)stage;
+    const u32x2 w = *(const u32x2*)(stw + 2u * lk.lane);
+    const uint32_t t0 = stw[128u + lk.lane], t1 = stw[192u + lk.lane];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    stw[lk.lane] = w1;
-    stw[64u + lk.lane] = w2;
+    // (streaming stores: the slot is read again only by the gather, and the lines should not push the input out of the L2)
+    __builtin_amdgcn_raw_buffer_store_b64(w, slot, 8u * lk.lane, sw.flushed, 2);
+    stw[lk.lane] = t0;
+    stw[64u + lk.lane] = t1;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    sw.flushed += 256u;
-    sw.posl -= 256u;
-    }
-  sw.fw0 = stw[lk.lane];
-  sw.ft = stw[64u + lk.lane];
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  if (sw.posl >= 256u)
-    {
-    sw.fl_nb = 1u;
-    sw.fl_off = sw.flushed;
-    sw.flushed += 256u;
-    sw.posl &= 255u;
+    sw.flushed += (uint32_t)FLB;
+    sw.posl -= (uint32_t)FLB;
     }
   }
 
@@ -283,21 +265,21 @@ __device__ __forceinline__ void step_tail(uint32_t v, uint32_t a, uint32_t a1, u
   }
   if (hm)
     {
-    // record: where the four bytes are (offset in the slot) and how far behind its group header, the value and its predecessor,
+    // record (fpc32_common.hpp): where the four bytes and the group's header are in the slot, the value and its predecessor,
     // which classes are open, the prediction that is known if only one is open
-    const uint32_t pre_lead = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lk.lane & ~7u) << 2), (int)pre);
+    const uint32_t hq_lead = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lk.lane & ~7u) << 2), (int)hq);
     const uint32_t idx = sw.nrec + popc_below(hm);
     if (hole)
       {
       u32x4 w;
-      w[0] = sw.flushed + (hq - sbase) + 3u;
-      w[1] = (3u + pre - pre_lead) | ((lk.lane & 7u) << 8) | ((uint32_t)ft1 << 12) | ((uint32_t)ft2 << 13) |
-             (((a2 - (t1abs + 64u)) >> 2) << 20);
+      w[0] = (sw.flushed + (hq - sbase) + 3u) | ((lk.lane & 7u) << REC_GI_SHIFT) | (ft1 ? REC_FT1 : 0u) | (ft2 ? REC_FT2 : 0u);
+      w[1] = sw.flushed + (hq_lead - sbase);
       w[2] = v;
       w[3] = a;
       uint32_t* r = sink.recs + RECW * idx;
       *(u32x4*)r = w;
       r[4] = ft1 ? (ft2 ? 0u : p2) : p1;
+      r[5] = a2 - (t1abs + 64u);
       }
     sw.nrec += (uint32_t)__popcll(hm);
     }
@@ -354,7 +336,6 @@ __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_en
   if (!FULL) { st1 = st1 && act; st2 = st2 && act; }
   const bool any1 = __ballot(st1) != 0ull, any2 = __ballot(st2) != 0ull;
   const uint32_t sbase = (uint32_t)(uintptr_t)(lds_u8*)stage;        // LDS address of the staging area (uniform)
-  flush_end(sw, stage, slot, lk);
   // Every value continues its runs and every prediction is exact: the 64 values are a constant - eight groups of a zero header
   // (FCM hit: code 0, no byte), or of header b6 db 6d and eight zero bytes (DFCM hit: code 5, residual byte 0x00; it is the choice
   // only if the FCM residual needs more than one byte, fpsc.c:146-189).  One LDS store, no byte layout.
@@ -376,7 +357,7 @@ __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_en
   else
     step_general<FULL, BALLOT, HOOK>(v, a, s, s1, a1, a2, st1, st2, any1, any2, act, i, i_end, n, t1abs, sbase, sw, lk, sink, sabotage);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  flush_begin(sw, stage, slot, lk);
+  flush_sync(sw, stage, slot, lk);
   sw.vp = v; sw.sp = s; sw.s1p = s1; sw.a1p = a1; sw.a2p = a2;
   }
 
@@ -400,351 +381,543 @@ __device__ __forceinline__ LaneK lane_constants(uint32_t lane)
   return lk;
   }
 
-// ---- the same step, written out ---------------------------------------------------------------------------------------------
-// The sweep is bound by instruction issue - a SIMD takes one vector and one scalar instruction per four cycles, and the step the
-// compiler makes of the C++ above costs ~67 of each per 64 values on the benchmark mesh (SQ counters, profiles/r04_*) - so the
-// full steps run hand-scheduled code: 25 vector instructions up to the
-// verdict "constant step" (+2 for its store), 4 per resolved predictor (the run-end mask is the run-start mask shifted by one lane:
-// scalar), 33 for selection, scan, headers and byte stores.  DPP sources are read at the earliest three instructions after they were
-// written (two wait states, which the assembler does not check); EXEC is all ones on entry and on exit.
-
 // (the compiler takes what an asm statement returns for divergent, scalar registers or not: these tell it otherwise)
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uint32_t)(x >> 32)) << 32) | uni((uint32_t)x); }
 
-// head: classes and run starts.  no1 / no2 = 1: no run of FCM / DFCM classes starts in this step.
-__device__ __forceinline__ void step_head_asm(uint32_t v, const Sweep& sw, uint32_t t1abs, uint32_t& a, uint32_t& s, uint32_t& s1,
-                                              uint32_t& a1, uint32_t& a2, uint64_t& st1, uint64_t& st2, uint32_t& no1, uint32_t& no2)
-  {
-  uint32_t s2, q1, q2, t, u;
-  asm volatile(
-    "s_nop 1\n"
-    "v_mov_b32_dpp %[a], %[vp] wave_ror:1 row_mask:0xf bank_mask:0xf\n"
-    "v_mov_b32_dpp %[s1], %[sp] wave_ror:1 row_mask:0xf bank_mask:0xf\n"
-    "v_mov_b32_dpp %[s2], %[s1p] wave_ror:1 row_mask:0xf bank_mask:0xf\n"
-    "v_mov_b32_dpp %[q1], %[a1p] wave_ror:1 row_mask:0xf bank_mask:0xf\n"
-    "v_mov_b32_dpp %[q2], %[a2p] wave_ror:1 row_mask:0xf bank_mask:0xf\n"
-    "v_mov_b32_dpp %[a], %[v] wave_shr:1 row_mask:0xf bank_mask:0xf\n"          // a = v[i-1]
-    "v_sub_u32 %[s], %[v], %[a]\n"                                                 // stride of v[i]
-    "v_lshrrev_b32 %[t], 26, %[a]\n"
-    "v_and_or_b32 %[a1], %[t], 60, %[t1]\n"                                        // FCM entry: table + 4 * (top four bits of v[i-1])
-    "v_mov_b32_dpp %[s1], %[s] wave_shr:1 row_mask:0xf bank_mask:0xf\n"          // stride of v[i-1]
-    "s_nop 0\n"
-    "v_mov_b32_dpp %[q1], %[a1] wave_shr:1 row_mask:0xf bank_mask:0xf\n"
-    "v_lshrrev_b32 %[u], 22, %[s1]\n"
-    "v_mov_b32_dpp %[s2], %[s1] wave_shr:1 row_mask:0xf bank_mask:0xf\n"         // stride of v[i-2]
-    "v_cmp_ne_u32_e64 %[st1], %[a1], %[q1]\n"
-    "v_lshrrev_b32 %[t], 17, %[s2]\n"
-    "v_bitop3_b32 %[t], %[t], %[u], %[k3e0] bitop3:0x6c\n"                         // ((s2 >> 17) & 0x3e0) ^ (s1 >> 22): the DFCM class
-    "v_lshl_add_u32 %[a2], %[t], 2, %[t2]\n"
-    "s_cmp_eq_u64 %[st1], 0\n"
-    "s_cselect_b32 %[no1], 1, 0\n"
-    "v_mov_b32_dpp %[q2], %[a2] wave_shr:1 row_mask:0xf bank_mask:0xf\n"
-    "v_cmp_ne_u32_e64 %[st2], %[a2], %[q2]\n"
-    "s_cmp_eq_u64 %[st2], 0\n"
-    "s_cselect_b32 %[no2], 1, 0\n"
-    : [a] "=&v"(a), [s] "=&v"(s), [s1] "=&v"(s1), [s2] "=&v"(s2), [a1] "=&v"(a1), [a2] "=&v"(a2), [q1] "=&v"(q1), [q2] "=&v"(q2),
-      [t] "=&v"(t), [u] "=&v"(u), [st1] "=&s"(st1), [st2] "=&s"(st2), [no1] "=&s"(no1), [no2] "=&s"(no2)
-    : [v] "v"(v), [vp] "v"(sw.vp), [sp] "v"(sw.sp), [s1p] "v"(sw.s1p), [a1p] "v"(sw.a1p), [a2p] "v"(sw.a2p), [t1] "s"(t1abs),
-      [t2] "s"(t1abs + 64u), [k3e0] "s"(0x3e0u)
-    : "scc", "memory");
-  st1 = uni(st1);
-  st2 = uni(st2);
-  no1 = uni(no1);
-  no2 = uni(no2);
-  }
+// ---- the full steps, written out: one asm statement for all whole blocks of a segment --------------------------------------------
+// Why: the kernel is bound by what ONE wave can issue.  A wave issues at most one instruction per ~4 cycles, scalar or vector,
+// branches cost several of those, and the step the compiler makes of C++ around asm pieces (round 4) spent more scalar and branch
+// instructions on glue than vector instructions on the coder (SQ counters: 128 M scalar against 102 M vector per sweep of the
+// benchmark mesh; ~12 branches per step) - and waited for memory it had asked for six steps ahead, because the flush and record
+// stores sit in the same in-order queue as the prefetch loads and the compiler's vmcnt knows nothing of stores inside asm.
+// So the loop is one piece of hand-scheduled code with these rules:
+//   * a step is general or uniform.  The GENERAL step always resolves both predictors with the LDS exchange (exec = the lanes where a
+//     run of equal classes starts or ends; lane 63 always ends one): there is no "pending table write" state, no variant without
+//     FCM run starts, and deferred values cost three selects, not a branch;
+//   * the UNIFORM step (the step before had no run start and only exact hits: the rows of a grid, flat parts of a scan) checks
+//     that this one is the same (9 vector instructions) and stores a constant pattern; the table is brought up to date when such
+//     a stretch ends (SW_LEAVE).  A general step without run starts looks whether the next one may try (SW_ENTRY);
+//   * the staging area leaves in blocks of 512 bytes - at most one per step, so there is no second case: the two LDS reads are
+//     issued at the end of every step, used at the start of the next under exec = "a block is full", no branch;
+//   * EVERY step issues exactly four vector memory instructions (prefetch load, block store, two record stores; the stores run
+//     with exec = 0 when there is nothing to store), so "the load of this step has arrived" is exactly s_waitcnt vmcnt(4 * PF);
+//   * eight value registers rotate (value of the step, of the step before, six loads in flight): the loop body is eight steps;
+//   * a record is 15 vector instructions (the header's position comes from two DPP moves, not from a cross-lane read).
+// Hazards the assembler does not see (gfx950): a DPP source written by a vector instruction needs two instructions in between,
+// v_readlane one, a vector instruction reading an SGPR pair / VCC written by a vector instruction two.  EXEC is all ones between
+// the pieces.  Fixed registers: v[54:55] / v[56:57] the words of the staging area read for the next step's flush, v[58:63] the
+// record being written (also the four progress words in the lag check).
+#define SW_DPPF " row_mask:0xf bank_mask:0xf\n"
+#define SW_DPPB " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
 
-// The constant step (no run starts): every prediction exact -> 24 or 88 bytes staged with one store.  Returns the bytes staged, 0 if
-// the step is not one.
-__device__ __forceinline__ uint32_t step_const_asm(uint32_t v, uint32_t a, uint32_t s1, uint32_t posl_abs, const LaneK& lk)
-  {
-  uint32_t x1, x2, t, adv;
-  uint64_t nz1, nz2;
-  asm volatile(
-    "v_xor_b32 %[x1], %[v], %[a]\n"
-    "v_add_u32 %[t], %[a], %[s1]\n"
-    "v_cmp_ne_u32_e64 %[nz1], 0, %[x1]\n"
-    "v_xor_b32 %[x2], %[v], %[t]\n"
-    "v_cmp_gt_u32_e32 vcc, 0x100, %[x1]\n"
-    "v_cmp_ne_u32_e64 %[nz2], 0, %[x2]\n"
-    "s_mov_b32 %[adv], 0\n"
-    "s_cmp_eq_u64 %[nz1], 0\n"
-    "s_cbranch_scc1 .Lconst_u0_%=\n"
-    "s_or_b64 %[nz2], %[nz2], vcc\n"                                               // a lane that is not an exact DFCM hit with a long FCM residual
-    "s_cmp_lg_u64 %[nz2], 0\n"
-    "s_cbranch_scc1 .Lconst_end_%=\n"
-    "s_mov_b64 exec, 0x3fffff\n"                                                   // 64 exact DFCM hits: 88 bytes, 22 dwords
-    "v_add_u32 %[t], %[posl], %[lane4]\n"
-    "s_mov_b32 %[adv], 88\n"
-    "ds_write_b32 %[t], %[pat5]\n"                                                 // (not dword aligned: gfx950 executes it)
-    "s_branch .Lconst_done_%=\n"
-    ".Lconst_u0_%=:\n"
-    "s_mov_b64 exec, 0x3f\n"                                                       // 64 exact FCM hits: 24 zero bytes (x1 is zero in every lane)
-    "v_add_u32 %[t], %[posl], %[lane4]\n"
-    "s_mov_b32 %[adv], 24\n"
-    "ds_write_b32 %[t], %[x1]\n"
-    ".Lconst_done_%=:\n"
-    "s_mov_b64 exec, -1\n"
-    ".Lconst_end_%=:\n"
-    : [x1] "=&v"(x1), [x2] "=&v"(x2), [t] "=&v"(t), [nz1] "=&s"(nz1), [nz2] "=&s"(nz2), [adv] "=&s"(adv)
-    : [v] "v"(v), [a] "v"(a), [s1] "v"(s1), [posl] "s"(posl_abs), [lane4] "v"(lk.lane4), [pat5] "v"(lk.pat5)
-    : "vcc", "scc", "memory");
-  return uni(adv);
-  }
+// what the previous step left to flush: block to the slot, tail to the front (exec = pend ? all : none)
+#define SW_FLUSH_STORES \
+  "buffer_store_dwordx2 v[56:57], %[lane8], %[slr], %[floff] offen nt\n" \
+  "ds_write2st64_b32 %[stw], v54, v55 offset1:1\n"
 
-// one predictor's run starts (see resolve_h): pending write, exchange by the lanes where a run starts or ends, prediction of the
-// starts (the others keep pdef).  ft = starts that met an entry nobody wrote in this segment; sent collects the lanes whose payload
-// is the sentinel.
-__device__ __forceinline__ uint32_t resolve_asm(uint32_t ad, uint32_t adp, uint32_t pay, uint32_t payp, uint32_t pdef, uint64_t st,
-                                                uint32_t pend, uint64_t& ft, uint64_t& sent)
-  {
-  uint32_t old, p;
-  asm volatile(
-    "s_cmp_eq_u32 %[pend], 0\n"
-    "s_cbranch_scc1 .Lres_np_%=\n"
-    "s_mov_b32 exec_lo, 0\n"                                                       // the previous step's last value: its lane 63 holds entry and payload
-    "s_brev_b32 exec_hi, 1\n"
-    "ds_write_b32 %[adp], %[payp]\n"
-    "v_cmp_eq_u32_e32 vcc, %[ksent], %[payp]\n"
-    "s_mov_b64 exec, -1\n"
-    "s_or_b64 %[sent], %[sent], vcc\n"
-    ".Lres_np_%=:\n"
-    "s_lshr_b64 vcc, %[st], 1\n"                                                   // a run ends where the next lane starts one; lane 63 always
-    "s_bitset1_b32 vcc_hi, 31\n"
-    "s_or_b64 exec, vcc, %[st]\n"
-    "ds_wrxchg_rtn_b32 %[old], %[ad], %[pay]\n"
-    "s_mov_b64 exec, -1\n"
-    "v_cmp_eq_u32_e32 vcc, %[ksent], %[pay]\n"
-    "s_or_b64 %[sent], %[sent], vcc\n"
-    "s_waitcnt lgkmcnt(0)\n"
-    "v_cndmask_b32_e64 %[p], %[pdef], %[old], %[st]\n"
-    "v_cmp_eq_u32_e32 vcc, %[ksent], %[old]\n"
-    "s_and_b64 %[ft], vcc, %[st]\n"
-    : [p] "=&v"(p), [old] "=&v"(old), [ft] "=&s"(ft), [sent] "+s"(sent)
-    : [ad] "v"(ad), [adp] "v"(adp), [pay] "v"(pay), [payp] "v"(payp), [pdef] "v"(pdef), [st] "s"(st), [pend] "s"(pend), [ksent] "s"(SENT)
-    : "vcc", "scc", "memory");
-  ft = uni(ft);
-  sent = uni(sent);
-  return p;
-  }
+// a stretch of uniform steps ends (or the loop does): the registers of its last step that were not kept - stride, stride before it,
+// table addresses - and the table writes of its last value (lane 63), which are the only ones of the stretch that last
+#define SW_LEAVE(VP) \
+  "s_cmp_eq_u32 %[ust], 88\n" \
+  "s_cselect_b32 %[tms], %[ustr], 0\n" \
+  "v_mov_b32 %[t3], 0\n" \
+  "v_mov_b32 %[sp], %[tms]\n" \
+  "v_mov_b32 %[s1p], %[tms]\n" \
+  "v_mov_b32_dpp %[t3], " VP " wave_shr:1" SW_DPPF \
+  "s_lshr_b32 %[cand], %[tms], 22\n" \
+  "s_and_b32 %[total], %[cand], 31\n" \
+  "v_lshrrev_b32 %[t3], 26, %[t3]\n" \
+  "s_lshl_b32 %[total], %[total], 5\n" \
+  "v_and_or_b32 %[a1p], %[t3], 60, %[t1s]\n" \
+  "s_xor_b32 %[total], %[total], %[cand]\n" \
+  "s_lshl_b32 %[total], %[total], 2\n" \
+  "s_add_u32 %[total], %[total], %[t2s]\n" \
+  "v_mov_b32 %[a2p], %[total]\n" \
+  "s_mov_b32 exec_lo, 0\n" \
+  "s_brev_b32 exec_hi, 1\n" \
+  "ds_write_b32 %[a1p], " VP "\n" \
+  "ds_write_b32 %[a2p], %[sp]\n" \
+  "v_cmp_eq_u32_e32 vcc, %[ksent], " VP "\n" \
+  "s_or_b64 %[sent], %[sent], vcc\n" \
+  "v_cmp_eq_u32_e32 vcc, %[ksent], %[sp]\n" \
+  "s_mov_b64 exec, -1\n" \
+  "s_or_b64 %[sent], %[sent], vcc\n" \
+  "s_mov_b32 %[ust], 0\n" \
+  "s_nop 1\n"
 
-// residual selection, byte layout, byte stores of a full step (see step_tail); hole = the lanes whose value is deferred (four zero
-// bytes, code 0).  posl1 = LDS address of the first free staging byte - 1.  Returns the bytes staged; for the records: hq1 = LDS
-// address of the lane's group header - 1, inc = residual bytes of the lanes up to and including this one, len = of this one.
-__device__ __forceinline__ uint32_t tail_asm(uint32_t v, uint32_t a, uint32_t p1, uint32_t p2, uint64_t hole, uint32_t posl1,
-                                             const LaneK& lk, uint32_t& hq1, uint32_t& inc, uint32_t& len)
-  {
-  uint32_t x1, x2, c1, c2, x, bc, t, total;
-  uint64_t nzl;
-  asm volatile(
-    "v_xor_b32 %[x1], %[v], %[p1]\n"                                               // FCM residual
-    "v_add_u32 %[t], %[a], %[p2]\n"
-    "v_xor_b32 %[x2], %[v], %[t]\n"                                                // DFCM residual
-    "v_ffbh_u32 %[c1], %[x1]\n"
-    "v_ffbh_u32 %[c2], %[x2]\n"
-    "v_min_u32 %[c1], 32, %[c1]\n"                                                 // leading zero bits: 0..32
-    "v_min_u32 %[c2], 31, %[c2]\n"                                                 // 0..31: a DFCM residual takes at least one byte
-    "v_lshrrev_b32 %[c1], 3, %[c1]\n"                                              // leading zero bytes m1
-    "v_lshrrev_b32 %[c2], 3, %[c2]\n"                                              // m2
-    "v_cmp_gt_u32_e32 vcc, %[c2], %[c1]\n"                                         // DFCM iff its residual is shorter (fpsc.c:146-189)
-    "v_max_u32 %[t], %[c1], %[c2]\n"
-    "v_cndmask_b32_e32 %[x], %[x1], %[x2], vcc\n"
-    "v_sub_u32 %[len], 4, %[t]\n"
-    "v_cndmask_b32_e32 %[t], 0, %[c4sh], vcc\n"                                    // code = length, + 4 for DFCM: already at the code's place in the header
-    "v_lshl_or_b32 %[bc], %[len], %[sh3], %[t]\n"
-    "s_cmp_eq_u64 %[hole], 0\n"
-    "s_cbranch_scc1 .Ltail_nh_%=\n"
-    "v_cndmask_b32_e64 %[len], %[len], 4, %[hole]\n"                               // deferred values: four zero bytes, code 0
-    "v_cndmask_b32_e64 %[bc], %[bc], 0, %[hole]\n"
-    "v_cndmask_b32_e64 %[x], %[x], 0, %[hole]\n"
-    "s_nop 0\n"
-    ".Ltail_nh_%=:\n"
-    "v_perm_b32 %[x1], %[x], %[x], %[kswap]\n"                                     // (x1 from here on: the residual, bytes reversed)
-    "v_or_b32_dpp %[bc], %[bc], %[bc] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-    "v_add_u32_dpp %[inc], %[len], %[len] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-    "v_cmp_ne_u32_e64 %[nzl], 0, %[len]\n"
-    "v_or_b32_dpp %[bc], %[bc], %[bc] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-    "v_add_u32_dpp %[inc], %[inc], %[inc] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-    "s_nop 0\n"
-    "v_or_b32_dpp %[bc], %[bc], %[bc] row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-    "v_add_u32_dpp %[inc], %[inc], %[inc] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-    "s_nop 1\n"
-    "v_add_u32_dpp %[inc], %[inc], %[inc] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-    "v_lshrrev_b32 %[t], 8, %[bc]\n"
-    "s_nop 0\n"
-    "v_add_u32_dpp %[inc], %[inc], %[inc] row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-    "s_nop 1\n"
-    "v_add_u32_dpp %[inc], %[inc], %[inc] row_bcast:31 row_mask:0xc bank_mask:0xf\n"       // inclusive sum of the lengths
-    "v_add3_u32 %[c2], %[posl1], %[grp3], %[inc]\n"                                // the four bytes that END with my residual's last byte
-    "v_sub_u32 %[hq1], %[c2], %[len]\n"                                            // my group's header - 1 (my residual begins 4 behind it)
-    "v_readlane_b32 %[total], %[inc], 63\n"
-    "s_mov_b64 exec, %[nzl]\n"
-    "ds_write_b8 %[c2], %[x1]\n"                                                   // most significant byte first, in this order (see step_tail)
-    "ds_write_b8_d16_hi %[c2], %[x] offset:1\n"
-    "ds_write_b8_d16_hi %[c2], %[x1] offset:2\n"
-    "ds_write_b8 %[c2], %[x] offset:3\n"
-    "s_mov_b64 exec, %[lead]\n"
-    "ds_write_b8_d16_hi %[hq1], %[bc] offset:1\n"                                  // three header bytes, big-endian, by the lanes that lead a group
-    "ds_write_b8 %[hq1], %[t] offset:2\n"
-    "ds_write_b8 %[hq1], %[bc] offset:3\n"
-    "s_mov_b64 exec, -1\n"
-    "s_add_u32 %[total], %[total], 24\n"
-    : [x1] "=&v"(x1), [x2] "=&v"(x2), [c1] "=&v"(c1), [c2] "=&v"(c2), [len] "=&v"(len), [x] "=&v"(x),
-      [inc] "=&v"(inc), [bc] "=&v"(bc), [hq1] "=&v"(hq1), [t] "=&v"(t), [total] "=&s"(total), [nzl] "=&s"(nzl)
-    : [v] "v"(v), [a] "v"(a), [p1] "v"(p1), [p2] "v"(p2), [posl1] "s"(posl1), [grp3] "v"(lk.grp3), [sh3] "v"(lk.sh3), [c4sh] "v"(lk.c4sh),
-      [lead] "s"(0x0101010101010101ull), [hole] "s"(hole), [kswap] "s"(0x00010203u)
-    : "vcc", "scc", "memory");
-  return uni(total);
-  }
+// the flips of the test hook (libtrico_testhooks.so only): a run start in the upper half of the wave gets another prediction
+#define SW_HOOK \
+  "s_and_b64 %[tm64], %[st1], %[hk]\n" \
+  "v_xor_b32 %[t3], 0x100, %[t1]\n" \
+  "s_nop 1\n" \
+  "v_cndmask_b32_e64 %[t1], %[t1], %[t3], %[tm64]\n" \
+  "s_and_b64 %[tm64], %[st2], %[hk]\n" \
+  "v_xor_b32 %[t3], 0x100, %[t2v]\n" \
+  "s_nop 1\n" \
+  "v_cndmask_b32_e64 %[t2v], %[t2v], %[t3], %[tm64]\n"
 
-// the records of a step's deferred values (see step_tail)
-__device__ __forceinline__ void write_records(uint64_t ft1, uint64_t ft2, uint32_t v, uint32_t a, uint32_t a1, uint32_t a2, uint32_t p1,
-                                              uint32_t p2, uint32_t hq1, uint32_t inc, uint32_t len, uint32_t t1abs, uint32_t sbase, Sweep& sw,
-                                              const LaneK& lk, const RecSink& sink)
-  {
-  const uint64_t hm = ft1 | ft2;
-  const bool f1 = (ft1 >> lk.lane) & 1ull, f2 = (ft2 >> lk.lane) & 1ull;
-  const uint32_t pre = inc - len;
-  const uint32_t pre_lead = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lk.lane & ~7u) << 2), (int)pre);
-  const uint32_t idx = sw.nrec + popc_below(hm);
-  if (f1 || f2)
-    {
-    u32x4 w;
-    w[0] = sw.flushed + (hq1 + 1u - sbase) + 3u;
-    w[1] = (3u + pre - pre_lead) | ((lk.lane & 7u) << 8) | ((uint32_t)f1 << 12) | ((uint32_t)f2 << 13) |
-           (((a2 - (t1abs + 64u)) >> 2) << 20);
-    w[2] = v;
-    w[3] = a;
-    uint32_t* r = sink.recs + RECW * idx;
-    *(u32x4*)r = w;
-    r[4] = f1 ? (f2 ? 0u : p2) : p1;
-    }
-  sw.nrec += (uint32_t)__popcll(hm);
-  }
+// one step: J label suffix, V its values, VP the values of the step before, LD the register the load of the step six ahead goes to.
+// Temporaries: A = v[i-1]; t0 s2 / x1 / reversed residual; t1 class before me / exchange result / FCM prediction; t2v the same
+// for DFCM; t3, t4 scratch / x2 / scan; t5 leading bytes / length; t6 leading bytes / header bits; t7 residual; t8 byte address;
+// t9 my group's header - 1.
+#define SW_QUAD_TRY(J) \
+  "s_cmp_lg_u32 %[ust], 0\n" \
+  "s_cbranch_scc1 .Lq" J "_%=\n" \
+  ".Lt" J "_%=:\n"
+#define SW_STEP(J, V, VP, LD, HOOKTXT) \
+  "buffer_load_dword " LD ", %[voff], %[inr], %[soff] offen\n" \
+  "s_add_u32 %[soff], %[soff], %[stepb]\n" \
+  "s_waitcnt vmcnt(12)\n" \
+  "s_cmp_lg_u32 %[ust], 0\n" \
+  "s_cbranch_scc1 .Lu" J "_%=\n" \
+  ".Lg" J "_%=:\n" \
+  /* classes and run starts */ \
+  "v_mov_b32_dpp %[A], " VP " wave_ror:1" SW_DPPF \
+  "v_mov_b32_dpp %[t0], %[s1p] wave_ror:1" SW_DPPF \
+  "v_mov_b32_dpp %[s1p], %[sp] wave_ror:1" SW_DPPF \
+  "v_mov_b32_dpp %[t1], %[a1p] wave_ror:1" SW_DPPF \
+  "v_mov_b32_dpp %[t2v], %[a2p] wave_ror:1" SW_DPPF \
+  "v_mov_b32_dpp %[A], " V " wave_shr:1" SW_DPPF                    /* A = v[i-1] */ \
+  "v_sub_u32 %[sp], " V ", %[A]\n"                                   /* stride of v[i] */ \
+  "v_lshrrev_b32 %[t3], 26, %[A]\n" \
+  "v_and_or_b32 %[a1p], %[t3], 60, %[t1s]\n"                         /* FCM entry: table + 4 * (top four bits of v[i-1]) */ \
+  "v_mov_b32_dpp %[s1p], %[sp] wave_shr:1" SW_DPPF                   /* stride of v[i-1] */ \
+  "s_nop 0\n" \
+  "v_mov_b32_dpp %[t1], %[a1p] wave_shr:1" SW_DPPF \
+  "v_lshrrev_b32 %[t4], 22, %[s1p]\n" \
+  "v_mov_b32_dpp %[t0], %[s1p] wave_shr:1" SW_DPPF                   /* stride of v[i-2] */ \
+  "v_cmp_ne_u32_e64 %[st1], %[a1p], %[t1]\n" \
+  "v_lshrrev_b32 %[t3], 17, %[t0]\n" \
+  "v_bitop3_b32 %[t3], %[t3], %[t4], %[k3e0] bitop3:0x6c\n"          /* ((s2 >> 17) & 0x3e0) ^ (s1 >> 22): the DFCM class */ \
+  "v_lshl_add_u32 %[a2p], %[t3], 2, %[t2s]\n" \
+  "s_waitcnt lgkmcnt(0)\n"                                           /* the staging words read at the end of the step before */ \
+  "s_cmp_lg_u32 %[pend], 0\n" \
+  "v_mov_b32_dpp %[t2v], %[a2p] wave_shr:1" SW_DPPF \
+  "v_cmp_ne_u32_e64 %[st2], %[a2p], %[t2v]\n" \
+  "s_cselect_b64 exec, -1, 0\n" \
+  SW_FLUSH_STORES \
+  /* run starts: exchange by the lanes where a run starts or ends (a run ends where the next lane starts one; lane 63 always) */ \
+  "s_lshr_b64 vcc, %[st1], 1\n" \
+  "s_bitset1_b32 vcc_hi, 31\n" \
+  "s_or_b64 exec, vcc, %[st1]\n" \
+  "ds_wrxchg_rtn_b32 %[t1], %[a1p], " V "\n" \
+  "v_cmp_eq_u32_e32 vcc, %[ksent], " V "\n" \
+  "s_or_b64 %[sent], %[sent], vcc\n" \
+  "s_lshr_b64 vcc, %[st2], 1\n" \
+  "s_bitset1_b32 vcc_hi, 31\n" \
+  "s_or_b64 exec, vcc, %[st2]\n" \
+  "ds_wrxchg_rtn_b32 %[t2v], %[a2p], %[sp]\n" \
+  "v_cmp_eq_u32_e32 vcc, %[ksent], %[sp]\n" \
+  "s_mov_b64 exec, -1\n" \
+  "s_or_b64 %[sent], %[sent], vcc\n" \
+  "s_or_b64 vcc, %[st1], %[st2]\n" \
+  "s_cselect_b32 %[cand], 0, 1\n"                                    /* no run start at all: the next step may be a uniform one */ \
+  "s_add_u32 %[tms], %[posl], %[sbase]\n" \
+  "s_sub_u32 %[tms], %[tms], 1\n"                                    /* LDS address of the first free staging byte - 1 */ \
+  "s_waitcnt lgkmcnt(0)\n" \
+  "v_cndmask_b32_e64 %[t1], %[A], %[t1], %[st1]\n"                   /* FCM prediction: inside a run the previous value */ \
+  "v_cndmask_b32_e64 %[t2v], %[s1p], %[t2v], %[st2]\n"               /* DFCM prediction: inside a run the previous stride */ \
+  "v_cmp_eq_u32_e32 vcc, %[ksent], %[t1]\n" \
+  "s_and_b64 %[ft1], vcc, %[st1]\n"                                  /* starts that met an entry nobody wrote in this segment */ \
+  "v_cmp_eq_u32_e32 vcc, %[ksent], %[t2v]\n" \
+  "s_and_b64 %[ft2], vcc, %[st2]\n" \
+  "s_or_b64 %[hole], %[ft1], %[ft2]\n" \
+  HOOKTXT \
+  /* residual selection (fpsc.c:146-189): DFCM iff its residual is shorter; byte layout; byte stores */ \
+  "v_xor_b32 %[t0], " V ", %[t1]\n" \
+  "v_add_u32 %[t3], %[A], %[t2v]\n" \
+  "v_xor_b32 %[t4], " V ", %[t3]\n" \
+  "v_ffbh_u32 %[t5], %[t0]\n" \
+  "v_ffbh_u32 %[t6], %[t4]\n" \
+  "v_min_u32 %[t5], 32, %[t5]\n" \
+  "v_bfe_u32 %[t6], %[t6], 3, 2\n"                                   /* leading zero bytes 0..3 (a DFCM residual takes at least one byte) */ \
+  "v_lshrrev_b32 %[t5], 3, %[t5]\n"                                  /* leading zero bytes 0..4 */ \
+  "v_cmp_gt_u32_e32 vcc, %[t6], %[t5]\n" \
+  "v_max_u32 %[t3], %[t5], %[t6]\n" \
+  "v_sub_u32 %[t5], 4, %[t3]\n"                                      /* length */ \
+  "v_cndmask_b32_e32 %[t7], %[t0], %[t4], vcc\n" \
+  "v_cndmask_b32_e32 %[t3], 0, %[c4sh], vcc\n"                       /* code = length, + 4 for DFCM: already at the code's place in the header */ \
+  "v_lshl_or_b32 %[t6], %[t5], %[sh3], %[t3]\n" \
+  "v_cndmask_b32_e64 %[t5], %[t5], 4, %[hole]\n"                     /* deferred values: four zero bytes, code 0 */ \
+  "v_cndmask_b32_e64 %[t6], %[t6], 0, %[hole]\n" \
+  "v_cndmask_b32_e64 %[t7], %[t7], 0, %[hole]\n" \
+  "v_perm_b32 %[t0], %[t7], %[t7], %[kswap]\n"                       /* the residual, bytes reversed */ \
+  "v_or_b32_dpp %[t6], %[t6], %[t6] quad_perm:[1,0,3,2]" SW_DPPB \
+  "v_add_u32_dpp %[t4], %[t5], %[t5] row_shr:1" SW_DPPB \
+  "v_cmp_ne_u32_e64 %[tm64], 0, %[t5]\n" \
+  "v_or_b32_dpp %[t6], %[t6], %[t6] quad_perm:[2,3,0,1]" SW_DPPB \
+  "v_add_u32_dpp %[t4], %[t4], %[t4] row_shr:2" SW_DPPB \
+  "s_nop 0\n" \
+  "v_or_b32_dpp %[t6], %[t6], %[t6] row_half_mirror" SW_DPPB \
+  "v_add_u32_dpp %[t4], %[t4], %[t4] row_shr:4" SW_DPPB \
+  "s_nop 1\n" \
+  "v_add_u32_dpp %[t4], %[t4], %[t4] row_shr:8" SW_DPPB \
+  "v_lshrrev_b32 %[t3], 8, %[t6]\n" \
+  "s_nop 0\n" \
+  "v_add_u32_dpp %[t4], %[t4], %[t4] row_bcast:15 row_mask:0xa bank_mask:0xf\n" \
+  "s_nop 1\n" \
+  "v_add_u32_dpp %[t4], %[t4], %[t4] row_bcast:31 row_mask:0xc bank_mask:0xf\n"     /* inclusive sum of the lengths */ \
+  "v_add3_u32 %[t8], %[tms], %[grp3], %[t4]\n"                       /* the four bytes that END with my residual's last byte */ \
+  "v_sub_u32 %[t9], %[t8], %[t5]\n"                                  /* my group's header - 1 (my residual begins 4 behind it) */ \
+  "v_readlane_b32 %[total], %[t4], 63\n" \
+  "s_mov_b64 exec, %[tm64]\n" \
+  "ds_write_b8 %[t8], %[t0]\n"                                       /* most significant byte first, in this order (see step_tail) */ \
+  "ds_write_b8_d16_hi %[t8], %[t7] offset:1\n" \
+  "ds_write_b8_d16_hi %[t8], %[t0] offset:2\n" \
+  "ds_write_b8 %[t8], %[t7] offset:3\n" \
+  "s_mov_b64 exec, %[lead]\n" \
+  "ds_write_b8_d16_hi %[t9], %[t6] offset:1\n"                       /* three header bytes, big-endian, by the lanes that lead a group */ \
+  "ds_write_b8 %[t9], %[t3] offset:2\n" \
+  "ds_write_b8 %[t9], %[t6] offset:3\n" \
+  "s_mov_b64 exec, -1\n" \
+  "s_add_u32 %[total], %[total], 24\n" \
+  /* records of the deferred values (fpc32_common.hpp) */ \
+  "s_cmp_eq_u64 %[hole], 0\n" \
+  "s_cbranch_scc1 .Lnr" J "_%=\n" \
+  "s_sub_u32 %[tms], %[flushed], %[sbase]\n" \
+  "s_mov_b64 vcc, %[hole]\n" \
+  "v_mov_b32_dpp %[t3], %[t9] quad_perm:[0,0,0,0]" SW_DPPF           /* the group's header - 1: from its first lane */ \
+  "v_cndmask_b32_e64 %[t4], 0, 1, %[ft1]\n" \
+  "v_cndmask_b32_e64 %[t5], 0, 2, %[ft2]\n" \
+  "v_mov_b32_dpp %[t3], %[t3] row_shr:4 row_mask:0xf bank_mask:0xa\n" \
+  "v_or_b32 %[t4], %[t4], %[t5]\n" \
+  "v_lshl_or_b32 %[t4], %[t4], 28, %[lanegi]\n" \
+  "s_add_u32 %[tms], %[tms], 4\n" \
+  "v_add3_u32 v58, %[t9], %[tms], %[t4]\n"                           /* w0: slot offset of the four bytes | gi | ft1 | ft2 */ \
+  "s_sub_u32 %[tms], %[tms], 3\n" \
+  "v_add_u32 v59, %[tms], %[t3]\n"                                   /* w1: slot offset of the group's header */ \
+  "v_mov_b32 v60, " V "\n" \
+  "v_mov_b32 v61, %[A]\n" \
+  "v_cndmask_b32_e64 %[t5], %[t2v], 0, %[ft2]\n" \
+  "v_cndmask_b32_e64 v62, %[t1], %[t5], %[ft1]\n"                    /* w4: the prediction that is known if only one is open */ \
+  "v_subrev_u32 v63, %[t2s], %[a2p]\n"                               /* w5: 4 * DFCM class */ \
+  "v_mbcnt_lo_u32_b32 %[t4], vcc_lo, 0\n" \
+  "v_mbcnt_hi_u32_b32 %[t4], vcc_hi, %[t4]\n" \
+  "v_add_lshl_u32 %[t4], %[t4], %[nrec], 5\n" \
+  "s_bcnt1_i32_b64 %[tms], %[hole]\n" \
+  "s_add_u32 %[nrec], %[nrec], %[tms]\n" \
+  "s_mov_b64 exec, %[hole]\n" \
+  "buffer_store_dwordx4 v[58:61], %[t4], %[rcr], 0 offen\n" \
+  "buffer_store_dwordx2 v[62:63], %[t4], %[rcr], 0 offen offset:16\n" \
+  "s_mov_b64 exec, -1\n" \
+  ".Lnr" J "_%=:\n" \
+  "s_cmp_lg_u32 %[cand], 0\n" \
+  "s_cbranch_scc1 .Lce" J "_%=\n" \
+  /* end of the step: bytes staged; the reads of the next step's flush; is a block full? */ \
+  ".Lend" J "_%=:\n" \
+  "s_add_u32 %[posl], %[posl], %[total]\n" \
+  "s_cmp_ge_u32 %[posl], 512\n" \
+  "s_cselect_b64 exec, -1, 0\n" \
+  "s_cselect_b32 %[pend], 1, 0\n" \
+  "s_cselect_b32 %[tms], 512, 0\n" \
+  "ds_read_b64 v[56:57], %[stw8]\n" \
+  "ds_read2st64_b32 v[54:55], %[stw] offset0:2 offset1:3\n" \
+  "s_mov_b64 exec, -1\n" \
+  "s_mov_b32 %[floff], %[flushed]\n" \
+  "s_add_u32 %[flushed], %[flushed], %[tms]\n" \
+  "s_sub_u32 %[posl], %[posl], %[tms]\n"
 
-// A constant step BEHIND a constant step of the same kind - the rows of a grid, the flat parts of a scan - needs neither classes nor
-// run starts.  After 64 exact DFCM hits (88 bytes) every stride of the step was the same S, and so was the stride before it: the
-// DFCM class of every value of the next step is f(S, S) as long as its strides are S again, the value two back is a - S, and the
-// step is another 64 hits iff  stride == S,  top four bits of a == top four bits of a - S (no FCM run start),  v ^ a >= 256  in
-// every lane: 9 vector instructions instead of 26.  After 64 exact FCM hits (24 bytes) all values were equal, all strides 0: the
-// next step is the same iff v == a in every lane.  Only vp is kept up to date in such a stretch; the step that ends it rebuilds the
-// other registers the head wants (uniform_leave).  Returns the bytes staged, 0 if the step is not one.
-__device__ __forceinline__ uint32_t step_uniform_asm(uint32_t v, uint32_t vp, uint32_t state, uint32_t S, uint32_t posl_abs, const LaneK& lk)
-  {
-  uint32_t a, t, x1, adv;
-  uint64_t m;
-  asm volatile(
-    "s_nop 1\n"
-    "v_mov_b32_dpp %[a], %[vp] wave_ror:1 row_mask:0xf bank_mask:0xf\n"
-    "s_mov_b32 %[adv], 0\n"
-    "s_cmp_eq_u32 %[state], 24\n"
-    "v_mov_b32_dpp %[a], %[v] wave_shr:1 row_mask:0xf bank_mask:0xf\n"          // a = v[i-1]
-    "v_xor_b32 %[x1], %[v], %[a]\n"
-    "s_cbranch_scc1 .Luni_zero_%=\n"
-    "v_sub_u32 %[t], %[v], %[a]\n"                                                 // stride of v[i]
-    "v_cmp_ne_u32_e64 %[m], %[S], %[t]\n"
-    "v_subrev_u32 %[t], %[S], %[a]\n"                                              // v[i-2], if the strides are what they were
-    "v_cmp_gt_u32_e32 vcc, 0x100, %[x1]\n"
-    "v_xor_b32 %[t], %[t], %[a]\n"
-    "s_or_b64 %[m], %[m], vcc\n"
-    "v_cmp_lt_u32_e32 vcc, 0xfffffff, %[t]\n"                                      // v[i-2] and v[i-1] in different FCM classes
-    "s_or_b64 %[m], %[m], vcc\n"
-    "s_cmp_lg_u64 %[m], 0\n"
-    "s_cbranch_scc1 .Luni_end_%=\n"
-    "s_mov_b64 exec, 0x3fffff\n"
-    "v_add_u32 %[t], %[posl], %[lane4]\n"
-    "s_mov_b32 %[adv], 88\n"
-    "ds_write_b32 %[t], %[pat5]\n"                                                 // (not dword aligned: gfx950 executes it)
-    "s_branch .Luni_done_%=\n"
-    ".Luni_zero_%=:\n"
-    "v_cmp_ne_u32_e32 vcc, 0, %[x1]\n"
-    "s_cmp_lg_u64 vcc, 0\n"
-    "s_cbranch_scc1 .Luni_end_%=\n"
-    "s_mov_b64 exec, 0x3f\n"
-    "v_add_u32 %[t], %[posl], %[lane4]\n"
-    "s_mov_b32 %[adv], 24\n"
-    "ds_write_b32 %[t], %[x1]\n"                                                   // (x1 is zero in every lane)
-    ".Luni_done_%=:\n"
-    "s_mov_b64 exec, -1\n"
-    ".Luni_end_%=:\n"
-    : [a] "=&v"(a), [t] "=&v"(t), [x1] "=&v"(x1), [m] "=&s"(m), [adv] "=&s"(adv)
-    : [v] "v"(v), [vp] "v"(vp), [state] "s"(state), [S] "s"(S), [posl] "s"(posl_abs), [lane4] "v"(lk.lane4), [pat5] "v"(lk.pat5)
-    : "vcc", "scc", "memory");
-  return uni(adv);
-  }
+// Four uniform steps at once (the steps J .. J + 3 of a block, J = 0 or 4, when the step before was uniform): the same tests as the
+// uniform step, for the four value registers, one verdict; 352 bytes (or 96) of pattern with two stores; the four loads of the
+// steps six ahead and four stores (one flush, three of nothing: the prefetch wait of later steps counts two memory instructions
+// per step) - about 20 instructions per step instead of 45.  Nothing is changed before the verdict: a no goes to the ordinary
+// step J.  A yes ends at the end-of-step code of step J + 3.
+#define SW_QUAD_STEP88(V, AR) \
+  "v_sub_u32 %[t3], " V ", " AR "\n"                                 /* stride */ \
+  "v_subrev_u32 %[t4], %[ustr], " AR "\n"                            /* v[i-2], if the strides are what they were */ \
+  "v_xor_b32 %[t3], %[ustr], %[t3]\n" \
+  "v_xor_b32 %[t4], %[t4], " AR "\n" \
+  "v_xor_b32 %[t6], " V ", " AR "\n" \
+  "v_and_or_b32 %[t3], %[t4], %[kf0], %[t3]\n"                       /* another stride, or v[i-2] and v[i-1] in different FCM classes */ \
+  "v_cmp_gt_u32_e32 vcc, 0x100, %[t6]\n"                            /* an FCM residual of one byte would win */ \
+  "v_or_b32 %[t5], %[t5], %[t3]\n" \
+  "s_or_b64 %[tm64], %[tm64], vcc\n"
+#define SW_QUAD(J, JE, V0, V1, V2, V3, VPREV, LD0, LD1, LD2, LD3) \
+  ".Lq" J "_%=:\n" \
+  "s_waitcnt vmcnt(2)\n" \
+  "v_mov_b32_dpp %[A], " VPREV " wave_ror:1" SW_DPPF \
+  "v_mov_b32_dpp %[t0], " V0 " wave_ror:1" SW_DPPF \
+  "v_mov_b32_dpp %[t1], " V1 " wave_ror:1" SW_DPPF \
+  "v_mov_b32_dpp %[t2v], " V2 " wave_ror:1" SW_DPPF \
+  "v_mov_b32_dpp %[A], " V0 " wave_shr:1" SW_DPPF                    /* v[i-1] of the four steps */ \
+  "v_mov_b32_dpp %[t0], " V1 " wave_shr:1" SW_DPPF \
+  "v_mov_b32_dpp %[t1], " V2 " wave_shr:1" SW_DPPF \
+  "v_mov_b32_dpp %[t2v], " V3 " wave_shr:1" SW_DPPF \
+  "s_cmp_eq_u32 %[ust], 24\n" \
+  "s_cbranch_scc1 .Lqz" J "_%=\n" \
+  "v_mov_b32 %[t5], 0\n" \
+  "s_mov_b64 %[tm64], 0\n" \
+  SW_QUAD_STEP88(V0, "%[A]") \
+  SW_QUAD_STEP88(V1, "%[t0]") \
+  SW_QUAD_STEP88(V2, "%[t1]") \
+  SW_QUAD_STEP88(V3, "%[t2v]") \
+  "v_cmp_ne_u32_e32 vcc, 0, %[t5]\n" \
+  "s_or_b64 %[tm64], %[tm64], vcc\n" \
+  "s_cmp_lg_u64 %[tm64], 0\n" \
+  "s_cbranch_scc1 .Lt" J "_%=\n" \
+  "s_mov_b32 %[total], 352\n" \
+  "s_mov_b64 %[tm64], 0xffffff\n"                                   /* dwords 64 .. 87 of the pattern */ \
+  "v_mov_b32 %[t4], %[pat5]\n" \
+  "v_mov_b32 %[t5], %[pat5b]\n" \
+  "s_branch .Lqc" J "_%=\n" \
+  ".Lqz" J "_%=:\n"                                                 /* behind exact FCM hits: every value equals the one before */ \
+  "v_xor_b32 %[t3], " V0 ", %[A]\n" \
+  "v_xor_b32 %[t4], " V1 ", %[t0]\n" \
+  "v_xor_b32 %[t5], " V2 ", %[t1]\n" \
+  "v_xor_b32 %[t6], " V3 ", %[t2v]\n" \
+  "v_or3_b32 %[t3], %[t3], %[t4], %[t5]\n" \
+  "v_or_b32 %[t4], %[t3], %[t6]\n" \
+  "v_cmp_ne_u32_e32 vcc, 0, %[t4]\n" \
+  "s_cmp_lg_u64 vcc, 0\n" \
+  "s_cbranch_scc1 .Lt" J "_%=\n" \
+  "s_mov_b32 %[total], 96\n"                                        /* 24 dwords of zero (t4 is zero in every lane) */ \
+  "s_mov_b64 %[tm64], 0\n" \
+  ".Lqc" J "_%=:\n" \
+  /* yes: what the step before left to flush, the pattern, the loads, the stores */ \
+  "s_waitcnt lgkmcnt(0)\n" \
+  "s_cmp_lg_u32 %[pend], 0\n" \
+  "s_cselect_b64 exec, -1, 0\n" \
+  SW_FLUSH_STORES \
+  "s_mov_b64 exec, -1\n" \
+  "s_cmp_eq_u32 %[total], 96\n" \
+  "s_cselect_b64 exec, 0xffffff, -1\n" \
+  "v_add_u32 %[t3], %[posl], %[stw]\n" \
+  "ds_write_b32 %[t3], %[t4]\n"                                     /* (not dword aligned: gfx950 executes it) */ \
+  "s_mov_b64 exec, %[tm64]\n" \
+  "ds_write_b32 %[t3], %[t5] offset:256\n" \
+  "s_mov_b64 exec, -1\n" \
+  "buffer_load_dword " LD0 ", %[voff], %[inr], %[soff] offen\n" \
+  "s_add_u32 %[soff], %[soff], %[stepb]\n" \
+  "buffer_load_dword " LD1 ", %[voff], %[inr], %[soff] offen\n" \
+  "s_add_u32 %[soff], %[soff], %[stepb]\n" \
+  "buffer_load_dword " LD2 ", %[voff], %[inr], %[soff] offen\n" \
+  "s_add_u32 %[soff], %[soff], %[stepb]\n" \
+  "buffer_load_dword " LD3 ", %[voff], %[inr], %[soff] offen\n" \
+  "s_add_u32 %[soff], %[soff], %[stepb]\n" \
+  "s_mov_b64 exec, 0\n" \
+  "buffer_store_dword %[t3], %[lane8], %[rcr], 0 offen\n" \
+  "buffer_store_dword %[t3], %[lane8], %[rcr], 0 offen\n" \
+  "buffer_store_dword %[t3], %[lane8], %[rcr], 0 offen\n" \
+  "s_mov_b64 exec, -1\n" \
+  "s_mov_b32 %[pend], 0\n" \
+  "s_branch .Lend" JE "_%=\n"
 
-// the registers of the previous step that such a stretch did not keep: stride, stride before it, table addresses of its last value
-__device__ __forceinline__ void uniform_leave(Sweep& sw, uint32_t t1abs)
-  {
-  const uint32_t S = sw.ustate == 88u ? sw.ustride : 0u;
-  sw.sp = S;
-  sw.s1p = S;
-  sw.a1p = ((dpp_shr1(0u, sw.vp) >> 26) & 0x3cu) | t1abs;                          // (lane 63 is the one that counts: the value before the last)
-  sw.a2p = (((((S >> 22) & 31u) << 5) ^ (S >> 22)) << 2) + (t1abs + 64u);
-  sw.ustate = 0u;
-  }
+// the out-of-line parts of step J: the uniform step, the end of a uniform stretch, the look at a general step without run starts
+#define SW_STEP_OOL(J, V, VP) \
+  ".Lu" J "_%=:\n" \
+  "s_waitcnt lgkmcnt(0)\n" \
+  "s_cmp_lg_u32 %[pend], 0\n" \
+  "s_cselect_b64 exec, -1, 0\n" \
+  SW_FLUSH_STORES \
+  "s_mov_b64 exec, -1\n" \
+  "s_mov_b32 %[pend], 0\n" \
+  "v_mov_b32_dpp %[A], " VP " wave_ror:1" SW_DPPF \
+  "s_cmp_eq_u32 %[ust], 24\n" \
+  "s_nop 0\n" \
+  "v_mov_b32_dpp %[A], " V " wave_shr:1" SW_DPPF                     /* A = v[i-1] */ \
+  "v_xor_b32 %[t0], " V ", %[A]\n" \
+  "s_cbranch_scc1 .Luz" J "_%=\n" \
+  /* behind 64 exact DFCM hits of stride S: again iff stride == S, v[i-2] = v[i-1] - S in the FCM class of v[i-1], v ^ v[i-1] >= 256 */ \
+  "v_sub_u32 %[t3], " V ", %[A]\n" \
+  "v_cmp_ne_u32_e64 %[tm64], %[ustr], %[t3]\n" \
+  "v_subrev_u32 %[t3], %[ustr], %[A]\n" \
+  "v_cmp_gt_u32_e32 vcc, 0x100, %[t0]\n" \
+  "v_xor_b32 %[t3], %[t3], %[A]\n" \
+  "s_or_b64 %[tm64], %[tm64], vcc\n" \
+  "v_cmp_lt_u32_e32 vcc, 0xfffffff, %[t3]\n" \
+  "s_or_b64 %[tm64], %[tm64], vcc\n" \
+  "s_cmp_lg_u64 %[tm64], 0\n" \
+  "s_cbranch_scc1 .Lul" J "_%=\n" \
+  "s_mov_b64 exec, 0x3fffff\n"                                       /* 88 bytes: eight times (header of eight codes 5, eight zero bytes) */ \
+  "v_add_u32 %[t3], %[posl], %[stw]\n" \
+  "s_mov_b32 %[total], 88\n" \
+  "ds_write_b32 %[t3], %[pat5]\n"                                    /* (not dword aligned: gfx950 executes it) */ \
+  "s_mov_b64 exec, -1\n" \
+  "s_branch .Lend" J "_%=\n" \
+  ".Luz" J "_%=:\n"                                                  /* behind 64 exact FCM hits: again iff every value equals the one before */ \
+  "v_cmp_ne_u32_e32 vcc, 0, %[t0]\n" \
+  "s_cmp_lg_u64 vcc, 0\n" \
+  "s_cbranch_scc1 .Lul" J "_%=\n" \
+  "s_mov_b64 exec, 0x3f\n"                                           /* 24 zero bytes (t0 is zero in every lane) */ \
+  "v_add_u32 %[t3], %[posl], %[stw]\n" \
+  "s_mov_b32 %[total], 24\n" \
+  "ds_write_b32 %[t3], %[t0]\n" \
+  "s_mov_b64 exec, -1\n" \
+  "s_branch .Lend" J "_%=\n" \
+  ".Lul" J "_%=:\n" \
+  SW_LEAVE(VP) \
+  "s_branch .Lg" J "_%=\n" \
+  /* a general step without a run start: 64 exact FCM hits (24 bytes), or 64 exact DFCM hits whose FCM residual is longer (88)? */ \
+  ".Lce" J "_%=:\n" \
+  "v_xor_b32 %[t0], " V ", %[A]\n" \
+  "v_add_u32 %[t3], %[A], %[s1p]\n" \
+  "v_cmp_ne_u32_e64 %[tm64], 0, %[t0]\n" \
+  "v_xor_b32 %[t4], " V ", %[t3]\n" \
+  "v_cmp_gt_u32_e32 vcc, 0x100, %[t0]\n" \
+  "s_cmp_eq_u64 %[tm64], 0\n" \
+  "s_cselect_b32 %[ust], 24, 0\n" \
+  "v_cmp_ne_u32_e64 %[tm64], 0, %[t4]\n" \
+  "v_readlane_b32 %[ustr], %[sp], 63\n" \
+  "s_or_b64 vcc, vcc, %[tm64]\n" \
+  "s_cmp_eq_u64 vcc, 0\n" \
+  "s_cselect_b32 %[tms], 88, 0\n" \
+  "s_or_b32 %[ust], %[ust], %[tms]\n" \
+  "s_branch .Lend" J "_%=\n"
 
-// one full step with the pieces above
+// Once per block of eight steps: my progress, everybody's; the components in front wait for the slowest (bounded), so that the component
+// waves read the same cache lines at about the same time and the interleaved array comes over HBM once, and the wave that did not
+// have to wait - the slow component - runs the next block at priority 3 (the waves of a workgroup hold their LDS until the last of
+// them is done, and the sweep ends when the slowest component does).  A wave that is done has 0xffffffff there.
+// (Measured and dropped in round 5, profiles/r05_sweep_experiments.txt: balancing the WORKGROUPS of a compute unit against the
+// hardware's oldest-first issue order - priorities by age, priorities from a table of progress per unit, sleeping while ahead of the
+// unit's slowest.  Each does what it says - with the last one every segment of the mesh takes the same time to 2 % - and none
+// changes when the kernel ends: the SIMDs issue about 1.3 instructions per 4 cycles whoever runs.)
+#define SW_PROG_READ \
+  "ds_read_b128 v[58:61], %[prog0]\n" \
+  "s_waitcnt lgkmcnt(0)\n" \
+  "v_readfirstlane_b32 %[pg0], v58\n" \
+  "v_readfirstlane_b32 %[pg1], v59\n" \
+  "v_readfirstlane_b32 %[pg2], v60\n"
+#define SW_LAG \
+  "v_mov_b32 %[t3], %[ib]\n" \
+  "s_mov_b64 exec, 1\n" \
+  "ds_write_b32 %[progc], %[t3]\n" \
+  "s_mov_b64 exec, -1\n" \
+  SW_PROG_READ \
+  "s_mov_b32 %[cand], 0\n" \
+  ".Lsp_%=:\n" \
+  "s_min_u32 %[tms], %[pg0], %[pg1]\n" \
+  "s_min_u32 %[tms], %[tms], %[pg2]\n" \
+  "s_cmp_ge_u32 %[tms], %[ib]\n"                                     /* nobody is behind me (done waves count as ahead) */ \
+  "s_cbranch_scc1 .Lgo_%=\n" \
+  "s_sleep 12\n"                                                     /* (768 cycles: the wave that is waited for needs the issue slots) */ \
+  "s_add_u32 %[cand], %[cand], 1\n" \
+  "s_cmp_lt_u32 %[cand], 4096\n" \
+  "s_cbranch_scc0 .Lgo_%=\n" \
+  SW_PROG_READ \
+  "s_branch .Lsp_%=\n" \
+  ".Lgo_%=:\n" \
+  "s_cmp_eq_u32 %[cand], 0\n" \
+  "s_cbranch_scc1 .Lp3_%=\n" \
+  "s_setprio 0\n" \
+  "s_branch .Lp_%=\n" \
+  ".Lp3_%=:\n" \
+  "s_setprio 3\n" \
+  ".Lp_%=:\n"
+
+#define SW_LOOP(HOOKTXT) \
+  "s_mov_b32 %[ust], 0\n" \
+  "s_mov_b32 %[ustr], 0\n" \
+  "s_mov_b32 %[pend], 0\n" \
+  "s_mov_b32 %[floff], 0\n" \
+  "buffer_load_dword %[c0], %[voff], %[inr], %[soff] offen\n" \
+  "s_add_u32 %[soff], %[soff], %[stepb]\n" \
+  "buffer_load_dword %[c1], %[voff], %[inr], %[soff] offen\n" \
+  "s_add_u32 %[soff], %[soff], %[stepb]\n" \
+  "buffer_load_dword %[c2], %[voff], %[inr], %[soff] offen\n" \
+  "s_add_u32 %[soff], %[soff], %[stepb]\n" \
+  "buffer_load_dword %[c3], %[voff], %[inr], %[soff] offen\n" \
+  "s_add_u32 %[soff], %[soff], %[stepb]\n" \
+  "buffer_load_dword %[c4], %[voff], %[inr], %[soff] offen\n" \
+  "s_add_u32 %[soff], %[soff], %[stepb]\n" \
+  "buffer_load_dword %[c5], %[voff], %[inr], %[soff] offen\n" \
+  "s_add_u32 %[soff], %[soff], %[stepb]\n" \
+  "s_waitcnt vmcnt(0)\n" \
+  ".Lblk_%=:\n" \
+  SW_LAG \
+  SW_QUAD_TRY("0") \
+  SW_STEP("0", "%[c0]", "%[c7]", "%[c6]", HOOKTXT) \
+  SW_STEP("1", "%[c1]", "%[c0]", "%[c7]", HOOKTXT) \
+  SW_STEP("2", "%[c2]", "%[c1]", "%[c0]", HOOKTXT) \
+  SW_STEP("3", "%[c3]", "%[c2]", "%[c1]", HOOKTXT) \
+  SW_QUAD_TRY("4") \
+  SW_STEP("4", "%[c4]", "%[c3]", "%[c2]", HOOKTXT) \
+  SW_STEP("5", "%[c5]", "%[c4]", "%[c3]", HOOKTXT) \
+  SW_STEP("6", "%[c6]", "%[c5]", "%[c4]", HOOKTXT) \
+  SW_STEP("7", "%[c7]", "%[c6]", "%[c5]", HOOKTXT) \
+  "s_add_u32 %[ib], %[ib], 512\n" \
+  "s_sub_u32 %[nblk], %[nblk], 1\n" \
+  "s_cmp_lg_u32 %[nblk], 0\n" \
+  "s_cbranch_scc1 .Lblk_%=\n" \
+  /* the end: the table and the registers as a general step leaves them, nothing left to flush, nothing in flight */ \
+  "s_cmp_eq_u32 %[ust], 0\n" \
+  "s_cbranch_scc1 .Lxg_%=\n" \
+  SW_LEAVE("%[c7]") \
+  ".Lxg_%=:\n" \
+  "s_waitcnt lgkmcnt(0)\n" \
+  "s_cmp_lg_u32 %[pend], 0\n" \
+  "s_cselect_b64 exec, -1, 0\n" \
+  SW_FLUSH_STORES \
+  "s_mov_b64 exec, -1\n" \
+  "s_waitcnt vmcnt(0) lgkmcnt(0)\n" \
+  "s_branch .Lout_%=\n" \
+  SW_QUAD("0", "3", "%[c0]", "%[c1]", "%[c2]", "%[c3]", "%[c7]", "%[c6]", "%[c7]", "%[c0]", "%[c1]") \
+  SW_QUAD("4", "7", "%[c4]", "%[c5]", "%[c6]", "%[c7]", "%[c3]", "%[c2]", "%[c3]", "%[c4]", "%[c5]") \
+  SW_STEP_OOL("0", "%[c0]", "%[c7]") \
+  SW_STEP_OOL("1", "%[c1]", "%[c0]") \
+  SW_STEP_OOL("2", "%[c2]", "%[c1]") \
+  SW_STEP_OOL("3", "%[c3]", "%[c2]") \
+  SW_STEP_OOL("4", "%[c4]", "%[c3]") \
+  SW_STEP_OOL("5", "%[c5]", "%[c4]") \
+  SW_STEP_OOL("6", "%[c6]", "%[c5]") \
+  SW_STEP_OOL("7", "%[c7]", "%[c6]") \
+  ".Lout_%=:\n"
+
+// What the loop is given besides the running state
+struct LoopK
+  {
+  u32x4 inr, slr, rcr;                            // descriptors: the input from the segment's first value on, the slot, the record list
+  uint32_t voff, stepb;                           // the lane's offset in the interleaved array, bytes of it a step covers
+  uint32_t t1abs, sbase;                          // LDS addresses of the wave's tables and of its staging area
+  uint32_t prog0, progc;                          // LDS addresses of the workgroup's progress words and of this wave's
+  };
+
+// nblk whole blocks of eight full steps, starting at value index i_begin of the stream
 template <bool HOOK>
-__device__ __forceinline__ void code_step_asm(uint32_t v, uint32_t t1abs, uint8_t* __restrict__ stage, rsrc_t slot,
-                                              Sweep& sw, const LaneK& lk, const RecSink& sink, uint32_t sabotage)
+__device__ __forceinline__ void sweep_blocks_asm(Sweep& sw, uint32_t nblk, uint32_t i_begin, const LoopK& k, const LaneK& lk, uint32_t sabotage)
   {
-  const uint32_t sbase = (uint32_t)(uintptr_t)(lds_u8*)stage;        // LDS address of the staging area (uniform)
-  flush_end(sw, stage, slot, lk);
-  if (sw.ustate)
+  uint32_t c0, c1, c2, c3, c4, c5, c6 = 0u, c7 = sw.vp;
+  uint32_t sp = sw.sp, s1p = sw.s1p, a1p = sw.a1p, a2p = sw.a2p;
+  uint32_t posl = uni(sw.posl), flushed = uni(sw.flushed), nrec = uni(sw.nrec), soff = 0u, ib = uni(i_begin);
+  uint64_t sent = uni(sw.sent);
+  nblk = uni(nblk);
+  uint32_t A, t0, t1, t2v, t3, t4, t5, t6, t7, t8, t9;
+  uint32_t ust, ustr, pend, floff, cand, total, tms, pg0, pg1, pg2, pg3;
+  uint64_t tm64, st1, st2, ft1, ft2, hole;
+  const uint32_t lane8 = 8u * lk.lane, stw = k.sbase + lk.lane4, stw8 = k.sbase + lane8, lanegi = (lk.lane & 7u) << REC_GI_SHIFT;
+  // the lane's dword of the pattern of exact DFCM hits (LaneK::pat5) 64 dwords on: four uniform steps are 88 dwords
+  uint32_t pat5b = 0;
+  for (uint32_t b = 0; b < 4u; ++b)
     {
-    const uint32_t staged = step_uniform_asm(v, sw.vp, sw.ustate, sw.ustride, sbase + sw.posl, lk);
-    if (staged)
-      {
-      sw.posl += staged;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      flush_begin(sw, stage, slot, lk);
-      sw.vp = v;
-      return;
-      }
-    uniform_leave(sw, t1abs);
+    const uint32_t q = (256u + 4u * lk.lane + b) % 11u;
+    pat5b |= (q == 0u ? 0xb6u : q == 1u ? 0xdbu : q == 2u ? 0x6du : 0u) << (8u * b);
     }
-  uint32_t a, s, s1, a1, a2, no1, no2;
-  uint64_t st1, st2;
-  step_head_asm(v, sw, t1abs, a, s, s1, a1, a2, st1, st2, no1, no2);
-  uint32_t staged = 0;
-  if (no1 & no2)
-    staged = step_const_asm(v, a, s1, sbase + sw.posl, lk);
-  if (staged)
-    {
-    sw.pend1 = sw.pend2 = 1u;
-    sw.ustate = staged;                                      // the next step may be the same again: see step_uniform_asm
-    sw.ustride = (uint32_t)__builtin_amdgcn_readlane((int)s, 63);
-    }
+  const uint64_t hk = (HOOK && sabotage) ? 0xffffffff00000000ull : 0ull;
+  // (every read-write operand is early-clobber: without the "&" the compiler may put an input that has the same value on entry -
+  // a constant 0, say - into the same register, and the loop changes it under that input's feet)
+#define SW_OPERANDS \
+    : [c0] "=&v"(c0), [c1] "=&v"(c1), [c2] "=&v"(c2), [c3] "=&v"(c3), [c4] "=&v"(c4), [c5] "=&v"(c5), [c6] "+&v"(c6), [c7] "+&v"(c7), \
+      [sp] "+&v"(sp), [s1p] "+&v"(s1p), [a1p] "+&v"(a1p), [a2p] "+&v"(a2p), \
+      [posl] "+&s"(posl), [flushed] "+&s"(flushed), [nrec] "+&s"(nrec), [soff] "+&s"(soff), [ib] "+&s"(ib), [nblk] "+&s"(nblk), [sent] "+&s"(sent), \
+      [A] "=&v"(A), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2v] "=&v"(t2v), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), \
+      [t7] "=&v"(t7), [t8] "=&v"(t8), [t9] "=&v"(t9), \
+      [ust] "=&s"(ust), [ustr] "=&s"(ustr), [pend] "=&s"(pend), [floff] "=&s"(floff), [cand] "=&s"(cand), [total] "=&s"(total), [tms] "=&s"(tms), \
+      [pg0] "=&s"(pg0), [pg1] "=&s"(pg1), [pg2] "=&s"(pg2), [pg3] "=&s"(pg3), \
+      [tm64] "=&s"(tm64), [st1] "=&s"(st1), [st2] "=&s"(st2), [ft1] "=&s"(ft1), [ft2] "=&s"(ft2), [hole] "=&s"(hole) \
+    : [voff] "v"(k.voff), [lane8] "v"(lane8), [stw] "v"(stw), [stw8] "v"(stw8), [grp3] "v"(lk.grp3), [sh3] "v"(lk.sh3), [c4sh] "v"(lk.c4sh), \
+      [lanegi] "v"(lanegi), [pat5] "v"(lk.pat5), [progc] "v"(k.progc), [prog0] "v"(k.prog0), [pat5b] "v"(pat5b), \
+      [inr] "s"(k.inr), [slr] "s"(k.slr), [rcr] "s"(k.rcr), [stepb] "s"(k.stepb), [t1s] "s"(k.t1abs), [t2s] "s"(k.t1abs + 64u), [sbase] "s"(k.sbase), \
+      [ksent] "s"(SENT), [k3e0] "s"(0x3e0u), [kswap] "s"(0x00010203u), [lead] "s"(0x0101010101010101ull), [hk] "s"(hk), [kf0] "s"(0xf0000000u) \
+    : "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "vcc", "scc", "memory"
+  if (HOOK)
+    asm volatile(SW_LOOP(SW_HOOK) SW_OPERANDS);
   else
-    {
-    uint32_t p1 = 0, p2 = s1;                                // inside a run: previous value / previous stride
-    uint64_t ft1 = 0, ft2 = 0;
-    if (no1 == 0u)
-      p1 = resolve_asm(a1, sw.a1p, v, sw.vp, a, st1, sw.pend1, ft1, sw.sent);
-    if (no2 == 0u)
-      p2 = resolve_asm(a2, sw.a2p, s, sw.sp, s1, st2, sw.pend2, ft2, sw.sent);
-    if (HOOK && sabotage)
-      {
-      // test hook (libtrico_testhooks.so only), see resolve_h
-      if (((st1 >> lk.lane) & 1ull) && lk.lane >= 32u) p1 ^= 0x100u;
-      if (((st2 >> lk.lane) & 1ull) && lk.lane >= 32u) p2 ^= 0x100u;
-      }
-    sw.pend1 = no1;                                          // (as integers: a bool that lives across blocks ends up as a lane mask)
-    sw.pend2 = no2;
-    uint32_t hq1, inc, len;
-    // (two copies of the tail: with no FCM run start, which is the rule, the FCM prediction IS the previous value - no move)
-    if (no1)
-      staged = tail_asm(v, a, a, p2, ft2, sbase + sw.posl - 1u, lk, hq1, inc, len);
-    else
-      staged = tail_asm(v, a, p1, p2, ft1 | ft2, sbase + sw.posl - 1u, lk, hq1, inc, len);
-    if (ft1 | ft2)
-      write_records(ft1, ft2, v, a, a1, a2, no1 ? a : p1, p2, hq1, inc, len, t1abs, sbase, sw, lk, sink);
-    }
-  sw.posl += staged;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  flush_begin(sw, stage, slot, lk);
-  sw.vp = v; sw.sp = s; sw.s1p = s1; sw.a1p = a1; sw.a2p = a2;
+    asm volatile(SW_LOOP("") SW_OPERANDS);
+#undef SW_OPERANDS
+  sw.vp = c7; sw.sp = sp; sw.s1p = s1p; sw.a1p = a1p; sw.a2p = a2p;
+  sw.posl = uni(posl); sw.flushed = uni(flushed); sw.nrec = uni(nrec); sw.sent = uni(sent);
+  sw.pend1 = sw.pend2 = 0u;
   }
 
 // store the bytes of staged word `w` (byte offset off inside the slot, multiple of 4) that lie below hi
@@ -768,12 +941,9 @@ __device__ __forceinline__ void sweep_begin(Sweep& sw, const uint32_t* __restric
   sw.pend1 = sw.pend2 = 0u;
   sw.posl = 0;
   sw.flushed = 0;
-  sw.fl_nb = 0;
   sw.nrec = 0;
   sw.flags = 0;
   sw.sent = 0;
-  sw.ustate = 0;
-  sw.ustride = 0;
   sw.a1p = sw.a2p = 0xfffffffeu;                       // the first value of a segment always looks at the table
   // the three values before the segment (0 before the stream: the reference starts from zeroed state, fpsc.c:104-116)
   const uint32_t m1 = i_begin >= 1u ? src[(size_t)(i_begin - 1u) * arity + c] : 0u;
@@ -794,12 +964,11 @@ __device__ __forceinline__ void sweep_begin(Sweep& sw, const uint32_t* __restric
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
 
-// what is left in the staging area (< 256 bytes) goes to the slot; returns the bytes the wave produced
-__device__ __forceinline__ uint32_t sweep_end(Sweep& sw, uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase, rsrc_t slot, const LaneK& lk)
+// what is left in the staging area (< 512 bytes) goes to the slot; returns the bytes the wave produced
+__device__ __forceinline__ uint32_t sweep_end(Sweep& sw, uint8_t* __restrict__ stage, uint8_t* __restrict__ gbase, const LaneK& lk)
   {
-  flush_end(sw, stage, slot, lk);
-  if (lk.lane4 < sw.posl)
-    store_span(gbase + sw.flushed, lk.lane4, ((const uint32_t*)stage)[lk.lane], sw.posl);
+  for (uint32_t off = lk.lane4; off < sw.posl; off += 256u)
+    store_span(gbase + sw.flushed, off, ((const uint32_t*)stage)[off >> 2], sw.posl);
   return sw.flushed + sw.posl;
   }
 
@@ -838,30 +1007,39 @@ __device__ __forceinline__ void guard_segment(const uint32_t* __restrict__ src, 
     else
       code_step<false, true, HOOK>(v, i0, seg_end, n, t1abs, stage, slot, sw, lk, sink, 0u);
     }
-  const uint32_t bytes = sweep_end(sw, stage, gbase, slot, lk);
+  const uint32_t bytes = sweep_end(sw, stage, gbase, lk);
   if (lane == 0)
     gmeta[row] = GuardMeta{ g, bytes, sw.nrec, 0u };
   }
 
-#ifndef TRICO_SWEEP_WAVES
-#define TRICO_SWEEP_WAVES 8
-#endif
+// ASM = false: every step through the compiled code_step (TRICO_FPC32_ASM=0, for A/B runs)
 template <bool HOOK, bool ASM>
-__global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(TRICO_SWEEP_WAVES, 8)))
+__global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t L, uint32_t S, uint32_t* __restrict__ outT,
               uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap, uint32_t* __restrict__ segbytes, uint32_t* __restrict__ rawbytes,
-              uint32_t* __restrict__ nrec, uint32_t* __restrict__ recs, uint32_t tune, uint32_t sabotage, uint32_t seed,
-              uint8_t* __restrict__ gslots, uint32_t* __restrict__ grecs, GuardMeta* __restrict__ gmeta)
+              uint32_t* __restrict__ nrec, uint32_t* __restrict__ recs, uint32_t sabotage, uint32_t seed,
+              uint8_t* __restrict__ gslots, uint32_t* __restrict__ grecs, GuardMeta* __restrict__ gmeta, uint64_t* __restrict__ diag)
   {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;      // (c in a scalar register)
   const uint32_t g = blockIdx.x;
+#ifdef TRICO_SWEEP_DIAG
+  const uint64_t dg_w0 = __builtin_amdgcn_s_memrealtime();
+#endif
   if (g >= S)
     {
     guard_segment<HOOK>(src, n, (uint32_t)arity, L, S, g - S, c, lane, seed, lds, gslots, grecs, gmeta);
+#ifdef TRICO_SWEEP_DIAG
+    if (lane == 0)
+      {
+      uint64_t* r = diag + 64 + ((size_t)g * arity + c) * 8;
+      r[0] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); r[1] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+      r[2] = dg_w0; r[3] = 0; r[4] = 0; r[5] = __builtin_amdgcn_s_memrealtime(); r[6] = 0; r[7] = 0;
+      }
+#endif
     return;
     }
-  volatile uint32_t* prog = lds + arity * LDSW;        // [4] progress of the component waves
+  volatile uint32_t* prog = lds + arity * LDSW;        // [4] progress of the component waves (value index; 0xffffffff: done, or no such wave)
   uint32_t* T = lds + c * LDSW;
   uint8_t* stage = (uint8_t*)(T + TAB);
   const uint32_t t1abs = (uint32_t)(uintptr_t)(lds_u8*)T;                  // LDS address of the wave's tables (a multiple of 64)
@@ -874,102 +1052,67 @@ k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t 
   const RecSink sink = { recs + rowi * RCAP * RECW };
   Sweep sw;
   sweep_begin(sw, src, n, (uint32_t)arity, c, g, i_begin, T, stage, lane);
-  // rolling prefetch: the next PF steps' values; a slot is loaded again as soon as its step begins (always PF steps in flight, never
-  // more: 320 workgroups per XCD share 4 MB of L2).  The descriptor begins at the segment and ends with the array: what a load
-  // beyond the segment fetches belongs to the next one and is not used, beyond the array it is zero.
-  const rsrc_t in = make_rsrc(src + (size_t)i_begin * arity, ((uint64_t)n - i_begin) * (uint64_t)arity * 4u);
+  // The descriptor of the input begins at the segment and ends with the array: what a load beyond the segment fetches belongs to
+  // the next one and is not used, beyond the array it is zero.
+  const uint8_t* seg_src = (const uint8_t*)(src + (size_t)i_begin * arity);
+  const uint64_t seg_bytes = ((uint64_t)n - i_begin) * (uint64_t)arity * 4u;
+  const rsrc_t in = make_rsrc(seg_src, seg_bytes);
   const uint32_t voff = (lane * (uint32_t)arity + c) * 4u;
   const uint32_t stepb = 256u * (uint32_t)arity;       // bytes of the interleaved array a step covers
-  uint32_t cur[PF];
-#pragma unroll
-  for (int pu = 0; pu < PF; ++pu)
-    cur[pu] = __builtin_amdgcn_raw_buffer_load_b32(in, voff, stepb * (uint32_t)pu, 0);
-  uint32_t soff = stepb * PF;                          // where the next load goes
-  const uint32_t lag = (tune >> 8) & 255u;             // eighths of a block a component wave may run ahead of the slowest (0 = any)
-  const bool prio = (tune & 255u) != 0u;
   if (lane == 0)
     prog[c] = i_begin;
-  if (lag)
-    __syncthreads();                                   // everybody's progress word is this workgroup's before anybody compares
-  uint32_t vlast = 0, ilast = 0xffffffffu;             // the last, partial step of the stream, if this segment has it
-  for (uint32_t ib = i_begin; ib < i_end; ib += 64u * PF)
+  if (c == 0 && lane >= (uint32_t)arity && lane < 4u)
+    prog[lane] = 0xffffffffu;
+  __syncthreads();                                     // everybody's progress word is this workgroup's before anybody compares
+#ifdef TRICO_SWEEP_DIAG
+  const uint64_t dg_t0 = __builtin_amdgcn_s_memtime(), dg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  // whole blocks of eight full steps: the hand-written loop; what is left (fewer than eight full steps and the last, partial step of
+  // a stream) goes through the compiled step
+  uint32_t i0 = i_begin;
+  if (ASM)
     {
-    if (prio)
+    const uint32_t nblk = (i_end - i_begin) / 512u;
+    if (nblk)
       {
-      // the component that is behind gets the issue slots first: the waves of a workgroup hold their LDS until the last of them
-      // is done, and the sweep ends when the slowest component does
-      if (lane == 0)
-        prog[c] = ib;
-      uint32_t ahead = 0;
-      for (int o = 0; o < arity; ++o)
-        ahead = max(ahead, (uint32_t)__builtin_amdgcn_readfirstlane((int)prog[o]) + 1u);      // (a finished wave's 0xffffffff counts as 0)
-      if (ib + 1u + 64u * PF <= ahead)
-        __builtin_amdgcn_s_setprio(3);
-      else
-        __builtin_amdgcn_s_setprio(0);
-      // ... and with a lag the ones in front wait for it (bounded), so that the component waves read the same cache lines at about
-      // the same time and the interleaved array comes over HBM once
-      for (uint32_t spin = 0; lag && spin < 4096u; ++spin)
-        {
-        uint32_t lo = 0xffffffffu;
-        for (int o = 0; o < arity; ++o)
-          lo = min(lo, (uint32_t)__builtin_amdgcn_readfirstlane((int)prog[o]));
-        if (lo == 0xffffffffu || ib <= lo + lag * 8u * PF)
-          break;
-        __builtin_amdgcn_s_sleep(12);                    // (768 cycles: the wave that is waited for needs the issue slots, not the waiting ones)
-        }
-      }
-    if (ib + 64u * PF <= i_end)
-      {
-      // eight full steps: no activity masks
-#pragma unroll
-      for (int pu = 0; pu < PF; ++pu)
-        {
-        const uint32_t vcur = cur[pu];
-        cur[pu] = __builtin_amdgcn_raw_buffer_load_b32(in, voff, soff, 0);
-        soff += stepb;
-        if (ASM)
-          code_step_asm<HOOK>(vcur, t1abs, stage, slot, sw, lk, sink, sabotage);
-        else
-          code_step<true, false, HOOK>(vcur, ib + 64u * pu, i_end, n, t1abs, stage, slot, sw, lk, sink, sabotage);
-        }
-      }
-    else
-      {
-      // the end of the segment: fewer than eight steps, nothing more to fetch
-#pragma unroll 1
-      for (int pu = 0; pu < PF; ++pu)
-        {
-        const uint32_t i0 = ib + 64u * pu;
-        if (i0 >= i_end)
-          break;
-        uint32_t vcur = cur[0];
-#pragma unroll
-        for (int q = 1; q < PF; ++q)
-          vcur = pu == q ? cur[q] : vcur;
-        if (i0 + 64u > i_end)
-          {
-          vlast = vcur;                                // (behind the loop: the step with activity masks is compiled code of its own)
-          ilast = i0;
-          break;
-          }
-        if (ASM)
-          code_step_asm<HOOK>(vcur, t1abs, stage, slot, sw, lk, sink, sabotage);
-        else
-          code_step<true, false, HOOK>(vcur, i0, i_end, n, t1abs, stage, slot, sw, lk, sink, sabotage);
-        }
+      LoopK k;
+      k.inr = make_desc(seg_src, seg_bytes);
+      k.slr = make_desc(gbase, segcap);
+      k.rcr = make_desc(sink.recs, (uint64_t)RCAP * RECW * 4u);
+      k.voff = voff;
+      k.stepb = stepb;
+      k.t1abs = t1abs;
+      k.sbase = (uint32_t)(uintptr_t)(lds_u8*)stage;
+      k.prog0 = (uint32_t)(uintptr_t)(lds_u8*)(uint32_t*)(lds + arity * LDSW);
+      k.progc = k.prog0 + 4u * c;
+      sweep_blocks_asm<HOOK>(sw, nblk, i_begin, k, lk, sabotage);
+      i0 += 512u * nblk;
       }
     }
-  if (ASM && sw.ustate)
-    uniform_leave(sw, t1abs);
-  if (ilast != 0xffffffffu)
-    {
-    // (the values beyond the stream come back as zeros, or as the next segment's: the step masks them by index)
-    code_step<false, false, HOOK>(vlast, ilast, i_end, n, t1abs, stage, slot, sw, lk, sink, sabotage);
-    }
-  const uint32_t bytes = sweep_end(sw, stage, gbase, slot, lk);
   if (lane == 0)
-    prog[c] = 0xffffffffu;                             // done: nobody is behind me any more, nobody waits for me
+    prog[c] = 0xffffffffu;                             // done with the part that takes time: nobody waits for me any more
+#ifdef TRICO_SWEEP_DIAG
+  const uint64_t dg_r1 = __builtin_amdgcn_s_memrealtime(), dg_t1 = __builtin_amdgcn_s_memtime();
+  if (g == S / 2u && lane == 0)
+    {
+    // clocks of one wave per component: shader clock and 100 MHz reference clock over the loop, steps it took
+    diag[4u * c + 0u] = dg_t1 - dg_t0;
+    diag[4u * c + 1u] = dg_r1 - dg_r0;
+    diag[4u * c + 2u] = (i0 - i_begin) / 64u;
+    diag[4u * c + 3u] = sw.nrec;
+    }
+#endif
+#pragma unroll 1
+  for (; i0 < i_end; i0 += 64u)
+    {
+    // (the values beyond the stream come back as zeros, or as the next segment's: the partial step masks them by index)
+    const uint32_t vcur = __builtin_amdgcn_raw_buffer_load_b32(in, voff, ((i0 - i_begin) >> 6) * stepb, 0);
+    if (i0 + 64u <= i_end)
+      code_step<true, false, HOOK>(vcur, i0, i_end, n, t1abs, stage, slot, sw, lk, sink, sabotage);
+    else
+      code_step<false, false, HOOK>(vcur, i0, i_end, n, t1abs, stage, slot, sw, lk, sink, sabotage);
+    }
+  const uint32_t bytes = sweep_end(sw, stage, gbase, lk);
   // what the segment leaves behind: the tables with the last value's writes applied (SENT = not written here)
   if (lane == 63u)
     {
@@ -987,6 +1130,15 @@ k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t 
     rawbytes[(size_t)c * S + g] = bytes;                 // what the slot holds
     nrec[rowi] = sw.nrec | (sw.flags << 16);
     }
+#ifdef TRICO_SWEEP_DIAG
+  if (lane == 0)
+    {
+    // per wave: where it ran (HW_ID, XCC_ID), when it started, when its loop began and ended, when it was done (100 MHz clock)
+    uint64_t* r = diag + 64 + ((size_t)g * arity + c) * 8;
+    r[0] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); r[1] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+    r[2] = dg_w0; r[3] = dg_r0; r[4] = dg_r1; r[5] = __builtin_amdgcn_s_memrealtime(); r[6] = dg_t1 - dg_t0; r[7] = sw.nrec;
+    }
+#endif
   }
 
 // ---- cross-segment scan: incoming payload of (segment, class) = the published entry of the nearest earlier segment that wrote
@@ -1064,10 +1216,10 @@ __device__ __forceinline__ void fixup_rows(int arity, uint32_t S, const uint32_t
       diff = diff || ((mine[t] ^ theirs[t]) & keep) != 0u;
       }
     const uint32_t* ra = recs + rowi * RCAP * RECW, * rb = grecs + row * RCAP * RECW;
-    for (uint32_t t = lane; t < 5u * m.nrec && !(H < m.nrec); t += 256u)
-      diff = diff || ra[RECW * (t / 5u) + t % 5u] != rb[RECW * (t / 5u) + t % 5u];
+    for (uint32_t t = lane; t < REC_CMPW * m.nrec && !(H < m.nrec); t += 256u)
+      diff = diff || ra[RECW * (t / REC_CMPW) + t % REC_CMPW] != rb[RECW * (t / REC_CMPW) + t % REC_CMPW];
     if (lane == 0 && H > m.nrec)
-      diff = diff || ra[RECW * m.nrec] < m.bytes;            // a record of the sweep inside the compared bytes that the guard does not have
+      diff = diff || (ra[RECW * m.nrec] & REC_POS) < m.bytes;      // a record of the sweep inside the compared bytes that the guard does not have
     if (diff)
       atomicOr(&nrec[rowi], FLAG_ORDER << 16);
     return;
@@ -1083,9 +1235,9 @@ __device__ __forceinline__ void fixup_rows(int arity, uint32_t S, const uint32_t
     {
     const u32x4 w = *(const u32x4*)(list + RECW * j);
     const uint32_t known = list[RECW * j + 4u];
-    const bool ft1 = (w[1] >> 12) & 1u, ft2 = (w[1] >> 13) & 1u;
+    const bool ft1 = (w[0] & REC_FT1) != 0u, ft2 = (w[0] & REC_FT2) != 0u;
     const uint32_t v = w[2], a = w[3];
-    const uint32_t k1 = a >> 28, k2 = 16u + ((w[1] >> 20) & 1023u);        // (fpsc.c:96-97: the FCM class is the predecessor's top four bits)
+    const uint32_t k1 = a >> 28, k2 = 16u + (list[RECW * j + 5u] >> 2);      // (fpsc.c:96-97: the FCM class is the predecessor's top four bits)
     const uint32_t p1 = ft1 ? row[k1] : known;
     const uint32_t p2 = ft2 ? row[k2] : known;
     const uint32_t x1 = v ^ p1, x2 = v ^ (a + p2);
@@ -1224,7 +1376,7 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
   uint32_t* rpos = &wlds[0][0];                                  // [H] the records' slot positions (the waves' buffers are idle until the setup is done)
   for (uint32_t j = tid; j < H; j += 256u)
     {
-    const uint32_t pos = list[RECW * j], hdr = pos - (list[RECW * j + 1u] & 255u), ln = list[RECW * j + 7u] & 15u;
+    const uint32_t pos = list[RECW * j] & REC_POS, hdr = list[RECW * j + 1u], ln = list[RECW * j + 7u] & 15u;
     rpos[j] = pos;
     for (uint32_t bb = ln; bb < 4u; ++bb)
       atomicAdd(&sub_out[(pos + bb) >> subshift], 1u);
@@ -1332,15 +1484,15 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
       uint32_t rj = rfirst[k];
       // The piece in hand and the loads of the next one: its 16 bytes per lane and the record each lane looks at first (a piece
       // rarely has more than 64).  A wave has nobody to cover its memory round trips here, so they are started a piece ahead.
-      struct Rec { uint32_t pos, meta, x, lc; };
+      struct Rec { uint32_t pos, hdr, gi, x, lc; };
       auto load_rec = [&](uint32_t j) -> Rec
         {
-        Rec r = { 0xffffffffu, 0u, 0u, 0u };
+        Rec r = { 0xffffffffu, 0u, 0u, 0u, 0u };
         if (j < H)
           {
-          const u32x4 w = *(const u32x4*)(list + RECW * j);
+          const u32x2 w = *(const u32x2*)(list + RECW * j);
           const uint32_t* t = list + RECW * j + 6u;
-          r.pos = w[0]; r.meta = w[1]; r.x = t[0]; r.lc = t[1];
+          r.pos = w[0] & REC_POS; r.gi = (w[0] >> REC_GI_SHIFT) & 7u; r.hdr = w[1]; r.x = t[0]; r.lc = t[1];
           }
         return r;
         };
@@ -1382,7 +1534,7 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
           {
           const uint32_t j = j0 + lane;
           const Rec r = j0 == rj0 ? r0 : load_rec(j);
-          const uint32_t ln = r.lc & 15u, hdr = r.pos - (r.meta & 255u), h24 = (r.lc >> 4) << (3u * ((r.meta >> 8) & 7u));
+          const uint32_t ln = r.lc & 15u, hdr = r.hdr, h24 = (r.lc >> 4) << (3u * r.gi);
           const bool in = j < H && hdr < pend;
           if (in)
             {
@@ -1510,7 +1662,51 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
 
 unsigned guard_workgroups(const Plan& p) { return p.S < GUARD_WGS ? p.S : GUARD_WGS; }
 
+#ifdef TRICO_HIP_TEST_HOOKS
+constexpr bool SWEEP_HOOK = true;
+#else
+constexpr bool SWEEP_HOOK = false;
+#endif
+
 } // namespace
+
+int fpc32_sweep_resident_workgroups(int arity)
+  {
+  // per device and arity: what the occupancy calculator says for this kernel with its LDS, times the compute units; one workgroup
+  // per compute unit less than that, because a launch that needs the very last place was seen to run in two rounds
+  static std::atomic<int> cache[16][4];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16)
+    dev = 0;
+  if (arity < 1) arity = 1;
+  if (arity > 3) arity = 3;
+  int have = cache[dev][arity].load();
+  if (have == 0)
+    {
+    static const int forced = [] { const char* e = getenv("TRICO_FPC32_WAVES"); return e ? atoi(e) : 0; }();      // tuning knob: waves per sweep
+    int per_cu = 0, cus = 0;
+    const size_t lds = (size_t)arity * LDSW * 4 + 16;
+    if (forced > 0)
+      have = forced / arity;
+    else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fpc32_sweep<SWEEP_HOOK, true>, 64 * arity, lds) == hipSuccess && per_cu > 0 &&
+             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+      {
+      static const int spare = [] { const char* e = getenv("TRICO_FPC32_SPARE"); return e ? atoi(e) : 1; }();
+      have = (per_cu - spare) * cus;
+      if (getenv("TRICO_HIP_DEBUG"))
+        fprintf(stderr, "trico_hip: float encoder sweep: %d workgroups of %d waves per compute unit x %d compute units (spare %d)\n", per_cu, arity, cus, spare);
+      }
+    else
+      {
+      (void)hipGetLastError();
+      have = 7680 / arity;
+      }
+    if (have < 1)
+      have = 1;
+    cache[dev][arity].store(have);
+    }
+  return have;
+  }
 
 int launch_fpc32_sweep(const uint32_t* d_src, uint32_t n, int arity, const Plan& p, uint8_t* d_ws)
   {
@@ -1526,29 +1722,55 @@ int launch_fpc32_sweep(const uint32_t* d_src, uint32_t n, int arity, const Plan&
   uint8_t* gslots = d_ws + p.off_gslots;
   uint32_t* grecs = (uint32_t*)(d_ws + p.off_grecs);
   GuardMeta* gmeta = (GuardMeta*)(d_ws + p.off_gmeta);
-  static const uint32_t tune = [] {
-    const char* e = getenv("TRICO_FPC32_PRIO"), * l = getenv("TRICO_FPC32_LAG");
-    return (e ? (uint32_t)atoi(e) & 255u : 1u) | ((l ? (uint32_t)atoi(l) & 255u : 8u) << 8);
-  }();
+#ifdef TRICO_SWEEP_DIAG
+  static uint64_t* diag = [] { void* q = nullptr; (void)hipMalloc(&q, 8 * (64 + 8192 * 3 * 8)); return (uint64_t*)q; }();
+#else
+  uint64_t* diag = (uint64_t*)(d_ws + p.off_diag);
+#endif
   static const bool use_asm = [] { const char* e = getenv("TRICO_FPC32_ASM"); return !(e && e[0] == '0'); }();      // (0: the compiled step, for A/B runs)
   static std::atomic<uint32_t> encodes{ 0 };
-  const uint32_t seed = encodes.fetch_add(1u) * 0x85EBCA6Bu;                // which segments the guard samples: another set every encode
+  const uint32_t count = encodes.fetch_add(1u);
+  const uint32_t seed = count * 0x85EBCA6Bu;                                // which segments the guard samples: another set every encode
+
   const unsigned threads = 64u * (unsigned)arity;
   const size_t lds = (size_t)arity * LDSW * 4 + 16;
   const unsigned G = guard_workgroups(p);
 #ifdef TRICO_HIP_TEST_HOOKS
   static const uint32_t sabotage = [] { const char* e = getenv("TRICO_HIP_ENCODE_SABOTAGE"); return e ? (uint32_t)atoi(e) : 0u; }();
-  constexpr bool HOOK = true;
 #else
   const uint32_t sabotage = 0u;
-  constexpr bool HOOK = false;
+#endif
+  constexpr bool HOOK = SWEEP_HOOK;
+#ifdef TRICO_SWEEP_DIAG
 #endif
   if (use_asm)
     hipLaunchKernelGGL((k_fpc32_sweep<HOOK, true>), dim3(p.S + G), dim3(threads), lds, st, d_src, n, arity, p.L, p.S, outT,
-                       slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, tune, sabotage, seed, gslots, grecs, gmeta);
+                       slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, sabotage, seed, gslots, grecs, gmeta, diag);
   else
     hipLaunchKernelGGL((k_fpc32_sweep<HOOK, false>), dim3(p.S + G), dim3(threads), lds, st, d_src, n, arity, p.L, p.S, outT,
-                       slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, tune, sabotage, seed, gslots, grecs, gmeta);
+                       slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, sabotage, seed, gslots, grecs, gmeta, diag);
+#ifdef TRICO_SWEEP_DIAG
+  {
+  // diagnostic build: clocks of the wave of segment S / 2 of every component, printed per launch; every wave's timeline to a file
+  const size_t words = 64 + (size_t)(p.S + G) * arity * 8;
+  static uint64_t* h = (uint64_t*)malloc(8 * (64 + 8192 * 3 * 8));
+  if (hipMemcpyAsync(h, diag, words * 8, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
+    {
+    for (int c = 0; c < arity; ++c)
+      fprintf(stderr, "sweep diag c%d: %llu shader clocks, %llu ticks of 100 MHz -> %.0f MHz; %llu steps in the loop = %.0f clocks per step; %llu records\n", c,
+              (unsigned long long)h[4 * c], (unsigned long long)h[4 * c + 1], h[4 * c + 1] ? 100.0 * (double)h[4 * c] / (double)h[4 * c + 1] : 0.0,
+              (unsigned long long)h[4 * c + 2], h[4 * c + 2] ? (double)h[4 * c] / (double)h[4 * c + 2] : 0.0, (unsigned long long)h[4 * c + 3]);
+    if (const char* f = getenv("TRICO_SWEEP_DIAG_FILE"))
+      if (FILE* fp = fopen(f, "wb"))
+        {
+        const uint64_t hdr[4] = { p.S, G, (uint64_t)arity, p.L };
+        fwrite(hdr, 8, 4, fp);
+        fwrite(h + 64, 8, words - 64, fp);
+        fclose(fp);
+        }
+    }
+  }
+#endif
   const unsigned colblocks = ((unsigned)arity * TAB + 255u) / 256u;
   hipLaunchKernelGGL(k_fpc32_pscan_a, dim3(colblocks, p.nch), dim3(256), 0, st, outT, p.S, arity, chlast);
   hipLaunchKernelGGL(k_fpc32_pscan_b, dim3(colblocks, p.nch), dim3(256), 0, st, outT, p.S, arity, chlast, inc);

@@ -524,6 +524,15 @@ int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int
     uint32_t raised = 0;
     for (int c = 0; c < arity; ++c)
       raised |= six[3 + c];
+#ifdef TRICO_HIP_TEST_HOOKS
+    if (raised != 0 && getenv("TRICO_HIP_ENCODE_KEEP_FLAGGED"))
+      {
+      // test hook: count the flags, keep what the one-sweep coder wrote (tools/dbg_sweep.py compares it with the oracle)
+      if (raised & FPC32_FLAG_ORDER) g_recoded_order += 1;
+      if (raised & FPC32_FLAG_SENTINEL) g_recoded_sentinel += 1;
+      raised = 0;
+      }
+#endif
     if (raised != 0)
       {
       if (raised & FPC32_FLAG_ORDER)
