@@ -22,6 +22,11 @@ other_mesh / pcie_inclusive / decode_concurrent / config3: the same step on the 
             configs[4]'s shape on one GPU (8 / 16 / 32 / 64 archives decoded as ONE batch, trico_hip_read_archives, with the hardware
             queue count unset, 1, 4 and 32), and BASELINE configs[2] (double vertices + normals + float uv, + u64 triangles so that the
             archive is the reference's golden) - N = 1 only, outside the timed region.  --quick skips them.
+Every block that is not the headline carries the reference's time beside it (`cpu_twin`, kind "reference", the sample stated):
+config3 on a tenth of its mesh with 1 thread and one thread per independent stream, the walk mesh in full, config5_mixed on meshes
+of a quarter of the vertices with one thread per stream of every archive.
+`--mode decode-mixed` is BASELINE configs[4] as the N-GPU job: rank r builds archive kind[r mod 3] of (grid, walk, multi) on its GPU
+(untimed) and decodes it K times; no collective; value = decoded bytes of all ranks / wall time.
 `python bench.py --gpus N` starts its N ranks itself (torch.distributed.run, RCCL) when no launcher did.
 """
 import argparse
@@ -122,6 +127,7 @@ def pmc_traffic(mesh, live=True):
     import tempfile
     if mesh != "grid":
         return None, None
+    failed = ""
     if live and shutil.which("rocprofv3"):
         tmp = tempfile.mkdtemp(prefix="trico_pmc_", dir="/tmp")
         try:
@@ -139,14 +145,15 @@ def pmc_traffic(mesh, live=True):
             t = _pmc_file_traffic(f)
             if t:
                 return t, "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/perf_fpc32.py grid"
-        except Exception as e:       # no profiler rights, timeout ...: say so and fall back
-            sys.stderr.write("bench.py: live PMC pass failed (%s), using the committed summary\n" % e)
+        except Exception as e:       # no profiler rights, timeout ...: say so, loudly, in the line too, and fall back
+            failed = "LIVE PMC PASS FAILED (%s): " % (repr(e)[:160])
+            sys.stderr.write("bench.py: %susing the committed summary for roofline.traffic\n" % failed)
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_fpc32_encode_hbm_traffic_pmc.txt")))
     if not files:
-        return None, None
-    return _pmc_file_traffic(files[-1]), os.path.relpath(files[-1], ROOT) + " (committed summary, not this run)"
+        return None, (failed + "no committed summary either") if failed else None
+    return _pmc_file_traffic(files[-1]), failed + os.path.relpath(files[-1], ROOT) + " (committed summary, NOT this run)"
 
 
 def encoder_variants(W, H):
@@ -160,6 +167,12 @@ def encoder_variants(W, H):
     for mesh in ("grid", "walk"):
         for coder, add in (("default", {}), ("two sweeps, exchange", {"TRICO_FPC32_SWEEPS": "2"}), ("two sweeps, ballots", {"TRICO_FPC32_XCHG": "0"})):
             env = dict(os.environ)
+            if add:
+                hooks = os.path.join(ROOT, "tests", "_build", "libtrico_testhooks.so")      # the coder switches exist in the test-hooks build only
+                if not os.path.exists(hooks):
+                    rows.append({"mesh": mesh, "coder": coder, "skipped": "tests/_build/libtrico_testhooks.so not built"})
+                    continue
+                env["TRICO_AMD_LIB"] = hooks
             env.update(add)
             try:
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "perf_fpc32.py"), mesh, str(W), str(H)], env=env, timeout=240,
@@ -192,6 +205,9 @@ def parse():
     ap.add_argument("--concurrent", default="8,16,32,64", help="archives decoded as one batch in the decode_concurrent block ('' : skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the walk mesh, PCIe-inclusive and concurrent-decode blocks")
     ap.add_argument("--quick", action="store_true", help="headline, roofline and the 1-thread CPU baseline only")
+    ap.add_argument("--mode", default="roundtrip", choices=["roundtrip", "decode-mixed"],
+                    help="'roundtrip' = the headline step (encode + gather + decode of one mesh per GPU); 'decode-mixed' = BASELINE configs[4]: rank r "
+                         "decodes an archive of kind (grid, walk, multi)[r mod 3] that it built itself, no collective, GB/s of decoded bytes")
     ap.add_argument("--shard", default="meshes", choices=["meshes", "streams"],
                     help="N > 1: 'meshes' = one mesh per GPU (BASELINE configs[3], weak scaling); 'streams' = ONE mesh, its component "
                          "streams and byte planes spread over the GPUs and assembled into one archive on rank 0 (strong scaling)")
@@ -279,6 +295,117 @@ def _reference_streams_parallel(L, v, t, raw, K=1, reps=3):
             "encode_GBps": round(tot / enc / 1e9, 4), "decode_GBps": round(tot / dec / 1e9, 4), "best_of": reps,
             "what": "%d archive(s) x 7 independent streams (x, y, z, b1..b4), one thread each calling the reference's coder; buffers "
                     "pre-faulted, threads released together" % K}
+
+
+def mesh_units(arrays):
+    """The independent units the format cuts streams into: one per component of a floating-point stream, one per byte
+    plane of an integer stream.  arrays: list of (kind, numpy array) with kind 'vec3' / 'vec2' (interleaved float32 / float64) or
+    'ints' (uint32 / uint64)."""
+    units = []
+    for kind, a in arrays:
+        if kind == "ints":
+            w = a.dtype.itemsize
+            b = a.view(np.uint8).reshape(-1, w)
+            units += [("plane", np.ascontiguousarray(b[:, k])) for k in range(w)]
+        else:
+            ar = 3 if kind == "vec3" else 2
+            m = a.reshape(-1, ar)
+            units += [("fp%d" % (8 * a.dtype.itemsize), np.ascontiguousarray(m[:, c])) for c in range(ar)]
+    return units
+
+
+def reference_units(L, units, parallel=True, reps=2, check=True):
+    """The reference's coders (trico_compress* / trico_decompress*, fpsc.c:86-417, 576-1164; LZ4_compress_default /
+    LZ4_decompress_safe of its vendored LZ4) on independent units - one thread per unit, released together, buffers touched before
+    (`parallel`), or one unit after the other on one thread.  Returns encode and decode seconds (best of `reps`)."""
+    import threading
+    libc = ctypes.CDLL(None)
+    libc.free.argtypes = [ctypes.c_void_p]
+    n_u = len(units)
+    out = [ctypes.c_void_p() for _ in range(n_u)]
+    out_len = [ctypes.c_uint32() for _ in range(n_u)]
+    back = [ctypes.c_void_p() for _ in range(n_u)]
+    back_n = [ctypes.c_uint32() for _ in range(n_u)]
+    lz = [np.empty(L.LZ4_compressBound(a.size), np.uint8) if k == "plane" else None for k, a in units]
+    lz_back = [np.empty(a.size, np.uint8) if k == "plane" else None for k, a in units]
+    lz_len = [0] * n_u
+
+    def enc(i):
+        k, a = units[i]
+        if k == "plane":
+            def work():
+                lz_len[i] = L.LZ4_compress_default(ctypes.c_void_p(a.ctypes.data), ctypes.c_void_p(lz[i].ctypes.data), a.size, lz[i].size)
+            return (lambda: lz[i].fill(0)), work
+        if k == "fp32":
+            return (lambda: None), (lambda: L.trico_compress(ctypes.byref(out_len[i]), ctypes.byref(out[i]), ctypes.c_void_p(a.ctypes.data),
+                                                             ctypes.c_uint32(a.size), ctypes.c_uint32(4), ctypes.c_uint32(10)))
+        return (lambda: None), (lambda: L.trico_compress_double_precision(ctypes.byref(out_len[i]), ctypes.byref(out[i]), ctypes.c_void_p(a.ctypes.data),
+                                                                          ctypes.c_uint32(a.size), ctypes.c_uint64(20), ctypes.c_uint64(20)))
+
+    def dec(i):
+        k, a = units[i]
+        if k == "plane":
+            return (lambda: lz_back[i].fill(0)), (lambda: L.LZ4_decompress_safe(ctypes.c_void_p(lz[i].ctypes.data), ctypes.c_void_p(lz_back[i].ctypes.data),
+                                                                                  lz_len[i], a.size))
+        f = L.trico_decompress if k == "fp32" else L.trico_decompress_double_precision
+        return (lambda: None), (lambda: f(ctypes.byref(back_n[i]), ctypes.byref(back[i]), out[i]))
+
+    def run(jobs):
+        if not parallel:
+            for pr, _ in jobs:
+                pr()
+            t0 = time.perf_counter()
+            for _, wk in jobs:
+                wk()
+            return time.perf_counter() - t0
+        gate = threading.Barrier(len(jobs) + 1)
+
+        def wrap(pr, wk):
+            def f():
+                pr()
+                gate.wait()
+                wk()
+            return f
+        th = [threading.Thread(target=wrap(pr, wk)) for pr, wk in jobs]
+        for x in th:
+            x.start()
+        gate.wait()
+        t0 = time.perf_counter()
+        for x in th:
+            x.join()
+        return time.perf_counter() - t0
+
+    best_e = best_d = None
+    for rep in range(reps):
+        e = run([enc(i) for i in range(n_u)])
+        d = run([dec(i) for i in range(n_u)])
+        if check and rep == reps - 1:
+            for i, (k, a) in enumerate(units):
+                got = lz_back[i].tobytes() if k == "plane" else ctypes.string_at(back[i].value, a.nbytes)
+                assert got == a.tobytes(), "reference round trip of unit %d" % i
+        for i, (k, _) in enumerate(units):
+            if k != "plane":
+                libc.free(out[i])
+                libc.free(back[i])
+        best_e = e if best_e is None or e < best_e else best_e
+        best_d = d if best_d is None or d < best_d else best_d
+    return best_e, best_d
+
+
+def cpu_twin(L, arrays, sample, one_thread=True):
+    """The reference on the units of `arrays` (mesh_units): one thread per unit, and - `one_thread` - all units one after the other on
+    one thread (the reference's own execution model: its API codes the components of a stream in turn, trico.c:229-260)."""
+    units = mesh_units(arrays)
+    raw = sum(a.nbytes for _, a in arrays)
+    pe, pd = reference_units(L, units, parallel=True)
+    row = {"kind": "reference", "sample": sample, "raw_bytes": raw, "nproc": os.cpu_count(),
+           "streams_parallel": {"threads": len(units), "cores": min(len(units), os.cpu_count() or 1), "encode_GBps": round(raw / pe / 1e9, 4),
+                                "decode_GBps": round(raw / pd / 1e9, 4), "value": round(raw / (pe + pd) / 1e9, 4)}}
+    if one_thread:
+        se, sd = reference_units(L, units, parallel=False, reps=1)
+        row.update({"cores": 1, "encode_GBps": round(raw / se / 1e9, 4), "decode_GBps": round(raw / sd / 1e9, 4),
+                    "value": round(raw / (se + sd) / 1e9, 4), "unit": "GB/s"})
+    return row
 
 
 def cpu_baseline(mesh, W, H, v, t, all_cores_K=()):
@@ -395,6 +522,11 @@ def extras(args, api, meshgen, dev, d_v, d_t, nv, nt, raw_bytes):
                          "value": round(raw_bytes / (e + d) / 1e9, 4), "encode_GBps": round(raw_bytes / e / 1e9, 4),
                          "decode_GBps": round(raw_bytes / d / 1e9, 4)}
     del d_ov, d_ot
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        if O.have_ref():
+            tw = cpu_baseline(other, W, H, ov, ot)                # the reference's API on one thread + one thread per stream, the whole mesh
+            out["other_mesh"]["cpu_twin"] = {k: tw[k] for k in ("kind", "sample", "cores", "value", "encode_GBps", "decode_GBps", "streams_parallel", "nproc")}
     # ---- host pointers through the plain C API (H2D of the raw arrays, D2H of archive and results included) ---------------
     hv, ht = d_v.cpu().numpy(), d_t.cpu().numpy().view(np.uint32)
     best = None
@@ -518,7 +650,7 @@ def decode_model(api, d_v, d_t, nv, nt, raw_bytes):
             "algorithmic_GBps_per_chain": {k: round(4.0 / v, 3) for k, v in ns.items()}}
 
 
-def config5_mixed(api, meshgen, dev, W, H, multi_devs, grid_dev):
+def config5_mixed(api, meshgen, dev, W, H, multi_devs, grid_dev, with_cpu=True):
     """BASELINE configs[4] on ONE GPU: eight archives of mixed content - 3 x grid (float vertices, u32 triangles), 3 x walk (the
     same types, noisy), 2 x multi (double vertices + normals, float uv, u64 triangles) - decoded as ONE batch, GB/s of decoded bytes."""
     wv, wt = meshgen.walk(W, H)
@@ -552,13 +684,46 @@ def config5_mixed(api, meshgen, dev, W, H, multi_devs, grid_dev):
     total = sum(arch[k][2] for k in order)
     for a, _, _ in arch.values():
         a.close()
+    twin = None
+    if with_cpu:
+        from oracle import oracle as O
+        if O.have_ref():
+            # the reference on the same batch, one thread per independent stream of every archive (3 x 7 + 3 x 7 + 2 x 16 = 74), on meshes of
+            # a quarter of the vertices: decode time only (the payloads are made by the same threads first)
+            sw, sh = max(16, W // 2), max(16, H // 2)
+            gv, gt = meshgen.grid(sw, sh)
+            wv2, wt2 = meshgen.walk(sw, sh)
+            mv, mn, muv, mt = meshgen.multi(sw, sh)
+            arrays = 3 * [("vec3", gv), ("ints", gt)] + 3 * [("vec3", wv2), ("ints", wt2)] + 2 * [("vec3", mv), ("vec3", mn), ("vec2", muv), ("ints", mt)]
+            units = mesh_units(arrays)
+            raw = sum(a.nbytes for _, a in arrays)
+            _, pd = reference_units(O.ref(), units, parallel=True, reps=2, check=False)
+            twin = {"kind": "reference", "sample": "the same 8 archives with meshes of %d x %d (a quarter of the vertices), %d decoded bytes" % (sw, sh, raw),
+                    "threads": len(units), "cores": min(len(units), os.cpu_count() or 1), "nproc": os.cpu_count(),
+                    "decode_GBps": round(raw / pd / 1e9, 3), "unit": "GB/s"}
     return {"workload": "8 archives decoded as one batch: 3 x grid + 3 x walk (float vertices, u32 triangles) + 2 x multi (double vertices, double "
                         "normals, float uv, u64 triangles), %d x %d each (BASELINE configs[4] on one GPU)" % (W, H),
             "decoded_bytes": total, "seconds": round(best, 3), "decode_GBps": round(total / best / 1e9, 3),
-            "chains": {"float": 3 * 6 + 2 * 2, "double": 2 * 6}, "bound": "the noisy double chains of the multi archives (decode_s of config3)"}
+            "chains": {"float": 3 * 6 + 2 * 2, "double": 2 * 6}, "bound": "the noisy double chains of the multi archives (decode_s of config3)",
+            "cpu_twin": twin}
 
 
-def config3_block(api, meshgen, dev, W, H, grid_dev=None):
+def _component_sizes(blob, ncomp_per_stream):
+    """payload sizes of the streams of an archive, in order (framing of trico.c:215-262: u8 type, u32 count, then u32 size + payload per component)"""
+    import struct
+    pos, out = 8, []
+    for nc in ncomp_per_stream:
+        pos += 5
+        sizes = []
+        for _ in range(nc):
+            nb = struct.unpack_from("<I", blob, pos)[0]
+            sizes.append(nb)
+            pos += 4 + nb
+        out.append(sizes)
+    return out
+
+
+def config3_block(api, meshgen, dev, W, H, grid_dev=None, with_cpu=True):
     """BASELINE configs[2]: double vertices + double normals + float uv (+ u64 triangles: the archive is then the reference's
     golden multi_WxH), device-resident encode and decode; sha256 against tests/golden/hashes.json."""
     v, nrm, uv, t = meshgen.multi(W, H)
@@ -569,14 +734,23 @@ def config3_block(api, meshgen, dev, W, H, grid_dev=None):
     fp_raw = v.nbytes + nrm.nbytes + uv.nbytes
     del v, nrm, uv, t
     res = None
+    L = api.lib()
+    spans = ctypes.c_uint64(0)
+    enc64_ms = None
     for rep in range(2):
         a = api.Archive.open_for_writing(raw // 3, device=True)
         torch.cuda.synchronize()
+        L.trico_hip_profile_enable(1)
+        L.trico_hip_profile_reset()
         t0 = time.perf_counter()
         for name, d, cnt in devs:
             assert a.write(name, d, cnt) == 1, api.last_error()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        ms = L.trico_hip_profile_ms(api.KERNEL_IDS["fpc64_encode"], ctypes.byref(spans))
+        L.trico_hip_profile_enable(0)
+        if spans.value:
+            enc64_ms = ms                                    # device time of the launch sequences of the two vec3 double streams together
         outs = [torch.empty_like(d) for _, d, _ in devs]
         torch.cuda.synchronize()
         t2 = time.perf_counter()
@@ -587,14 +761,39 @@ def config3_block(api, meshgen, dev, W, H, grid_dev=None):
         t3 = time.perf_counter()
         ok = all(bool(torch.equal(o, d)) for (_, d, _), o in zip(devs, outs))
         size = a.get_size()
-        sha = hashlib.sha256(a.tobytes()).hexdigest() if rep == 0 else res["sha256"]
+        if rep == 0:
+            blob = a.tobytes()
+            sha = hashlib.sha256(blob).hexdigest()
+            comp_sizes = _component_sizes(blob, [3, 3, 2, 8])
+            del blob
+        else:
+            sha = res["sha256"]
         r.close()
         a.close()
         del outs
         res = {"sha256": sha, "archive_bytes": size, "encode_s": round(t1 - t0, 4), "decode_s": round(t3 - t2, 4), "roundtrip_ok": ok}
     mixed = None
     if grid_dev is not None:
-        mixed = config5_mixed(api, meshgen, dev, W, H, devs, grid_dev)
+        mixed = config5_mixed(api, meshgen, dev, W, H, devs, grid_dev, with_cpu=with_cpu)
+    # the double encoder against the HBM roof: algorithmic bytes (raw doubles in + payload bytes out) / device time
+    roof = None
+    dbl_raw = 2 * 3 * 8 * n
+    dbl_pay = sum(comp_sizes[0]) + sum(comp_sizes[1])
+    if enc64_ms:
+        gb = (dbl_raw + dbl_pay) / (enc64_ms * 1e-3) / 1e9
+        roof = {"kernel": "double encoder (k_fpc64_sort.hip over k_sort.hip: hashes, two radix sorts, predictions, codes, scan, pack), the two vec3 "
+                          "double streams of the mesh", "bound": "hbm", "achieved": round(gb, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(gb / HBM_PEAK_GBPS, 5), "traffic": None, "algorithmic_bytes": dbl_raw + dbl_pay, "launch_ms": round(enc64_ms, 3),
+                "what_bounds_it": "about 25 passes over 12 bytes per value and table: the sorts move (hash, index) pairs, the predictions gather and scatter 8 bytes at random"}
+    twin = None
+    if with_cpu:
+        from oracle import oracle as O
+        if O.have_ref():
+            sw, sh = max(16, W // 4), max(16, (2 * H) // 5)                    # a tenth of the vertices: ~20 s of host time
+            mv, mn, muv, mt = meshgen.multi(sw, sh)
+            twin = cpu_twin(O.ref(), [("vec3", mv), ("vec3", mn), ("vec2", muv), ("ints", mt)],
+                            "multi(%d,%d): %d double vertices + double normals + float uv + u64 triangles (a tenth of the block's mesh); the units of a "
+                            "stream one after the other on one thread, and one thread per unit (6 double + 2 float components, 8 byte planes)" % (sw, sh, sw * sh))
     g = None
     hp = os.path.join(ROOT, "tests", "golden", "hashes.json")
     if os.path.exists(hp):
@@ -610,7 +809,84 @@ def config3_block(api, meshgen, dev, W, H, grid_dev=None):
             "raw_bytes": raw, "floating_point_raw_bytes": fp_raw, "archive_bytes": res["archive_bytes"], "parity": parity,
             "encode_GBps": round(raw / res["encode_s"] / 1e9, 3), "decode_GBps": round(raw / res["decode_s"] / 1e9, 3),
             "encode_s": res["encode_s"], "decode_s": res["decode_s"],
-            "value": round(raw / (res["encode_s"] + res["decode_s"]) / 1e9, 4), "config5_mixed": mixed}
+            "value": round(raw / (res["encode_s"] + res["decode_s"]) / 1e9, 4), "roofline": roof, "cpu_twin": twin, "config5_mixed": mixed}
+
+
+def decode_mixed(args, api, meshgen, dev, sync, dist, rank, world, real_stdout, host_only):
+    """BASELINE configs[4] as the N-GPU job: every rank decodes its own archive, kinds mixed over the ranks (rank r: grid, walk, multi,
+    grid, ...): float and double components, u32 and u64 index planes.  The archive is built by the rank itself before the clock
+    starts (and compared with the reference's golden where there is one); a step = open the archive, read every stream into HBM.
+    No data-path collective: ranks only meet at the barriers around the timed region."""
+    W, H = args.W, args.H
+    n = W * H
+    kind = ("grid", "walk", "multi")[rank % 3]
+    if kind == "multi":
+        v, nrm, uv, t = meshgen.multi(W, H)
+        streams = [("vertices_double", v, n), ("vertex_normals_double", nrm, n), ("uv_per_vertex", uv, n), ("triangles_long", t, 2 * n)]
+    else:
+        v, t = (meshgen.grid if kind == "grid" else meshgen.walk)(W, H)
+        streams = [("vertices", v, n), ("triangles", t, 2 * n)]
+    devs = [(name, torch.from_numpy(a.view(np.uint8)).to(dev), cnt) for name, a, cnt in streams]
+    raw = sum(a.nbytes for _, a, _ in streams)
+    a = api.Archive.open_for_writing(raw // 3, device=True)
+    for name, d, cnt in devs:
+        assert a.write(name, d, cnt) == 1, api.last_error()
+    sync()
+    sha = hashlib.sha256(a.tobytes()).hexdigest()
+    parity = "unchecked (no golden for this size)"
+    hp = os.path.join(ROOT, "tests", "golden", "hashes.json")
+    if os.path.exists(hp):
+        g = json.load(open(hp)).get("%s_%dx%d" % (kind, W, H))
+        if g is not None:
+            if g["sha256"] != sha:
+                raise SystemExit("bench.py: %s archive sha256 differs from the reference's golden on rank %d" % (kind, rank))
+            parity = "sha256 == reference golden"
+    outs = [torch.empty_like(d) for _, d, _ in devs]
+
+    def step():
+        r = api.Archive.open_for_reading(a.get_buffer_pointer(), a.get_size())
+        for (name, d, cnt), o in zip(devs, outs):
+            assert r.read(name, o) == 1, api.last_error()
+        sync()
+        r.close()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        sync()
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    if not all(bool(torch.equal(o, d)) for (_, d, _), o in zip(devs, outs)):
+        raise SystemExit("bench.py: decoded arrays differ from the input on rank %d" % rank)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    t1 = time.perf_counter()
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(raw)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        step_s = el.item() / args.steps
+        out = {"metric": "decode GB/s (output bytes), mixed archives", "value": round(tot.item() / step_s / 1e9, 4), "unit": "GB/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "u32 / u64 bit patterns",
+               "data": "synthetic" if not host_only else "synthetic; HOST REHEARSAL of the rank body (gloo, stand-in coder): not a measurement",
+               "config": {"workload": "BASELINE configs[4]: one .trc archive per GPU, kinds (grid, walk, multi)[rank mod 3] of %d x %d - float vertices + u32 "
+                                      "triangles / double vertices + double normals + float uv + u64 triangles - built on the GPU, decoded into HBM" % (W, H),
+                          "mode": "decode-mixed", "kind_rank0": kind, "decoded_bytes_all_ranks": int(tot.item()), "parity_rank0": parity,
+                          "parallelism": "1 process per GPU, %d independent archives, no collective in the timed region" % world},
+               "decode_GBps": round(tot.item() / step_s / 1e9, 4)}
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    a.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -652,6 +928,10 @@ def main():
     L = api.lib()
     if not L.trico_hip_available():
         raise SystemExit("bench.py: no HIP device: " + api.last_error())
+    if args.mode == "decode-mixed":
+        if dist is None and world > 1:
+            raise SystemExit("bench.py: no process group")
+        return decode_mixed(args, api, meshgen, dev, sync, dist, rank, world, real_stdout, host_only)
 
     W, H = args.W, args.H
     nv, nt = W * H, 2 * W * H
@@ -852,7 +1132,8 @@ def main():
             if args.mesh == "grid":
                 del d_v2, d_t2
                 torch.cuda.empty_cache()
-                out["config3"] = config3_block(api, meshgen, dev, W, H, grid_dev=[("vertices", d_v, nv), ("triangles", d_t, nt)])
+                out["config3"] = config3_block(api, meshgen, dev, W, H, grid_dev=[("vertices", d_v, nv), ("triangles", d_t, nt)],
+                                               with_cpu=not args.no_cpu_baseline)
                 out["config5_mixed"] = out["config3"].pop("config5_mixed")
                 out["encoder_variants"] = encoder_variants(W, H)
         if world == 1 and not args.no_cpu_baseline:

@@ -13,13 +13,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(shard):
+def _run(shard, mode="roundtrip", ranks=2, W=1000, H=1000):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--W", "1000", "--H", "1000", "--shard", shard, "--backend", "gloo", "--api", "tests.fake_hip_api", "--no-cpu-baseline"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "1",
+           "--W", str(W), "--H", str(H), "--shard", shard, "--mode", mode, "--backend", "gloo", "--api", "tests.fake_hip_api", "--no-cpu-baseline"]
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
@@ -39,3 +39,18 @@ def test_rank_body_world2(shard, native_libs):
     assert j["config"]["parity"] == "sha256 == reference golden", j["config"]
     golden = json.load(open(os.path.join(ROOT, "tests", "golden", "hashes.json")))["grid_1000x1000"]
     assert j["config"]["archive_bytes_rank0"] == golden["bytes"] if "bytes" in golden else True
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_decode_mixed_rank_body(ranks, native_libs):
+    """BASELINE configs[4]'s N-GPU form (bench.py --mode decode-mixed): every rank builds and decodes an archive of its own kind (rank 0
+    grid, rank 1 walk, rank 2 multi: float / double components, u32 / u64 planes), no collective; rank 0 prints one line whose decoded
+    bytes are the sum over the ranks and whose own archive is the reference's golden."""
+    W, H = 1000, 1000
+    j = _run("meshes", mode="decode-mixed", ranks=ranks, W=W, H=H)
+    assert j["n_gpus"] == ranks and j["unit"] == "GB/s" and j["value"] > 0 and j["scaling"] == "weak"
+    assert j["config"]["mode"] == "decode-mixed" and "HOST REHEARSAL" in j["data"]
+    n = W * H
+    raw = [n * 12 + 2 * n * 12, n * 12 + 2 * n * 12, 2 * n * 24 + n * 8 + 2 * n * 24]
+    assert j["config"]["decoded_bytes_all_ranks"] == sum(raw[:ranks])
+    assert j["config"]["parity_rank0"] == "sha256 == reference golden"

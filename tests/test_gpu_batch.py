@@ -267,14 +267,17 @@ def test_the_device_passes_the_lane_order_test_of_the_exchange(api):
     assert api.lib().trico_hip_fpc32_code_sweep() == 3
 
 
-@pytest.mark.parametrize("env_add", [{"TRICO_FPC32_SWEEPS": "2"}, {"TRICO_FPC32_XCHG": "0"}, {"TRICO_FPC32_PRIO": "0"},
-                                     {"TRICO_FPC32_LAG": "0"}, {"TRICO_FPC32_SWEEPS": "2", "TRICO_FPC32_PRIO": "0"}])
+@pytest.mark.parametrize("env_add", [{"TRICO_FPC32_SWEEPS": "2"}, {"TRICO_FPC32_XCHG": "0"}, {"TRICO_FPC32_ASM": "0"},
+                                     {"TRICO_FPC32_REPLAY": "4"}, {"TRICO_FPC32_SPARE": "3", "TRICO_FPC32_REPLAY": "1"}])
 def test_encoder_variants_write_the_same_bytes(env_add):
     """The other shapes of the float encoder: TRICO_FPC32_SWEEPS=2 = index sweep + code sweep with the exchange (round 3's encoder,
     kept for measurements); TRICO_FPC32_XCHG=0 = two sweeps with ballots, i.e. what a device that fails the lane-order test runs, what
     a stream is coded with again when the one-sweep coder raised a flag, and what the decoders' self-check re-encodes with;
-    TRICO_FPC32_PRIO / _LAG = how the component waves of a workgroup are kept together.  They decide time and traffic, never bytes."""
+    TRICO_FPC32_ASM=0 = the one-sweep coder with every step through the compiled code instead of the hand-written loop; _REPLAY = blocks
+    of the segment before that a wave replays into its tables first; _SPARE = workgroup places per compute unit left free.  They decide
+    time and traffic, never bytes.  The switches exist in the test-hooks build only."""
     env = dict(os.environ)
+    env["TRICO_AMD_LIB"] = os.path.join(ROOT, "tests", "_build", "libtrico_testhooks.so")
     env.update(env_add)
     out = subprocess.run([sys.executable, "-c", ENC_CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ENCODE OK" in out.stdout, out.stdout + out.stderr

@@ -89,7 +89,9 @@ print("ONESWEEP OK", len(x))
 def test_one_sweep_encoder_writes_the_reference_bytes(sweeps):
     """sweeps = 2: the same streams through round 3's encoder (index sweep + code sweep with the exchange)."""
     env = dict(os.environ)
-    env["TRICO_FPC32_SWEEPS"] = sweeps
+    if sweeps != "1":                    # (the switch exists in the test-hooks build only; "1" is the product library as it is)
+        env["TRICO_AMD_LIB"] = os.path.join(ROOT, "tests", "_build", "libtrico_testhooks.so")
+        env["TRICO_FPC32_SWEEPS"] = sweeps
     out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "mode": 3 if sweeps == "1" else 2}], env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "ONESWEEP OK" in out.stdout, out.stdout + out.stderr

@@ -1,5 +1,6 @@
 """timing experiments on the double decoder that may produce wrong values: config 3's decode seconds, no comparison"""
 import os, sys, time
+os.environ.setdefault("TRICO_AMD_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "_build", "libtrico_testhooks.so"))   # TRICO_HIP_DECODE_CHECK exists in the test-hooks build only
 os.environ["TRICO_HIP_DECODE_CHECK"] = "0"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -34,7 +34,7 @@ LIBTRICO = os.path.join(LIBDIR, "libtrico.so")
 LIBTRICO_A = os.path.join(LIBDIR, "libtrico.a")
 HOOKDIR = os.path.join(ROOT, "tests", "_build")
 LIBTRICO_HOOKS = os.path.join(HOOKDIR, "libtrico_testhooks.so")   # same library + the sabotage switches (tests only; never in lib/)
-HOOKED = ("shim.hip", "dist.hip", "k_fpc32_sweep.hip")                        # sources that look at TRICO_HIP_TEST_HOOKS
+HOOKED = ("shim.hip", "dist.hip", "k_fpc32_sweep.hip", "k_fpc32_encode.hip", "k_lz4_chunked.hip")                        # sources that look at TRICO_HIP_TEST_HOOKS
 LIBMESHGEN = os.path.join(LIBDIR, "libtrico_meshgen.so")
 LIBIO = os.path.join(LIBDIR, "libtrico_io.so")
 BINDIR = os.path.join(HERE, "bin")

@@ -1,6 +1,7 @@
 // common.hpp — internal declarations shared by the HIP translation units (gfx950 only).
 // Nothing here crosses the C-ABI; see include/trico/trico_hip.h for the exported surface.
 #pragma once
+#include <stdlib.h>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -9,6 +10,15 @@
 #include "trico/trico_hip.h"
 
 namespace trico {
+
+// Switches that exist for measurements and for the tests' A/B runs (which coder, how many waves, self-check off ...) are read in the
+// test-hooks build only (tests/_build/libtrico_testhooks.so, -DTRICO_HIP_TEST_HOOKS); the product library does not look at them.
+#ifdef TRICO_HIP_TEST_HOOKS
+inline const char* tune_env(const char* name) { return getenv(name); }
+#else
+inline const char* tune_env(const char*) { return nullptr; }
+#endif
+
 
 // ---- error plumbing -------------------------------------------------------------------------
 void set_error(const char* msg);

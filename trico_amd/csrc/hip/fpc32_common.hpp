@@ -55,7 +55,7 @@ inline Plan make_plan(uint32_t n, int arity)
   if (target > 8u * GUARD_WGS)
     target -= GUARD_WGS;
   uint64_t L = ((uint64_t)n + target - 1) / target;
-  L = (L + 127) / 128 * 128;                    // multiple of 128: two sub-ranges of whole steps in the index sweep
+  L = (L + 511) / 512 * 512;                    // whole blocks of eight steps: the hand-written loop of the sweep takes those, the compiled step the rest
   if (L < 1024) L = 1024;
   p.L = (uint32_t)L;
   p.S = (uint32_t)(((uint64_t)n + L - 1) / L);

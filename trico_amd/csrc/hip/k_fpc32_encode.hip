@@ -953,7 +953,7 @@ bool lane_order_tested()
 
 bool fpc32_xchg_usable()
   {
-  static const bool env_off = [] { const char* e = getenv("TRICO_FPC32_XCHG"); return e && e[0] == '0'; }();
+  static const bool env_off = [] { const char* e = tune_env("TRICO_FPC32_XCHG"); return e && e[0] == '0'; }();
   return !env_off && lane_order_tested();
   }
 
@@ -979,7 +979,7 @@ bool lds_lane_order_ok() { return lane_order_tested(); }
 // TRICO_FPC32_SWEEPS=2 (measurements): two sweeps, with the exchange where it is usable (2) - round 3's encoder.
 int fpc32_code_sweep_mode()
   {
-  static const int sweeps = [] { const char* e = getenv("TRICO_FPC32_SWEEPS"); return e ? atoi(e) : 1; }();
+  static const int sweeps = [] { const char* e = tune_env("TRICO_FPC32_SWEEPS"); return e ? atoi(e) : 1; }();
   if (!fpc32_xchg_usable())
     return M_BALLOT;
   return sweeps == 2 ? M_XCHG : M_SWEEP;
@@ -1017,10 +1017,7 @@ int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
     hipLaunchKernelGGL(k_fpc32_offsets, dim3(arity), dim3(1024), 0, st, segbytes, p.S, arity, segoff, d_sizes, nrec);
     return hip_ok(hipGetLastError(), "k_fpc32_offsets") ? 1 : 0;
     }
-  static const uint32_t prio_mode = [] {
-    const char* e = getenv("TRICO_FPC32_PRIO"), * l = getenv("TRICO_FPC32_LAG");
-    return (e ? (uint32_t)atoi(e) & 255u : 8u) | ((l ? (uint32_t)atoi(l) & 255u : 1u) << 8);
-  }();
+  const uint32_t prio_mode = 8u | (1u << 8);      // priority by progress, at most one block of lag between the component waves (measured in round 3)
   if (!hip_ok(hipMemsetAsync(summ, 0, p.rows * ROW * 4, st), "memset(summ)"))
     return 0;
   const size_t lds_a = ((size_t)BLOCK_V * arity + (size_t)arity * LDSW_A) * 4;

@@ -361,6 +361,26 @@ __device__ __forceinline__ void code_step(uint32_t v, uint32_t i0, uint32_t i_en
   sw.vp = v; sw.sp = s; sw.s1p = s1; sw.a1p = a1; sw.a2p = a2;
   }
 
+// Replay of one full step in front of a segment: the table writes of its 64 values, nothing else (see SW_RSTEP).  The compiled
+// form: the guard workgroups (BALLOT) and TRICO_FPC32_ASM=0.
+template <bool BALLOT>
+__device__ __forceinline__ void replay_step(uint32_t v, uint32_t t1abs, Sweep& sw, const LaneK& lk)
+  {
+  const uint32_t a = shr1_across(sw.vp, v);
+  const uint32_t s = v - a;
+  const uint32_t s1 = shr1_across(sw.sp, s);
+  const uint32_t s2 = shr1_across(sw.s1p, s1);
+  const uint32_t a1 = ((a >> 26) & 0x3cu) | t1abs;
+  const uint32_t a2 = (((((s2 >> 22) & 31u) << 5) ^ (s1 >> 22)) << 2) + (t1abs + 64u);
+  const bool st1 = a1 != shr1_across(sw.a1p, a1);
+  const bool st2 = a2 != shr1_across(sw.a2p, a2);
+  uint32_t p1 = a, p2 = s1;
+  bool ft1 = false, ft2 = false;
+  // (both predictors every time: a step without a run start writes its last value's entries, nothing stays pending)
+  resolve_h<true, true, true, BALLOT, false>(a1, a2, st1, st2, true, v, s, p1, p2, ft1, ft2, t1abs, sw, lk, 0u);
+  sw.vp = v; sw.sp = s; sw.s1p = s1; sw.a1p = a1; sw.a2p = a2;
+  }
+
 __device__ __forceinline__ LaneK lane_constants(uint32_t lane)
   {
   LaneK lk;
@@ -703,6 +723,54 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   "s_mov_b32 %[pend], 0\n" \
   "s_branch .Lend" JE "_%=\n"
 
+// Replay: in front of its segment a wave runs over the last blocks of the segment before - classes, run starts and the exchange on the
+// tables, no coding - so that a class written there has its true entry when the segment begins and its first value in the segment
+// is not deferred.  (An entry comes from the latest earlier value of its class: if that one lies in the window, replaying the
+// window gives exactly it; a class nobody wrote in the window stays "never written" and is deferred as before.  The table the
+// segment publishes then also holds what the window wrote, which is still the latest payload of those classes at the segment's
+// end.)  On the benchmark mesh 32 steps in front of 342 halve the deferred values of the noisy component (393 -> 180 per
+// segment), and with them the fix-up and the slow path of the gather.  The loads keep the rhythm of the main loop (a store of
+// nothing stands for its flush store).
+#define SW_RSTEP(V, VP, LD) \
+  "buffer_load_dword " LD ", %[voff], %[inr], %[soff] offen\n" \
+  "s_add_u32 %[soff], %[soff], %[stepb]\n" \
+  "s_waitcnt vmcnt(12) lgkmcnt(0)\n" \
+  "v_mov_b32_dpp %[A], " VP " wave_ror:1" SW_DPPF \
+  "v_mov_b32_dpp %[t0], %[s1p] wave_ror:1" SW_DPPF \
+  "v_mov_b32_dpp %[s1p], %[sp] wave_ror:1" SW_DPPF \
+  "v_mov_b32_dpp %[t1], %[a1p] wave_ror:1" SW_DPPF \
+  "v_mov_b32_dpp %[t2v], %[a2p] wave_ror:1" SW_DPPF \
+  "v_mov_b32_dpp %[A], " V " wave_shr:1" SW_DPPF \
+  "v_sub_u32 %[sp], " V ", %[A]\n" \
+  "v_lshrrev_b32 %[t3], 26, %[A]\n" \
+  "v_and_or_b32 %[a1p], %[t3], 60, %[t1s]\n" \
+  "v_mov_b32_dpp %[s1p], %[sp] wave_shr:1" SW_DPPF \
+  "s_nop 0\n" \
+  "v_mov_b32_dpp %[t1], %[a1p] wave_shr:1" SW_DPPF \
+  "v_lshrrev_b32 %[t4], 22, %[s1p]\n" \
+  "v_mov_b32_dpp %[t0], %[s1p] wave_shr:1" SW_DPPF \
+  "v_cmp_ne_u32_e64 %[st1], %[a1p], %[t1]\n" \
+  "v_lshrrev_b32 %[t3], 17, %[t0]\n" \
+  "v_bitop3_b32 %[t3], %[t3], %[t4], %[k3e0] bitop3:0x6c\n" \
+  "v_lshl_add_u32 %[a2p], %[t3], 2, %[t2s]\n" \
+  "s_lshr_b64 vcc, %[st1], 1\n" \
+  "s_bitset1_b32 vcc_hi, 31\n" \
+  "v_mov_b32_dpp %[t2v], %[a2p] wave_shr:1" SW_DPPF \
+  "v_cmp_ne_u32_e64 %[st2], %[a2p], %[t2v]\n" \
+  "s_or_b64 exec, vcc, %[st1]\n" \
+  "ds_wrxchg_rtn_b32 %[t8], %[a1p], " V "\n" \
+  "v_cmp_eq_u32_e32 vcc, %[ksent], " V "\n" \
+  "s_or_b64 %[sent], %[sent], vcc\n" \
+  "s_lshr_b64 vcc, %[st2], 1\n" \
+  "s_bitset1_b32 vcc_hi, 31\n" \
+  "s_or_b64 exec, vcc, %[st2]\n" \
+  "ds_wrxchg_rtn_b32 %[t9], %[a2p], %[sp]\n" \
+  "v_cmp_eq_u32_e32 vcc, %[ksent], %[sp]\n" \
+  "s_mov_b64 exec, 0\n" \
+  "buffer_store_dword %[t3], %[lane8], %[rcr], 0 offen\n" \
+  "s_mov_b64 exec, -1\n" \
+  "s_or_b64 %[sent], %[sent], vcc\n"
+
 // the out-of-line parts of step J: the uniform step, the end of a uniform stretch, the look at a general step without run starts
 #define SW_STEP_OOL(J, V, VP) \
   ".Lu" J "_%=:\n" \
@@ -824,6 +892,21 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   "buffer_load_dword %[c5], %[voff], %[inr], %[soff] offen\n" \
   "s_add_u32 %[soff], %[soff], %[stepb]\n" \
   "s_waitcnt vmcnt(0)\n" \
+  "s_cmp_eq_u32 %[nrb], 0\n" \
+  "s_cbranch_scc1 .Lblk_%=\n" \
+  ".Lrb_%=:\n" \
+  SW_RSTEP("%[c0]", "%[c7]", "%[c6]") \
+  SW_RSTEP("%[c1]", "%[c0]", "%[c7]") \
+  SW_RSTEP("%[c2]", "%[c1]", "%[c0]") \
+  SW_RSTEP("%[c3]", "%[c2]", "%[c1]") \
+  SW_RSTEP("%[c4]", "%[c3]", "%[c2]") \
+  SW_RSTEP("%[c5]", "%[c4]", "%[c3]") \
+  SW_RSTEP("%[c6]", "%[c5]", "%[c4]") \
+  SW_RSTEP("%[c7]", "%[c6]", "%[c5]") \
+  "s_sub_u32 %[nrb], %[nrb], 1\n" \
+  "s_cmp_lg_u32 %[nrb], 0\n" \
+  "s_cbranch_scc1 .Lrb_%=\n" \
+  "s_waitcnt lgkmcnt(0)\n" \
   ".Lblk_%=:\n" \
   SW_LAG \
   SW_QUAD_TRY("0") \
@@ -875,8 +958,9 @@ struct LoopK
 
 // nblk whole blocks of eight full steps, starting at value index i_begin of the stream
 template <bool HOOK>
-__device__ __forceinline__ void sweep_blocks_asm(Sweep& sw, uint32_t nblk, uint32_t i_begin, const LoopK& k, const LaneK& lk, uint32_t sabotage)
+__device__ __forceinline__ void sweep_blocks_asm(Sweep& sw, uint32_t nrb, uint32_t nblk, uint32_t i_begin, const LoopK& k, const LaneK& lk, uint32_t sabotage)
   {
+  nrb = uni(nrb);
   uint32_t c0, c1, c2, c3, c4, c5, c6 = 0u, c7 = sw.vp;
   uint32_t sp = sw.sp, s1p = sw.s1p, a1p = sw.a1p, a2p = sw.a2p;
   uint32_t posl = uni(sw.posl), flushed = uni(sw.flushed), nrec = uni(sw.nrec), soff = 0u, ib = uni(i_begin);
@@ -899,7 +983,7 @@ __device__ __forceinline__ void sweep_blocks_asm(Sweep& sw, uint32_t nblk, uint3
 #define SW_OPERANDS \
     : [c0] "=&v"(c0), [c1] "=&v"(c1), [c2] "=&v"(c2), [c3] "=&v"(c3), [c4] "=&v"(c4), [c5] "=&v"(c5), [c6] "+&v"(c6), [c7] "+&v"(c7), \
       [sp] "+&v"(sp), [s1p] "+&v"(s1p), [a1p] "+&v"(a1p), [a2p] "+&v"(a2p), \
-      [posl] "+&s"(posl), [flushed] "+&s"(flushed), [nrec] "+&s"(nrec), [soff] "+&s"(soff), [ib] "+&s"(ib), [nblk] "+&s"(nblk), [sent] "+&s"(sent), \
+      [posl] "+&s"(posl), [flushed] "+&s"(flushed), [nrec] "+&s"(nrec), [soff] "+&s"(soff), [ib] "+&s"(ib), [nblk] "+&s"(nblk), [nrb] "+&s"(nrb), [sent] "+&s"(sent), \
       [A] "=&v"(A), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2v] "=&v"(t2v), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), \
       [t7] "=&v"(t7), [t8] "=&v"(t8), [t9] "=&v"(t9), \
       [ust] "=&s"(ust), [ustr] "=&s"(ustr), [pend] "=&s"(pend), [floff] "=&s"(floff), [cand] "=&s"(cand), [total] "=&s"(total), [tms] "=&s"(tms), \
@@ -981,7 +1065,7 @@ struct GuardMeta { uint32_t seg, bytes, nrec, pad; };
 template <bool HOOK>
 __device__ __forceinline__ void guard_segment(const uint32_t* __restrict__ src, uint32_t n, uint32_t arity, uint32_t L, uint32_t S, uint32_t j,
                                               uint32_t c, uint32_t lane, uint32_t seed, uint32_t* __restrict__ lds, uint8_t* __restrict__ gslots,
-                                              uint32_t* __restrict__ grecs, GuardMeta* __restrict__ gmeta)
+                                              uint32_t* __restrict__ grecs, GuardMeta* __restrict__ gmeta, uint32_t rblocks)
   {
   const uint32_t g = (uint32_t)(((uint64_t)j * 0x9E3779B1ull + seed) % S);        // which segment: from a counter of the encodes
   uint32_t* T = lds + c * LDSW;
@@ -996,7 +1080,11 @@ __device__ __forceinline__ void guard_segment(const uint32_t* __restrict__ src, 
   const rsrc_t slot = make_rsrc(gbase, GUARD_CAP);
   const RecSink sink = { grecs + row * RCAP * RECW };
   Sweep sw;
-  sweep_begin(sw, src, n, arity, c, g, i_begin, T, stage, lane);
+  const uint32_t ws = i_begin - 512u * (i_begin / 512u < rblocks ? i_begin / 512u : rblocks);      // the window the sweep replays in front of the segment
+  sweep_begin(sw, src, n, arity, c, g, ws, T, stage, lane);
+#pragma unroll 1
+  for (uint32_t i0 = ws; i0 < i_begin; i0 += 64u)
+    replay_step<true>(src[(size_t)(i0 + lane) * arity + c], t1abs, sw, lk);
 #pragma unroll 1
   for (uint32_t i0 = i_begin; i0 < i_end; i0 += 64u)
     {
@@ -1018,7 +1106,8 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
 k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t L, uint32_t S, uint32_t* __restrict__ outT,
               uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap, uint32_t* __restrict__ segbytes, uint32_t* __restrict__ rawbytes,
               uint32_t* __restrict__ nrec, uint32_t* __restrict__ recs, uint32_t sabotage, uint32_t seed,
-              uint8_t* __restrict__ gslots, uint32_t* __restrict__ grecs, GuardMeta* __restrict__ gmeta, uint64_t* __restrict__ diag)
+              uint8_t* __restrict__ gslots, uint32_t* __restrict__ grecs, GuardMeta* __restrict__ gmeta, uint64_t* __restrict__ diag,
+              uint32_t rblocks)
   {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;      // (c in a scalar register)
@@ -1028,7 +1117,7 @@ k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t 
 #endif
   if (g >= S)
     {
-    guard_segment<HOOK>(src, n, (uint32_t)arity, L, S, g - S, c, lane, seed, lds, gslots, grecs, gmeta);
+    guard_segment<HOOK>(src, n, (uint32_t)arity, L, S, g - S, c, lane, seed, lds, gslots, grecs, gmeta, rblocks);
 #ifdef TRICO_SWEEP_DIAG
     if (lane == 0)
       {
@@ -1051,11 +1140,14 @@ k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t 
   const size_t rowi = (size_t)g * arity + c;
   const RecSink sink = { recs + rowi * RCAP * RECW };
   Sweep sw;
-  sweep_begin(sw, src, n, (uint32_t)arity, c, g, i_begin, T, stage, lane);
-  // The descriptor of the input begins at the segment and ends with the array: what a load beyond the segment fetches belongs to
+  // the blocks of the segment before that are replayed (SW_RSTEP): the wave starts there, with empty tables
+  const uint32_t rblk = i_begin / 512u < rblocks ? i_begin / 512u : rblocks;
+  const uint32_t ws = i_begin - 512u * rblk;
+  sweep_begin(sw, src, n, (uint32_t)arity, c, g, ws, T, stage, lane);
+  // The descriptor of the input begins at the window and ends with the array: what a load beyond the segment fetches belongs to
   // the next one and is not used, beyond the array it is zero.
-  const uint8_t* seg_src = (const uint8_t*)(src + (size_t)i_begin * arity);
-  const uint64_t seg_bytes = ((uint64_t)n - i_begin) * (uint64_t)arity * 4u;
+  const uint8_t* seg_src = (const uint8_t*)(src + (size_t)ws * arity);
+  const uint64_t seg_bytes = ((uint64_t)n - ws) * (uint64_t)arity * 4u;
   const rsrc_t in = make_rsrc(seg_src, seg_bytes);
   const uint32_t voff = (lane * (uint32_t)arity + c) * 4u;
   const uint32_t stepb = 256u * (uint32_t)arity;       // bytes of the interleaved array a step covers
@@ -1070,10 +1162,15 @@ k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t 
   // whole blocks of eight full steps: the hand-written loop; what is left (fewer than eight full steps and the last, partial step of
   // a stream) goes through the compiled step
   uint32_t i0 = i_begin;
-  if (ASM)
+  const uint32_t nblk = ASM ? (i_end - i_begin) / 512u : 0u;
+  if (nblk == 0u)
     {
-    const uint32_t nblk = (i_end - i_begin) / 512u;
-    if (nblk)
+#pragma unroll 1
+    for (uint32_t r0 = ws; r0 < i_begin; r0 += 64u)
+      replay_step<false>(__builtin_amdgcn_raw_buffer_load_b32(in, voff, ((r0 - ws) >> 6) * stepb, 0), t1abs, sw, lk);
+    }
+  else
+    {
       {
       LoopK k;
       k.inr = make_desc(seg_src, seg_bytes);
@@ -1085,7 +1182,7 @@ k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t 
       k.sbase = (uint32_t)(uintptr_t)(lds_u8*)stage;
       k.prog0 = (uint32_t)(uintptr_t)(lds_u8*)(uint32_t*)(lds + arity * LDSW);
       k.progc = k.prog0 + 4u * c;
-      sweep_blocks_asm<HOOK>(sw, nblk, i_begin, k, lk, sabotage);
+      sweep_blocks_asm<HOOK>(sw, rblk, nblk, i_begin, k, lk, sabotage);
       i0 += 512u * nblk;
       }
     }
@@ -1106,7 +1203,7 @@ k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t 
   for (; i0 < i_end; i0 += 64u)
     {
     // (the values beyond the stream come back as zeros, or as the next segment's: the partial step masks them by index)
-    const uint32_t vcur = __builtin_amdgcn_raw_buffer_load_b32(in, voff, ((i0 - i_begin) >> 6) * stepb, 0);
+    const uint32_t vcur = __builtin_amdgcn_raw_buffer_load_b32(in, voff, ((i0 - ws) >> 6) * stepb, 0);
     if (i0 + 64u <= i_end)
       code_step<true, false, HOOK>(vcur, i0, i_end, n, t1abs, stage, slot, sw, lk, sink, sabotage);
     else
@@ -1683,7 +1780,7 @@ int fpc32_sweep_resident_workgroups(int arity)
   int have = cache[dev][arity].load();
   if (have == 0)
     {
-    static const int forced = [] { const char* e = getenv("TRICO_FPC32_WAVES"); return e ? atoi(e) : 0; }();      // tuning knob: waves per sweep
+    static const int forced = [] { const char* e = tune_env("TRICO_FPC32_WAVES"); return e ? atoi(e) : 0; }();      // tuning knob: waves per sweep
     int per_cu = 0, cus = 0;
     const size_t lds = (size_t)arity * LDSW * 4 + 16;
     if (forced > 0)
@@ -1691,7 +1788,7 @@ int fpc32_sweep_resident_workgroups(int arity)
     else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fpc32_sweep<SWEEP_HOOK, true>, 64 * arity, lds) == hipSuccess && per_cu > 0 &&
              hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
       {
-      static const int spare = [] { const char* e = getenv("TRICO_FPC32_SPARE"); return e ? atoi(e) : 1; }();
+      static const int spare = [] { const char* e = tune_env("TRICO_FPC32_SPARE"); return e ? atoi(e) : 1; }();
       have = (per_cu - spare) * cus;
       if (getenv("TRICO_HIP_DEBUG"))
         fprintf(stderr, "trico_hip: float encoder sweep: %d workgroups of %d waves per compute unit x %d compute units (spare %d)\n", per_cu, arity, cus, spare);
@@ -1727,7 +1824,8 @@ int launch_fpc32_sweep(const uint32_t* d_src, uint32_t n, int arity, const Plan&
 #else
   uint64_t* diag = (uint64_t*)(d_ws + p.off_diag);
 #endif
-  static const bool use_asm = [] { const char* e = getenv("TRICO_FPC32_ASM"); return !(e && e[0] == '0'); }();      // (0: the compiled step, for A/B runs)
+  static const uint32_t rblocks = [] { const char* e = tune_env("TRICO_FPC32_REPLAY"); return e ? (uint32_t)atoi(e) : 0u; }();     // blocks of 8 steps replayed in front of a segment (SW_RSTEP; 0: measured, not worth it with this gather)
+  static const bool use_asm = [] { const char* e = tune_env("TRICO_FPC32_ASM"); return !(e && e[0] == '0'); }();      // (0: the compiled step, for A/B runs)
   static std::atomic<uint32_t> encodes{ 0 };
   const uint32_t count = encodes.fetch_add(1u);
   const uint32_t seed = count * 0x85EBCA6Bu;                                // which segments the guard samples: another set every encode
@@ -1745,10 +1843,10 @@ int launch_fpc32_sweep(const uint32_t* d_src, uint32_t n, int arity, const Plan&
 #endif
   if (use_asm)
     hipLaunchKernelGGL((k_fpc32_sweep<HOOK, true>), dim3(p.S + G), dim3(threads), lds, st, d_src, n, arity, p.L, p.S, outT,
-                       slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, sabotage, seed, gslots, grecs, gmeta, diag);
+                       slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, sabotage, seed, gslots, grecs, gmeta, diag, rblocks);
   else
     hipLaunchKernelGGL((k_fpc32_sweep<HOOK, false>), dim3(p.S + G), dim3(threads), lds, st, d_src, n, arity, p.L, p.S, outT,
-                       slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, sabotage, seed, gslots, grecs, gmeta, diag);
+                       slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, sabotage, seed, gslots, grecs, gmeta, diag, rblocks);
 #ifdef TRICO_SWEEP_DIAG
   {
   // diagnostic build: clocks of the wave of segment S / 2 of every component, printed per launch; every wave's timeline to a file

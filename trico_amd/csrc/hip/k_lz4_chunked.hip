@@ -985,7 +985,7 @@ __global__ void __launch_bounds__(EMIT_T) k_lz4_bigcopy(const uint8_t* __restric
 // instruction in lane order (the float encoder's test, k_fpc32_encode.hip); TRICO_LZ4_XCHG=0 keeps the scoreboard + ballot rounds
 static bool lz4_use_xchg()
   {
-  static const bool off = [] { const char* e = getenv("TRICO_LZ4_XCHG"); return e && e[0] == '0'; }();
+  static const bool off = [] { const char* e = tune_env("TRICO_LZ4_XCHG"); return e && e[0] == '0'; }();
   return !off && lds_lane_order_ok();
   }
 

@@ -596,7 +596,7 @@ namespace trico {
 
 bool decode_check_enabled()
   {
-  static const bool on = [] { const char* e = getenv("TRICO_HIP_DECODE_CHECK"); return !(e && e[0] == '0'); }();
+  static const bool on = [] { const char* e = tune_env("TRICO_HIP_DECODE_CHECK"); return !(e && e[0] == '0'); }();
   return on;
   }
 
