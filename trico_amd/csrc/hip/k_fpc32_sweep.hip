@@ -434,7 +434,8 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
 // what the previous step left to flush: block to the slot, tail to the front (exec = pend ? all : none)
 #define SW_FLUSH_STORES \
   "buffer_store_dwordx2 v[56:57], %[lane8], %[slr], %[floff] offen nt\n" \
-  "ds_write2st64_b32 %[stw], v54, v55 offset1:1\n"
+  "ds_write2st64_b32 %[stw], v54, v55 offset1:1\n" \
+  "s_mov_b32 %[pend], 0\n"
 
 // a stretch of uniform steps ends (or the loop does): the registers of its last step that were not kept - stride, stride before it,
 // table addresses - and the table writes of its last value (lane 63), which are the only ones of the stretch that last
@@ -493,17 +494,17 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   "s_cbranch_scc1 .Lu" J "_%=\n" \
   ".Lg" J "_%=:\n" \
   /* classes and run starts */ \
-  "v_mov_b32_dpp %[A], " VP " wave_ror:1" SW_DPPF \
+  "v_mov_b32_dpp v61, " VP " wave_ror:1" SW_DPPF \
   "v_mov_b32_dpp %[t0], %[s1p] wave_ror:1" SW_DPPF \
   "v_mov_b32_dpp %[s1p], %[sp] wave_ror:1" SW_DPPF \
   "v_mov_b32_dpp %[t1], %[a1p] wave_ror:1" SW_DPPF \
   "v_mov_b32_dpp %[t2v], %[a2p] wave_ror:1" SW_DPPF \
-  "v_mov_b32_dpp %[A], " V " wave_shr:1" SW_DPPF                    /* A = v[i-1] */ \
-  "v_sub_u32 %[sp], " V ", %[A]\n"                                   /* stride of v[i] */ \
-  "v_lshrrev_b32 %[t3], 26, %[A]\n" \
+  "v_mov_b32_dpp v61, " V " wave_shr:1" SW_DPPF                    /* A = v[i-1] */ \
+  "v_sub_u32 %[sp], " V ", v61\n"                                   /* stride of v[i] */ \
+  "v_lshrrev_b32 %[t3], 26, v61\n" \
   "v_and_or_b32 %[a1p], %[t3], 60, %[t1s]\n"                         /* FCM entry: table + 4 * (top four bits of v[i-1]) */ \
   "v_mov_b32_dpp %[s1p], %[sp] wave_shr:1" SW_DPPF                   /* stride of v[i-1] */ \
-  "s_nop 0\n" \
+  "s_waitcnt lgkmcnt(0)\n"                                           /* the staging words read at the end of the step before (also a wait state of the next move) */ \
   "v_mov_b32_dpp %[t1], %[a1p] wave_shr:1" SW_DPPF \
   "v_lshrrev_b32 %[t4], 22, %[s1p]\n" \
   "v_mov_b32_dpp %[t0], %[s1p] wave_shr:1" SW_DPPF                   /* stride of v[i-2] */ \
@@ -511,14 +512,13 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   "v_lshrrev_b32 %[t3], 17, %[t0]\n" \
   "v_bitop3_b32 %[t3], %[t3], %[t4], %[k3e0] bitop3:0x6c\n"          /* ((s2 >> 17) & 0x3e0) ^ (s1 >> 22): the DFCM class */ \
   "v_lshl_add_u32 %[a2p], %[t3], 2, %[t2s]\n" \
-  "s_waitcnt lgkmcnt(0)\n"                                           /* the staging words read at the end of the step before */ \
+  "s_lshr_b64 vcc, %[st1], 1\n"                                      /* a run ends where the next lane starts one ... */ \
   "s_cmp_lg_u32 %[pend], 0\n" \
   "v_mov_b32_dpp %[t2v], %[a2p] wave_shr:1" SW_DPPF \
   "v_cmp_ne_u32_e64 %[st2], %[a2p], %[t2v]\n" \
   "s_cselect_b64 exec, -1, 0\n" \
   SW_FLUSH_STORES \
-  /* run starts: exchange by the lanes where a run starts or ends (a run ends where the next lane starts one; lane 63 always) */ \
-  "s_lshr_b64 vcc, %[st1], 1\n" \
+  /* run starts: exchange by the lanes where a run starts or ends (... lane 63 always) */ \
   "s_bitset1_b32 vcc_hi, 31\n" \
   "s_or_b64 exec, vcc, %[st1]\n" \
   "ds_wrxchg_rtn_b32 %[t1], %[a1p], " V "\n" \
@@ -531,12 +531,8 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   "v_cmp_eq_u32_e32 vcc, %[ksent], %[sp]\n" \
   "s_mov_b64 exec, -1\n" \
   "s_or_b64 %[sent], %[sent], vcc\n" \
-  "s_or_b64 vcc, %[st1], %[st2]\n" \
-  "s_cselect_b32 %[cand], 0, 1\n"                                    /* no run start at all: the next step may be a uniform one */ \
-  "s_add_u32 %[tms], %[posl], %[sbase]\n" \
-  "s_sub_u32 %[tms], %[tms], 1\n"                                    /* LDS address of the first free staging byte - 1 */ \
   "s_waitcnt lgkmcnt(0)\n" \
-  "v_cndmask_b32_e64 %[t1], %[A], %[t1], %[st1]\n"                   /* FCM prediction: inside a run the previous value */ \
+  "v_cndmask_b32_e64 %[t1], v61, %[t1], %[st1]\n"                   /* FCM prediction: inside a run the previous value */ \
   "v_cndmask_b32_e64 %[t2v], %[s1p], %[t2v], %[st2]\n"               /* DFCM prediction: inside a run the previous stride */ \
   "v_cmp_eq_u32_e32 vcc, %[ksent], %[t1]\n" \
   "s_and_b64 %[ft1], vcc, %[st1]\n"                                  /* starts that met an entry nobody wrote in this segment */ \
@@ -546,7 +542,7 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   HOOKTXT \
   /* residual selection (fpsc.c:146-189): DFCM iff its residual is shorter; byte layout; byte stores */ \
   "v_xor_b32 %[t0], " V ", %[t1]\n" \
-  "v_add_u32 %[t3], %[A], %[t2v]\n" \
+  "v_add_u32 %[t3], v61, %[t2v]\n" \
   "v_xor_b32 %[t4], " V ", %[t3]\n" \
   "v_ffbh_u32 %[t5], %[t0]\n" \
   "v_ffbh_u32 %[t6], %[t4]\n" \
@@ -571,14 +567,15 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   "s_nop 0\n" \
   "v_or_b32_dpp %[t6], %[t6], %[t6] row_half_mirror" SW_DPPB \
   "v_add_u32_dpp %[t4], %[t4], %[t4] row_shr:4" SW_DPPB \
-  "s_nop 1\n" \
+  "s_or_b64 vcc, %[st1], %[st2]\n" \
+  "s_cselect_b32 %[cand], 0, 1\n"                                    /* no run start at all: the next step may be a uniform one */ \
   "v_add_u32_dpp %[t4], %[t4], %[t4] row_shr:8" SW_DPPB \
   "v_lshrrev_b32 %[t3], 8, %[t6]\n" \
   "s_nop 0\n" \
   "v_add_u32_dpp %[t4], %[t4], %[t4] row_bcast:15 row_mask:0xa bank_mask:0xf\n" \
   "s_nop 1\n" \
   "v_add_u32_dpp %[t4], %[t4], %[t4] row_bcast:31 row_mask:0xc bank_mask:0xf\n"     /* inclusive sum of the lengths */ \
-  "v_add3_u32 %[t8], %[tms], %[grp3], %[t4]\n"                       /* the four bytes that END with my residual's last byte */ \
+  "v_add3_u32 %[t8], %[pa], %[grp3], %[t4]\n"                       /* the four bytes that END with my residual's last byte */ \
   "v_sub_u32 %[t9], %[t8], %[t5]\n"                                  /* my group's header - 1 (my residual begins 4 behind it) */ \
   "v_readlane_b32 %[total], %[t4], 63\n" \
   "s_mov_b64 exec, %[tm64]\n" \
@@ -608,7 +605,6 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   "s_sub_u32 %[tms], %[tms], 3\n" \
   "v_add_u32 v59, %[tms], %[t3]\n"                                   /* w1: slot offset of the group's header */ \
   "v_mov_b32 v60, " V "\n" \
-  "v_mov_b32 v61, %[A]\n" \
   "v_cndmask_b32_e64 %[t5], %[t2v], 0, %[ft2]\n" \
   "v_cndmask_b32_e64 v62, %[t1], %[t5], %[ft1]\n"                    /* w4: the prediction that is known if only one is open */ \
   "v_subrev_u32 v63, %[t2s], %[a2p]\n"                               /* w5: 4 * DFCM class */ \
@@ -626,17 +622,16 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   "s_cbranch_scc1 .Lce" J "_%=\n" \
   /* end of the step: bytes staged; the reads of the next step's flush; is a block full? */ \
   ".Lend" J "_%=:\n" \
-  "s_add_u32 %[posl], %[posl], %[total]\n" \
-  "s_cmp_ge_u32 %[posl], 512\n" \
-  "s_cselect_b64 exec, -1, 0\n" \
-  "s_cselect_b32 %[pend], 1, 0\n" \
-  "s_cselect_b32 %[tms], 512, 0\n" \
+  "s_add_u32 %[pa], %[pa], %[total]\n" \
+  "s_cmp_ge_u32 %[pa], %[lim]\n"                                     /* 512 bytes or more are staged */ \
+  "s_cbranch_scc0 .Lnf" J "_%=\n" \
   "ds_read_b64 v[56:57], %[stw8]\n" \
   "ds_read2st64_b32 v[54:55], %[stw] offset0:2 offset1:3\n" \
-  "s_mov_b64 exec, -1\n" \
   "s_mov_b32 %[floff], %[flushed]\n" \
-  "s_add_u32 %[flushed], %[flushed], %[tms]\n" \
-  "s_sub_u32 %[posl], %[posl], %[tms]\n"
+  "s_mov_b32 %[pend], 1\n" \
+  "s_add_u32 %[flushed], %[flushed], 512\n" \
+  "s_sub_u32 %[pa], %[pa], 512\n" \
+  ".Lnf" J "_%=:\n"
 
 // Four uniform steps at once (the steps J .. J + 3 of a block, J = 0 or 4, when the step before was uniform): the same tests as the
 // uniform step, for the four value registers, one verdict; 352 bytes (or 96) of pattern with two stores; the four loads of the
@@ -656,11 +651,11 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
 #define SW_QUAD(J, JE, V0, V1, V2, V3, VPREV, LD0, LD1, LD2, LD3) \
   ".Lq" J "_%=:\n" \
   "s_waitcnt vmcnt(2)\n" \
-  "v_mov_b32_dpp %[A], " VPREV " wave_ror:1" SW_DPPF \
+  "v_mov_b32_dpp v61, " VPREV " wave_ror:1" SW_DPPF \
   "v_mov_b32_dpp %[t0], " V0 " wave_ror:1" SW_DPPF \
   "v_mov_b32_dpp %[t1], " V1 " wave_ror:1" SW_DPPF \
   "v_mov_b32_dpp %[t2v], " V2 " wave_ror:1" SW_DPPF \
-  "v_mov_b32_dpp %[A], " V0 " wave_shr:1" SW_DPPF                    /* v[i-1] of the four steps */ \
+  "v_mov_b32_dpp v61, " V0 " wave_shr:1" SW_DPPF                    /* v[i-1] of the four steps */ \
   "v_mov_b32_dpp %[t0], " V1 " wave_shr:1" SW_DPPF \
   "v_mov_b32_dpp %[t1], " V2 " wave_shr:1" SW_DPPF \
   "v_mov_b32_dpp %[t2v], " V3 " wave_shr:1" SW_DPPF \
@@ -668,7 +663,7 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   "s_cbranch_scc1 .Lqz" J "_%=\n" \
   "v_mov_b32 %[t5], 0\n" \
   "s_mov_b64 %[tm64], 0\n" \
-  SW_QUAD_STEP88(V0, "%[A]") \
+  SW_QUAD_STEP88(V0, "v61") \
   SW_QUAD_STEP88(V1, "%[t0]") \
   SW_QUAD_STEP88(V2, "%[t1]") \
   SW_QUAD_STEP88(V3, "%[t2v]") \
@@ -682,7 +677,7 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   "v_mov_b32 %[t5], %[pat5b]\n" \
   "s_branch .Lqc" J "_%=\n" \
   ".Lqz" J "_%=:\n"                                                 /* behind exact FCM hits: every value equals the one before */ \
-  "v_xor_b32 %[t3], " V0 ", %[A]\n" \
+  "v_xor_b32 %[t3], " V0 ", v61\n" \
   "v_xor_b32 %[t4], " V1 ", %[t0]\n" \
   "v_xor_b32 %[t5], " V2 ", %[t1]\n" \
   "v_xor_b32 %[t6], " V3 ", %[t2v]\n" \
@@ -702,7 +697,7 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   "s_mov_b64 exec, -1\n" \
   "s_cmp_eq_u32 %[total], 96\n" \
   "s_cselect_b64 exec, 0xffffff, -1\n" \
-  "v_add_u32 %[t3], %[posl], %[stw]\n" \
+  "v_add_u32 %[t3], %[pa], %[lane4p1]\n" \
   "ds_write_b32 %[t3], %[t4]\n"                                     /* (not dword aligned: gfx950 executes it) */ \
   "s_mov_b64 exec, %[tm64]\n" \
   "ds_write_b32 %[t3], %[t5] offset:256\n" \
@@ -720,7 +715,6 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   "buffer_store_dword %[t3], %[lane8], %[rcr], 0 offen\n" \
   "buffer_store_dword %[t3], %[lane8], %[rcr], 0 offen\n" \
   "s_mov_b64 exec, -1\n" \
-  "s_mov_b32 %[pend], 0\n" \
   "s_branch .Lend" JE "_%=\n"
 
 // Replay: in front of its segment a wave runs over the last blocks of the segment before - classes, run starts and the exchange on the
@@ -735,14 +729,14 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   "buffer_load_dword " LD ", %[voff], %[inr], %[soff] offen\n" \
   "s_add_u32 %[soff], %[soff], %[stepb]\n" \
   "s_waitcnt vmcnt(12) lgkmcnt(0)\n" \
-  "v_mov_b32_dpp %[A], " VP " wave_ror:1" SW_DPPF \
+  "v_mov_b32_dpp v61, " VP " wave_ror:1" SW_DPPF \
   "v_mov_b32_dpp %[t0], %[s1p] wave_ror:1" SW_DPPF \
   "v_mov_b32_dpp %[s1p], %[sp] wave_ror:1" SW_DPPF \
   "v_mov_b32_dpp %[t1], %[a1p] wave_ror:1" SW_DPPF \
   "v_mov_b32_dpp %[t2v], %[a2p] wave_ror:1" SW_DPPF \
-  "v_mov_b32_dpp %[A], " V " wave_shr:1" SW_DPPF \
-  "v_sub_u32 %[sp], " V ", %[A]\n" \
-  "v_lshrrev_b32 %[t3], 26, %[A]\n" \
+  "v_mov_b32_dpp v61, " V " wave_shr:1" SW_DPPF \
+  "v_sub_u32 %[sp], " V ", v61\n" \
+  "v_lshrrev_b32 %[t3], 26, v61\n" \
   "v_and_or_b32 %[a1p], %[t3], 60, %[t1s]\n" \
   "v_mov_b32_dpp %[s1p], %[sp] wave_shr:1" SW_DPPF \
   "s_nop 0\n" \
@@ -779,26 +773,25 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   "s_cselect_b64 exec, -1, 0\n" \
   SW_FLUSH_STORES \
   "s_mov_b64 exec, -1\n" \
-  "s_mov_b32 %[pend], 0\n" \
-  "v_mov_b32_dpp %[A], " VP " wave_ror:1" SW_DPPF \
+  "v_mov_b32_dpp v61, " VP " wave_ror:1" SW_DPPF \
   "s_cmp_eq_u32 %[ust], 24\n" \
   "s_nop 0\n" \
-  "v_mov_b32_dpp %[A], " V " wave_shr:1" SW_DPPF                     /* A = v[i-1] */ \
-  "v_xor_b32 %[t0], " V ", %[A]\n" \
+  "v_mov_b32_dpp v61, " V " wave_shr:1" SW_DPPF                     /* A = v[i-1] */ \
+  "v_xor_b32 %[t0], " V ", v61\n" \
   "s_cbranch_scc1 .Luz" J "_%=\n" \
   /* behind 64 exact DFCM hits of stride S: again iff stride == S, v[i-2] = v[i-1] - S in the FCM class of v[i-1], v ^ v[i-1] >= 256 */ \
-  "v_sub_u32 %[t3], " V ", %[A]\n" \
+  "v_sub_u32 %[t3], " V ", v61\n" \
   "v_cmp_ne_u32_e64 %[tm64], %[ustr], %[t3]\n" \
-  "v_subrev_u32 %[t3], %[ustr], %[A]\n" \
+  "v_subrev_u32 %[t3], %[ustr], v61\n" \
   "v_cmp_gt_u32_e32 vcc, 0x100, %[t0]\n" \
-  "v_xor_b32 %[t3], %[t3], %[A]\n" \
+  "v_xor_b32 %[t3], %[t3], v61\n" \
   "s_or_b64 %[tm64], %[tm64], vcc\n" \
   "v_cmp_lt_u32_e32 vcc, 0xfffffff, %[t3]\n" \
   "s_or_b64 %[tm64], %[tm64], vcc\n" \
   "s_cmp_lg_u64 %[tm64], 0\n" \
   "s_cbranch_scc1 .Lul" J "_%=\n" \
   "s_mov_b64 exec, 0x3fffff\n"                                       /* 88 bytes: eight times (header of eight codes 5, eight zero bytes) */ \
-  "v_add_u32 %[t3], %[posl], %[stw]\n" \
+  "v_add_u32 %[t3], %[pa], %[lane4p1]\n" \
   "s_mov_b32 %[total], 88\n" \
   "ds_write_b32 %[t3], %[pat5]\n"                                    /* (not dword aligned: gfx950 executes it) */ \
   "s_mov_b64 exec, -1\n" \
@@ -808,7 +801,7 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   "s_cmp_lg_u64 vcc, 0\n" \
   "s_cbranch_scc1 .Lul" J "_%=\n" \
   "s_mov_b64 exec, 0x3f\n"                                           /* 24 zero bytes (t0 is zero in every lane) */ \
-  "v_add_u32 %[t3], %[posl], %[stw]\n" \
+  "v_add_u32 %[t3], %[pa], %[lane4p1]\n" \
   "s_mov_b32 %[total], 24\n" \
   "ds_write_b32 %[t3], %[t0]\n" \
   "s_mov_b64 exec, -1\n" \
@@ -818,8 +811,8 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   "s_branch .Lg" J "_%=\n" \
   /* a general step without a run start: 64 exact FCM hits (24 bytes), or 64 exact DFCM hits whose FCM residual is longer (88)? */ \
   ".Lce" J "_%=:\n" \
-  "v_xor_b32 %[t0], " V ", %[A]\n" \
-  "v_add_u32 %[t3], %[A], %[s1p]\n" \
+  "v_xor_b32 %[t0], " V ", v61\n" \
+  "v_add_u32 %[t3], v61, %[s1p]\n" \
   "v_cmp_ne_u32_e64 %[tm64], 0, %[t0]\n" \
   "v_xor_b32 %[t4], " V ", %[t3]\n" \
   "v_cmp_gt_u32_e32 vcc, 0x100, %[t0]\n" \
@@ -875,6 +868,8 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   ".Lp_%=:\n"
 
 #define SW_LOOP(HOOKTXT) \
+  "s_add_u32 %[pa], %[pa], %[sbase]\n"                               /* bytes staged -> LDS address of the first free staging byte - 1 */ \
+  "s_sub_u32 %[pa], %[pa], 1\n" \
   "s_mov_b32 %[ust], 0\n" \
   "s_mov_b32 %[ustr], 0\n" \
   "s_mov_b32 %[pend], 0\n" \
@@ -934,6 +929,8 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   SW_FLUSH_STORES \
   "s_mov_b64 exec, -1\n" \
   "s_waitcnt vmcnt(0) lgkmcnt(0)\n" \
+  "s_add_u32 %[pa], %[pa], 1\n" \
+  "s_sub_u32 %[pa], %[pa], %[sbase]\n" \
   "s_branch .Lout_%=\n" \
   SW_QUAD("0", "3", "%[c0]", "%[c1]", "%[c2]", "%[c3]", "%[c7]", "%[c6]", "%[c7]", "%[c0]", "%[c1]") \
   SW_QUAD("4", "7", "%[c4]", "%[c5]", "%[c6]", "%[c7]", "%[c3]", "%[c2]", "%[c3]", "%[c4]", "%[c5]") \
@@ -966,7 +963,7 @@ __device__ __forceinline__ void sweep_blocks_asm(Sweep& sw, uint32_t nrb, uint32
   uint32_t posl = uni(sw.posl), flushed = uni(sw.flushed), nrec = uni(sw.nrec), soff = 0u, ib = uni(i_begin);
   uint64_t sent = uni(sw.sent);
   nblk = uni(nblk);
-  uint32_t A, t0, t1, t2v, t3, t4, t5, t6, t7, t8, t9;
+  uint32_t t0, t1, t2v, t3, t4, t5, t6, t7, t8, t9;
   uint32_t ust, ustr, pend, floff, cand, total, tms, pg0, pg1, pg2, pg3;
   uint64_t tm64, st1, st2, ft1, ft2, hole;
   const uint32_t lane8 = 8u * lk.lane, stw = k.sbase + lk.lane4, stw8 = k.sbase + lane8, lanegi = (lk.lane & 7u) << REC_GI_SHIFT;
@@ -983,16 +980,16 @@ __device__ __forceinline__ void sweep_blocks_asm(Sweep& sw, uint32_t nrb, uint32
 #define SW_OPERANDS \
     : [c0] "=&v"(c0), [c1] "=&v"(c1), [c2] "=&v"(c2), [c3] "=&v"(c3), [c4] "=&v"(c4), [c5] "=&v"(c5), [c6] "+&v"(c6), [c7] "+&v"(c7), \
       [sp] "+&v"(sp), [s1p] "+&v"(s1p), [a1p] "+&v"(a1p), [a2p] "+&v"(a2p), \
-      [posl] "+&s"(posl), [flushed] "+&s"(flushed), [nrec] "+&s"(nrec), [soff] "+&s"(soff), [ib] "+&s"(ib), [nblk] "+&s"(nblk), [nrb] "+&s"(nrb), [sent] "+&s"(sent), \
-      [A] "=&v"(A), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2v] "=&v"(t2v), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), \
+      [pa] "+&s"(posl), [flushed] "+&s"(flushed), [nrec] "+&s"(nrec), [soff] "+&s"(soff), [ib] "+&s"(ib), [nblk] "+&s"(nblk), [nrb] "+&s"(nrb), [sent] "+&s"(sent), \
+      [t0] "=&v"(t0), [t1] "=&v"(t1), [t2v] "=&v"(t2v), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), \
       [t7] "=&v"(t7), [t8] "=&v"(t8), [t9] "=&v"(t9), \
       [ust] "=&s"(ust), [ustr] "=&s"(ustr), [pend] "=&s"(pend), [floff] "=&s"(floff), [cand] "=&s"(cand), [total] "=&s"(total), [tms] "=&s"(tms), \
       [pg0] "=&s"(pg0), [pg1] "=&s"(pg1), [pg2] "=&s"(pg2), [pg3] "=&s"(pg3), \
       [tm64] "=&s"(tm64), [st1] "=&s"(st1), [st2] "=&s"(st2), [ft1] "=&s"(ft1), [ft2] "=&s"(ft2), [hole] "=&s"(hole) \
     : [voff] "v"(k.voff), [lane8] "v"(lane8), [stw] "v"(stw), [stw8] "v"(stw8), [grp3] "v"(lk.grp3), [sh3] "v"(lk.sh3), [c4sh] "v"(lk.c4sh), \
-      [lanegi] "v"(lanegi), [pat5] "v"(lk.pat5), [progc] "v"(k.progc), [prog0] "v"(k.prog0), [pat5b] "v"(pat5b), \
+      [lanegi] "v"(lanegi), [pat5] "v"(lk.pat5), [progc] "v"(k.progc), [prog0] "v"(k.prog0), [pat5b] "v"(pat5b), [lane4p1] "v"(lk.lane4 + 1u), \
       [inr] "s"(k.inr), [slr] "s"(k.slr), [rcr] "s"(k.rcr), [stepb] "s"(k.stepb), [t1s] "s"(k.t1abs), [t2s] "s"(k.t1abs + 64u), [sbase] "s"(k.sbase), \
-      [ksent] "s"(SENT), [k3e0] "s"(0x3e0u), [kswap] "s"(0x00010203u), [lead] "s"(0x0101010101010101ull), [hk] "s"(hk), [kf0] "s"(0xf0000000u) \
+      [ksent] "s"(SENT), [k3e0] "s"(0x3e0u), [kswap] "s"(0x00010203u), [lead] "s"(0x0101010101010101ull), [hk] "s"(hk), [kf0] "s"(0xf0000000u), [lim] "s"(k.sbase + 511u) \
     : "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "vcc", "scc", "memory"
   if (HOOK)
     asm volatile(SW_LOOP(SW_HOOK) SW_OPERANDS);
