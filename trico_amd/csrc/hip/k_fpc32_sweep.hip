@@ -482,6 +482,12 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
 // Temporaries: A = v[i-1]; t0 s2 / x1 / reversed residual; t1 class before me / exchange result / FCM prediction; t2v the same
 // for DFCM; t3, t4 scratch / x2 / scan; t5 leading bytes / length; t6 leading bytes / header bits; t7 residual; t8 byte address;
 // t9 my group's header - 1.
+#define SW_RESIDUAL_STORES \
+  "s_mov_b64 exec, %[tm64]\n" \
+  "ds_write_b8 %[t8], %[t0]\n"                                       /* most significant byte first, in this order (see step_tail) */ \
+  "ds_write_b8_d16_hi %[t8], %[t7] offset:1\n" \
+  "ds_write_b8_d16_hi %[t8], %[t0] offset:2\n" \
+  "ds_write_b8 %[t8], %[t7] offset:3\n"
 #define SW_QUAD_TRY(J) \
   "s_cmp_lg_u32 %[ust], 0\n" \
   "s_cbranch_scc1 .Lq" J "_%=\n" \
@@ -578,11 +584,7 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   "v_add3_u32 %[t8], %[pa], %[grp3], %[t4]\n"                       /* the four bytes that END with my residual's last byte */ \
   "v_sub_u32 %[t9], %[t8], %[t5]\n"                                  /* my group's header - 1 (my residual begins 4 behind it) */ \
   "v_readlane_b32 %[total], %[t4], 63\n" \
-  "s_mov_b64 exec, %[tm64]\n" \
-  "ds_write_b8 %[t8], %[t0]\n"                                       /* most significant byte first, in this order (see step_tail) */ \
-  "ds_write_b8_d16_hi %[t8], %[t7] offset:1\n" \
-  "ds_write_b8_d16_hi %[t8], %[t0] offset:2\n" \
-  "ds_write_b8 %[t8], %[t7] offset:3\n" \
+  SW_RESIDUAL_STORES \
   "s_mov_b64 exec, %[lead]\n" \
   "ds_write_b8_d16_hi %[t9], %[t6] offset:1\n"                       /* three header bytes, big-endian, by the lanes that lead a group */ \
   "ds_write_b8 %[t9], %[t3] offset:2\n" \
