@@ -12,6 +12,23 @@ api.lib()
 v, t = meshgen.grid(W, H)
 nv, nt = W * H, 2 * W * H
 raw = v.nbytes + t.nbytes
+# the copies alone: the triangles (1.2 GB) up and down through trico_hip_copy (staging.hip for pageable memory of this size)
+import ctypes
+L = api.lib()
+d = L.trico_hip_device_alloc(t.nbytes)
+assert d
+back = np.empty_like(t)
+for it in range(3):
+    c0 = time.perf_counter()
+    assert L.trico_hip_copy(d, api.ptr(t), t.nbytes)
+    c1 = time.perf_counter()
+    assert L.trico_hip_copy(api.ptr(back), d, t.nbytes)
+    c2 = time.perf_counter()
+    print("copy %d: up %.1f ms (%.1f GB/s), down %.1f ms (%.1f GB/s)" % (it, (c1 - c0) * 1e3, t.nbytes / (c1 - c0) / 1e9,
+                                                                       (c2 - c1) * 1e3, t.nbytes / (c2 - c1) / 1e9), flush=True)
+assert back.tobytes() == t.tobytes()
+L.trico_hip_device_free(d)
+del back
 for it in range(3):
     t0 = time.perf_counter()
     a = api.Archive.open_for_writing(raw // 4)

@@ -44,6 +44,13 @@ void trim_pool();               // hipFree everything the pool holds
 // are copied to buf.p + offset on current_stream()
 const void* stage_in(DevBuf& buf, const void* src, size_t bytes, size_t offset = 0);
 
+// ---- copies between host and device (staging.hip) -------------------------------------------
+// Large transfers from / to PAGEABLE host memory go through a ring of pinned chunks filled by a few host threads; everything else is
+// one hipMemcpyAsync on `st`.  upload: the source may be reused on return, kernels launched on st afterwards see the bytes.
+// download: what st has produced so far; with wait = true the bytes are in h_dst on return (a staged download always is).
+bool upload_bytes(void* d_dst, const void* h_src, size_t bytes, hipStream_t st);
+bool download_bytes(void* h_dst, const void* d_src, size_t bytes, hipStream_t st, bool wait);
+
 } // namespace trico
 
 // Per-archive workspace.  One context must not be used from two threads at once (same rule as

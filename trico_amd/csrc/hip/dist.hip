@@ -40,7 +40,8 @@ int trico_hip_fpc_encode_component(trico_hip_ctx* ctx, const void* src, uint32_t
     {
     if (!ctx->in.reserve((size_t)n * arity * width + 16))
       return 0;
-    TRICO_HIP_TRY(hipMemcpyAsync(ctx->in.p, src, (size_t)n * arity * width, hipMemcpyHostToDevice, current_stream()));
+    if (!upload_bytes(ctx->in.p, src, (size_t)n * arity * width, current_stream()))
+      return 0;
     d_src = ctx->in.p;
     }
   if (n && !launch_deinterleave(d_src, n, arity, width, ctx->unit.p, stride))
@@ -76,7 +77,8 @@ int trico_hip_int_encode_plane(trico_hip_ctx* ctx, const void* src, uint32_t cou
     {
     if (!ctx->in.reserve((size_t)count * width + 16))
       return 0;
-    TRICO_HIP_TRY(hipMemcpyAsync(ctx->in.p, src, (size_t)count * width, hipMemcpyHostToDevice, current_stream()));
+    if (!upload_bytes(ctx->in.p, src, (size_t)count * width, current_stream()))
+      return 0;
     d_src = ctx->in.p;
     }
   if (count && !launch_planes_split(d_src, count, width, ctx->unit.p, stride))

@@ -487,7 +487,7 @@ static int run_batch(trico_hip_decode_job* jobs, int count)
   // ---- results for host destinations -------------------------------------------------------------------------------------------
   for (int i = 0; i < count; ++i)
     if (jobs[i].ok && kind[i] != K_SKIP && d_dst[i] != jobs[i].dst)
-      if (!hip_ok(hipMemcpy(jobs[i].dst, d_dst[i], job_out_bytes(jobs[i]), hipMemcpyDeviceToHost), "D2H(decoded values)"))
+      if (!download_bytes(jobs[i].dst, d_dst[i], job_out_bytes(jobs[i]), current_stream(), true))
         {
         jobs[i].ok = 0;
         all_ok = 0;

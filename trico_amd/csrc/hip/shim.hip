@@ -197,7 +197,7 @@ const void* stage_in(DevBuf& buf, const void* src, size_t bytes, size_t offset)
   {
   if (trico_hip_pointer_is_device(src))
     return src;
-  if (!hip_ok(hipMemcpyAsync(buf.p + offset, src, bytes, hipMemcpyHostToDevice, current_stream()), "H2D stage"))
+  if (!upload_bytes(buf.p + offset, src, bytes, current_stream()))
     return nullptr;
   return buf.p + offset;
   }
@@ -345,7 +345,16 @@ int trico_hip_copy(void* dst, const void* src, size_t bytes)
     return 1;
   if (!device_ready())
     return 0;
-  TRICO_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, current_stream()));
+  const bool dst_dev = trico_hip_pointer_is_device(dst) != 0, src_dev = trico_hip_pointer_is_device(src) != 0;
+  if (dst_dev && !src_dev)
+    {
+    if (!upload_bytes(dst, src, bytes, current_stream()))
+      return 0;
+    }
+  else if (src_dev && !dst_dev)
+    return download_bytes(dst, src, bytes, current_stream(), true) ? 1 : 0;
+  else
+    TRICO_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, current_stream()));
   TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
   return 1;
   }
@@ -928,8 +937,8 @@ int trico_hip_fpc_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[3], c
   const size_t out_bytes = (size_t)n * arity * width;
   if (!dst_dev && out_bytes)
     {
-    TRICO_HIP_TRY(hipMemcpyAsync(dst, ctx->out.p, out_bytes, hipMemcpyDeviceToHost, current_stream()));
-    TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
+    if (!download_bytes(dst, ctx->out.p, out_bytes, current_stream(), true))
+      return 0;
     }
   return 1;
   }
@@ -1100,8 +1109,8 @@ int trico_hip_int_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[8], c
   const size_t out_bytes = (size_t)count * width;
   if (!dst_dev && out_bytes)
     {
-    TRICO_HIP_TRY(hipMemcpyAsync(dst, ctx->out.p, out_bytes, hipMemcpyDeviceToHost, current_stream()));
-    TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
+    if (!download_bytes(dst, ctx->out.p, out_bytes, current_stream(), true))
+      return 0;
     }
   return 1;
   }
