@@ -6,7 +6,7 @@ rows = []
 for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if pat in r["Kernel_Name"]:
-            m = re.search(r"(k_\w+)", r["Kernel_Name"])
+            m = re.search(r"(k\d*_\w+(<[\w, ]+>)?)", r["Kernel_Name"])
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), m.group(1) if m else r["Kernel_Name"][:30], r.get("Queue_Id", "?")))
 rows.sort()
 t0 = rows[0][0] if rows else 0

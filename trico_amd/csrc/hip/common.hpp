@@ -187,7 +187,7 @@ int launch_fpc64_decode_batch(const Fpc64ChainJob* d_jobs, uint32_t njobs, uint8
 
 // sort-based throughput encoder for doubles (k_fpc64_sort.hip): table lookups as stable sorts by hash
 uint32_t fpc64_sorted_threshold();
-size_t fpc64_sorted_workspace(uint32_t n);
+size_t fpc64_sorted_workspace(uint32_t n, int arity);
 int launch_fpc64_encode_sorted(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
                                uint8_t* d_ws, size_t ws_bytes);
 

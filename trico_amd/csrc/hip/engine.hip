@@ -218,7 +218,7 @@ Plan make_plan(const trico_hip_decode_job* jobs, int count, const Kind* kind)
         {
         const size_t stride = align_up(fpc_bound(j.n, 8), 256);
         const bool sorted = j.n >= fpc64_sorted_threshold() && j.n <= 0x7fffffffu;
-        const size_t ws = stride * j.arity + (sorted ? fpc64_sorted_workspace(j.n) : (size_t)j.arity * 2 * ((size_t)1 << 20) * 8) + 256;
+        const size_t ws = stride * j.arity + (sorted ? fpc64_sorted_workspace(j.n, j.arity) : (size_t)j.arity * 2 * ((size_t)1 << 20) * 8) + 256;
         p.vws64 = ws > p.vws64 ? ws : p.vws64;
         }
       }

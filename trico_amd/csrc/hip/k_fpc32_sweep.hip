@@ -35,7 +35,6 @@ namespace fpc32 {
 
 namespace {
 
-constexpr int PF = 6;                             // steps (of 64 values) whose loads a wave keeps in flight (sweep_blocks_asm is written for 6)
 constexpr int FLB = 512;                          // the staging area leaves in blocks of this many bytes (8 per lane)
 constexpr int STAGE_LIVE = FLB + 280;             // < 512 unflushed + <= 280 of the step
 constexpr int STAGE = STAGE_LIVE + 256;           // + 4 dump bytes per lane (compiled step only)
@@ -421,7 +420,7 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
 //   * the staging area leaves in blocks of 512 bytes - at most one per step, so there is no second case: the two LDS reads are
 //     issued at the end of every step, used at the start of the next under exec = "a block is full", no branch;
 //   * EVERY step issues exactly four vector memory instructions (prefetch load, block store, two record stores; the stores run
-//     with exec = 0 when there is nothing to store), so "the load of this step has arrived" is exactly s_waitcnt vmcnt(4 * PF);
+//     with exec = 0 when there is nothing to store), so "the load of this step has arrived" is exactly s_waitcnt vmcnt(4 * 6);
 //   * eight value registers rotate (value of the step, of the step before, six loads in flight): the loop body is eight steps;
 //   * a record is 15 vector instructions (the header's position comes from two DPP moves, not from a cross-lane read).
 // Hazards the assembler does not see (gfx950): a DPP source written by a vector instruction needs two instructions in between,

@@ -1,20 +1,39 @@
-// k_fpc64_sort.hip — throughput encoder for 64-bit floating-point streams: the table lookups become sorts.
+// k_fpc64_sort.hip — throughput encoder for 64-bit floating-point streams: the table walk is handed to 1024 owners per table.
 //
 // Replaces trico_compress_double_precision(..., 20, 20) (fpsc.c:576-800) + the xyz / uv transposes for streams
 // large enough to pay for it.  The predictors' tables have 2^20 entries each, far too many classes for the
 // per-segment LDS tables of the float encoder, but the exactness argument is the same: the FCM hash
 // of value i is the top 20 bits of v[i-1], the DFCM hash a function of the strides of v[i-1] and v[i-2], so every
 // value's two hashes are known from the input alone, and a table read returns the payload (value / stride) of the
-// latest earlier value with the same hash, or 0.  "Latest earlier element with the same key" is the predecessor in a
-// stable sort by key:
-//   keys    (k64_keys):   both hashes of every value, and an index array
+// latest earlier value with the same hash, or 0.
+//
+// Round 5 (the path every stream takes unless its hashes are badly skewed):
+//   * runs: where value i has the hash of value i-1, its table read returns what i-1 wrote - the payload of i-1, known
+//     from the input.  Only the FIRST value of a run of equal hashes reads the table and only the LAST one's write is
+//     ever read, so a run is at most two table operations.  Smooth components (a grid's x and y, a constant normal)
+//     are almost nothing but runs.
+//   * owners: the hash's low 10 bits name one of 1024 owners per component, the other 10 bits an entry of the owner's
+//     table (8 KiB: LDS).  k64_part_hist / k64_part_scatter write every owner's operations, in value order, into its
+//     list (a stable one-digit partition: count matrix, scan, ballots for the order inside a step - one launch per
+//     table for all components, the source is read as whole vertices); an operation is 16 bytes: value index, table
+//     entry, read / write flags, and the payload it writes.
+//   * walk (k64_walk): one wave per owner streams through its list 64 operations at a time and applies them to its LDS
+//     table in list order: the lanes of a step that share an entry find each other with ballots, a read takes the
+//     payload of the nearest lower writer among them or the table's word, the last writer writes the table.  A read's
+//     result goes to the operation's place in a second list.
+//   * home (k64_home): the lists hold a tile's operations as 1024 short runs per component; one workgroup per tile
+//     collects them and stores the results to pred[value index] - all inside the tile's window of pred, which the
+//     L2 of the workgroup's XCD turns into whole lines.  (Storing the results from the walk itself, one 8-byte store
+//     per operation anywhere in pred, and fetching the payloads from the source the same way, cost 35-80 ps per
+//     operation on this machine - as much as the sort it replaces.)
+//   * sizes, scan, emit as before (all components in one launch each); a value inside a run takes its prediction from
+//     its neighbour instead of pred[].
+// A stream whose longest list would make the walk slower than sorting (one owner with most of the operations and no
+// runs: e.g. values alternating between two hashes) takes the path of round 2 for that table instead, which is
+// indifferent to skew:
+//   keys    both hashes of every value, and an index array
 //   sort    (k_sort.hip: stable LSD radix sort, two 10-bit passes): (hash, index) pairs, one sort per table
 //   preds   (k64_pred):   sorted neighbour with the same hash -> its payload, scattered back to the value's index
-//   sizes   (k64_sizes):  code selection (fpsc.c:640-700) -> bytes per group of two values (1 header byte + residuals)
-//   scan    (k_sort.hip: exclusive sum): byte offset of every group
-//   emit    (k64_emit):   tiles of 1024 groups are packed in LDS and written out with aligned dword stores
-// Everything is data-parallel; HBM traffic is ~25 passes over 4-8 byte arrays per value (sort-dominated), which on
-// this machine is two orders of magnitude cheaper than walking the 16 MiB tables value by value.
 #include "common.hpp"
 #include <stdlib.h>
 
@@ -24,25 +43,43 @@ namespace {
 
 typedef uint64_t u64;
 
-constexpr int TILE_G = 1024;                 // groups per emit tile
-constexpr int TILE_T = 256;                  // threads per emit workgroup (4 groups each)
+constexpr int TILE_G = 512;                  // groups per emit tile
+constexpr int TILE_T = 256;                  // threads per emit workgroup (2 groups each)
 constexpr int TILE_BYTES = TILE_G * 17;      // a group is at most 1 + 8 + 8 bytes
+
+constexpr int OWN_BITS = 10;
+constexpr uint32_t OWNERS = 1u << OWN_BITS;               // lists per component and table
+constexpr uint32_t ENTRIES = 1u << (20 - OWN_BITS);       // table entries of an owner
+constexpr u64 OP_READ = 1ull << 42, OP_WRITE = 1ull << 43; // an operation: value index | entry << 32 | flags
 
 __device__ __forceinline__ u64 val_at(const u64* __restrict__ src, int64_t i, int arity, int c)
   {
   return i >= 0 ? src[(size_t)i * arity + c] : 0ull;          // values before the stream count as 0 (fpsc.c:596-600)
   }
 
-__global__ void __launch_bounds__(256) k64_keys(const u64* __restrict__ src, uint32_t n, int arity, int c,
-                                                uint32_t* __restrict__ k1, uint32_t* __restrict__ k2)
+// hash of value i in table T (0: FCM, fpsc.c:565-568 with a 20-bit table; 1: DFCM, fpsc.c:570-573, two strides of history)
+template <int T>
+__device__ __forceinline__ uint32_t key_from(u64 v1, u64 v2, u64 v3)
+  {
+  if (T == 0)
+    return (uint32_t)(v1 >> 44);
+  const u64 s1 = v1 - v2, s2 = v2 - v3;
+  return (uint32_t)(((((s2 >> 44) & 1023ull) << 10) ^ (s1 >> 44)) & 0xfffffull);
+  }
+template <int T>
+__device__ __forceinline__ uint32_t key_of(const u64* __restrict__ src, int64_t i, int arity, int c)
+  {
+  const u64 v1 = val_at(src, i - 1, arity, c), v2 = val_at(src, i - 2, arity, c);
+  return key_from<T>(v1, v2, T ? val_at(src, i - 3, arity, c) : 0ull);
+  }
+
+// ---- the skew-proof path: keys, sort, predecessor in sorted order ------------------------------------------------------------
+template <int T>
+__global__ void __launch_bounds__(256) k64_keys(const u64* __restrict__ src, uint32_t n, int arity, int c, uint32_t* __restrict__ k)
   {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n)
-    return;
-  const u64 v1 = val_at(src, (int64_t)i - 1, arity, c), v2 = val_at(src, (int64_t)i - 2, arity, c), v3 = val_at(src, (int64_t)i - 3, arity, c);
-  const u64 s1 = v1 - v2, s2 = v2 - v3;
-  k1[i] = (uint32_t)(v1 >> 44);                                             // fpsc.c:565-568 with a 20-bit table
-  k2[i] = (uint32_t)(((((s2 >> 44) & 1023ull) << 10) ^ (s1 >> 44)) & 0xfffffull);   // fpsc.c:570-573: two strides of history
+  if (i < n)
+    k[i] = key_of<T>(src, (int64_t)i, arity, c);
   }
 
 // sorted position p holds value index vs[p] with hash ks[p]; its table read is the payload of the previous
@@ -63,14 +100,318 @@ __global__ void __launch_bounds__(256) k64_pred(const uint32_t* __restrict__ ks,
   pred[vs[p]] = pay;
   }
 
+// ---- owners: count, place, walk -----------------------------------------------------------------------------------------------
+// What value i does to table T of its component: nothing inside a run of equal hashes, a read at the run's first value, a write at
+// its last.  op_of returns the operation word (0: none), the owner and what the value writes (FCM: itself, DFCM: its stride).
+struct Op { u64 w, pay; };                   // (16 bytes, loaded and stored as one)
+
+// The kernels that look at every value read the source through LDS: a thread needs v[i-4 .. i] of its component, 24 bytes apart
+// in a vec3 stream - fetched directly, every such load touches as many cache lines as the wave has lanes.
+// stage: buf[(k + 4) * arity + c] = v[i0 + k][c] for k in [-4, count), zeros before the stream (fpsc.c:596-600); coalesced
+constexpr int HIST = 4;                      // values of history before the first one
+__device__ __forceinline__ void stage_values(const u64* __restrict__ src, uint32_t n, int arity, uint32_t i0, uint32_t count, u64* buf,
+                                             uint32_t tid, uint32_t nthreads)
+  {
+  const uint32_t total = (count + HIST) * (uint32_t)arity;
+  const int64_t base = ((int64_t)i0 - HIST) * arity, end = (int64_t)n * arity;
+  for (uint32_t k = tid; k < total; k += nthreads)
+    {
+    const int64_t idx = base + k;
+    buf[k] = (idx >= 0 && idx < end) ? src[idx] : 0ull;
+    }
+  }
+
+// the same for one wave and a step of 64 values, in two halves, so that the words of the next step are on their way while this one is
+// looked at: chunk_fetch issues the loads (clamped to the stream, nothing is waited for), chunk_stash puts them into LDS
+struct Chunk { u64 r[4]; };                  // (64 + HIST) * 3 = 204 words at most
+__device__ __forceinline__ void chunk_fetch(const u64* __restrict__ src, uint32_t n, int arity, uint32_t ib, int lane, Chunk& ch)
+  {
+  const int64_t base = ((int64_t)ib - HIST) * arity, end = (int64_t)n * arity;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    {
+    int64_t idx = base + lane + 64 * k;
+    idx = idx < 0 ? 0 : (idx < end ? idx : end - 1);
+    ch.r[k] = src[idx];
+    }
+  }
+__device__ __forceinline__ void chunk_stash(uint32_t n, int arity, uint32_t ib, int lane, const Chunk& ch, u64* buf)
+  {
+  const int64_t base = ((int64_t)ib - HIST) * arity, end = (int64_t)n * arity;
+  const int total = (64 + HIST) * arity;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    {
+    const int w = lane + 64 * k;
+    const int64_t idx = base + w;
+    if (w < total)
+      buf[w] = (idx >= 0 && idx < end) ? ch.r[k] : 0ull;
+    }
+  }
+
+// p points at the staged v[i] of the component, the values before it are `arity` words apart
+template <int T>
+__device__ __forceinline__ u64 op_of(const u64* p, uint32_t i, uint32_t n, int arity, uint32_t& owner, u64& pay)
+  {
+  const u64 v0 = p[0], v1 = p[-arity], v2 = p[-2 * arity];
+  const u64 v3 = T ? p[-3 * arity] : 0ull, v4 = T ? p[-4 * arity] : 0ull;
+  const uint32_t k = key_from<T>(v1, v2, v3), kprev = key_from<T>(v2, v3, v4), knext = key_from<T>(v0, v1, v2);
+  const bool first = i == 0u || k != kprev, last = i + 1u == n || knext != k;
+  owner = k & (OWNERS - 1u);
+  pay = T ? v0 - v1 : v0;
+  return (first || last) ? ((u64)i | ((u64)(k >> OWN_BITS) << 32) | (first ? OP_READ : 0ull) | (last ? OP_WRITE : 0ull)) : 0ull;
+  }
+
+// one wave per tile of `tile` values: cnt[c][owner] of its operations -> column `t` of hist[(c * OWNERS + owner)][t]
+template <int T>
+__global__ void __launch_bounds__(256) k64_part_hist(const u64* __restrict__ src, uint32_t n, int arity, uint32_t tile, uint32_t ntiles,
+                                                     uint32_t* __restrict__ hist)
+  {
+  __shared__ uint32_t cnt[4][3][OWNERS];
+  __shared__ u64 vals[4][(64 + HIST) * 3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t t = blockIdx.x * 4u + (uint32_t)wave;
+  for (int c = 0; c < arity; ++c)
+    for (uint32_t o = lane; o < OWNERS; o += 64u)
+      cnt[wave][c][o] = 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    hist[(size_t)arity * OWNERS * ntiles] = 0u;                 // the scan's last cell: the number of operations
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (t >= ntiles)
+    return;
+  const uint32_t i0 = t * tile, i1 = (n - i0 < tile) ? n : i0 + tile;
+  Chunk ch;
+  chunk_fetch(src, n, arity, i0, lane, ch);
+  for (uint32_t ib = i0; ib < i1; ib += 64u)
+    {
+    const uint32_t i = ib + (uint32_t)lane;
+    chunk_stash(n, arity, ib, lane, ch, vals[wave]);
+    chunk_fetch(src, n, arity, ib + 64u, lane, ch);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int c = 0; c < arity; ++c)
+      {
+      uint32_t owner = 0;
+      u64 pay;
+      const u64 op = i < i1 ? op_of<T>(vals[wave] + (lane + HIST) * arity + c, i, n, arity, owner, pay) : 0ull;
+      if (op)
+        atomicAdd(&cnt[wave][c][owner], 1u);
+      }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (int c = 0; c < arity; ++c)
+    for (uint32_t o = lane; o < OWNERS; o += 64u)
+      hist[((size_t)c * OWNERS + o) * ntiles + t] = cnt[wave][c][o];
+  }
+
+// the same wave walks its tile again and writes every operation to its place in its owner's list: the list's next free position,
+// kept in LDS, + the number of lower lanes with an operation for the same owner (10 ballots); steps, tiles, owners are visited in
+// order, so a list holds its operations in value order
+template <int T>
+__global__ void __launch_bounds__(256) k64_part_scatter(const u64* __restrict__ src, uint32_t n, int arity, uint32_t tile, uint32_t ntiles,
+                                                        const uint32_t* __restrict__ offs, Op* __restrict__ ops)
+  {
+  __shared__ uint32_t pos[4][3][OWNERS];
+  __shared__ u64 vals[4][(64 + HIST) * 3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t t = blockIdx.x * 4u + (uint32_t)wave;
+  if (t >= ntiles)
+    return;
+  for (int c = 0; c < arity; ++c)
+    for (uint32_t o = lane; o < OWNERS; o += 64u)
+      pos[wave][c][o] = offs[((size_t)c * OWNERS + o) * ntiles + t];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const uint32_t i0 = t * tile, i1 = (n - i0 < tile) ? n : i0 + tile;
+  const uint64_t below = (1ull << lane) - 1ull;
+  Chunk ch;
+  chunk_fetch(src, n, arity, i0, lane, ch);
+  for (uint32_t ib = i0; ib < i1; ib += 64u)
+    {
+    const uint32_t i = ib + (uint32_t)lane;
+    chunk_stash(n, arity, ib, lane, ch, vals[wave]);
+    chunk_fetch(src, n, arity, ib + 64u, lane, ch);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int c = 0; c < arity; ++c)
+      {
+      uint32_t owner = 0;
+      u64 pay = 0ull;
+      const u64 op = i < i1 ? op_of<T>(vals[wave] + (lane + HIST) * arity + c, i, n, arity, owner, pay) : 0ull;
+      uint64_t same = __ballot(op != 0ull);
+      if (same == 0ull)
+        continue;                                              // (a step inside runs: nothing to place)
+#pragma unroll
+      for (int b = 0; b < OWN_BITS; ++b)
+        {
+        const bool bit = (owner >> b) & 1u;
+        const uint64_t m = __ballot(bit);
+        same &= bit ? m : ~m;
+        }
+      const uint32_t base = pos[wave][c][owner];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (op)
+        {
+        ops[base + (uint32_t)__popcll(same & below)] = Op{ op, pay };
+        if ((same >> lane) == 1ull)                            // highest lane of this owner
+          pos[wave][c][owner] = base + (uint32_t)__popcll(same);
+        }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+    }
+  }
+
+// longest list and the number of operations -> res[0], res[1]
+__global__ void __launch_bounds__(256) k64_list_max(const uint32_t* __restrict__ offs, uint32_t lists, uint32_t ntiles, uint32_t* __restrict__ res)
+  {
+  const uint32_t l = blockIdx.x * 256u + threadIdx.x;
+  if (l < lists)
+    atomicMax(&res[0], offs[(size_t)(l + 1u) * ntiles] - offs[(size_t)l * ntiles]);
+  if (l == 0u)
+    res[1] = offs[(size_t)lists * ntiles];
+  }
+
+// One wave per list, four steps of 64 operations per round; the operations of the next two rounds are in flight while a round is
+// applied.  The loop body is three rounds, so that the registers of the rounds in flight change roles without being moved, and
+// every fetch is unconditional (clamped to the list), so that nothing is waited for before it is used.
+// A step is applied without a loop: the lanes with the same entry find each other with 10 ballots; a read returns the payload of
+// the nearest lower lane that writes the same entry, or the table's word; the highest writing lane of an entry writes the table.
+// The results go into a second list, in the same places.
+template <int T>
+__global__ void __launch_bounds__(64) k64_walk(const Op* __restrict__ ops, Op* __restrict__ done, const uint32_t* __restrict__ offs, uint32_t ntiles, Op* __restrict__ sink)
+  {
+  __shared__ u64 tab[ENTRIES];
+  const uint32_t lane = threadIdx.x, l = blockIdx.x;
+  const uint32_t b = offs[(size_t)l * ntiles], e = offs[(size_t)(l + 1u) * ntiles];
+  if (b == e)
+    return;
+  for (uint32_t k = lane; k < ENTRIES; k += 64u)
+    tab[k] = 0ull;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const uint64_t below = (1ull << lane) - 1ull;
+  const uint32_t last = e - 1u;
+  auto fetch = [&](uint32_t p, Op (&op)[4])
+    {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      {
+      const uint32_t q = p + 64u * k + lane;
+      op[k] = ops[q < last ? q : last];
+      }
+    };
+  auto apply = [&](uint32_t p, const Op (&ops4)[4])
+    {
+    // who meets whom (vector compares and ballots only) ...
+    uint32_t ent[4];
+    uint64_t prior[4];
+    bool lastw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      {
+      const u64 op = p + 64u * k + lane < e ? ops4[k].w : 0ull;
+      ent[k] = (uint32_t)(op >> 32) & (ENTRIES - 1u);
+      const bool rd = (op & OP_READ) != 0ull, wr = (op & OP_WRITE) != 0ull;
+      uint64_t same = __ballot(rd || wr);
+#pragma unroll
+      for (int bit = 0; bit < 20 - OWN_BITS; ++bit)
+        {
+        const bool s1 = (ent[k] >> bit) & 1u;
+        const uint64_t m = __ballot(s1);
+        same &= s1 ? m : ~m;
+        }
+      const uint64_t writers = same & __ballot(wr);
+      prior[k] = writers & below;
+      lastw[k] = wr && (writers >> lane) == 1ull;              // no higher lane writes this entry
+      }
+    // ... the table, step by step (the LDS unit keeps a wave's accesses in order: nothing is waited for in between) ...
+    u64 word[4];
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      {
+      const u64 pay = ops4[k].pay;
+      word[k] = tab[ent[k]];
+      const int from = prior[k] ? 63 - __builtin_clzll(prior[k]) : (int)lane;
+      lo[k] = (uint32_t)__shfl((int)(uint32_t)pay, from);
+      hi[k] = (uint32_t)__shfl((int)(uint32_t)(pay >> 32), from);
+      if (lastw[k])
+        tab[ent[k]] = pay;
+      }
+    // ... the results, into a list of their own (stores into the list being read would have to wait for its fetches).  Every lane
+    // stores, the ones past the list's end into a word of the list's own: a round is straight-line code and the compiler's count
+    // of the memory operations in flight stays exact.
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      {
+      const uint32_t q = p + 64u * k + lane;
+      Op* dst = q < e ? done + q : sink + l;
+      *dst = Op{ ops4[k].w, prior[k] ? ((u64)hi[k] << 32 | lo[k]) : word[k] };
+      }
+    };
+  Op oa[4], ob[4], oc[4];
+  fetch(b, oa);
+  fetch(b + 256u, ob);
+#pragma unroll 1
+  for (uint32_t p = b;; p += 768u)
+    {
+    fetch(p + 512u, oc);
+    apply(p, oa);
+    if (p + 256u >= e)
+      break;
+    fetch(p + 768u, oa);
+    apply(p + 256u, ob);
+    if (p + 512u >= e)
+      break;
+    fetch(p + 1024u, ob);
+    apply(p + 512u, oc);
+    if (p + 768u >= e)
+      break;
+    }
+  }
+
+// One workgroup per tile and component: the tile's operations are a run in every list; a quarter wave per run puts the results of the
+// reads into the tile's window of pred, built in LDS and written out whole (the words of values that read nothing are never looked at:
+// code_of takes those predictions from the neighbours).  A window without any read is not written.
+constexpr uint32_t HOME_TILE_MAX = 16384;                     // values per tile: 128 KiB of LDS
+__global__ void __launch_bounds__(1024) k64_home(const Op* __restrict__ ops, const uint32_t* __restrict__ offs, uint32_t ntiles, uint32_t tile,
+                                                 uint32_t n, u64* __restrict__ pred)
+  {
+  extern __shared__ __attribute__((aligned(16))) u64 win[];
+  const uint32_t t = blockIdx.x, c = blockIdx.y, sub = threadIdx.x >> 4, l16 = threadIdx.x & 15u;
+  const uint32_t i0 = t * tile, cnt = n - i0 < tile ? n - i0 : tile;
+  int found = 0;
+  for (uint32_t o = sub; o < OWNERS; o += 64u)
+    {
+    const size_t cell = ((size_t)c * OWNERS + o) * ntiles + t;
+    const uint32_t b = offs[cell], e = offs[cell + 1];
+    for (uint32_t q = b + l16; q < e; q += 16u)
+      {
+      const Op op = ops[q];
+      if (op.w & OP_READ)
+        {
+        win[(uint32_t)op.w - i0] = op.pay;
+        found = 1;
+        }
+      }
+    }
+  if (!__syncthreads_or(found))
+    return;
+  u64* __restrict__ out = pred + (size_t)c * n + i0;
+  for (uint32_t k = threadIdx.x; k < cnt; k += 1024u)
+    out[k] = win[k];
+  }
+
 __device__ __forceinline__ uint32_t blen64(u64 x) { return x ? (uint32_t)(71 - __builtin_clzll(x)) >> 3 : 0u; }
 
-// code, residual and residual length of value i (fpsc.c:640-700): FCM codes 0..8, DFCM codes 9..15 (1..7 bytes)
-__device__ __forceinline__ uint32_t code_of(const u64* __restrict__ src, uint32_t i, int arity, int c, const u64* __restrict__ pred1,
-                                            const u64* __restrict__ pred2, u64& x, uint32_t& len)
+// code, residual and residual length of value i (fpsc.c:640-700): FCM codes 0..8, DFCM codes 9..15 (1..7 bytes).
+// p points at the staged v[i]; pred1 / pred2 hold the table reads of the values that begin a run of equal hashes; inside a run
+// the read returns what the value before wrote: v[i-1], and the stride v[i-1] - v[i-2].
+__device__ __forceinline__ uint32_t code_of(const u64* p, int arity, uint32_t i, const u64* __restrict__ pred1, const u64* __restrict__ pred2,
+                                            u64& x, uint32_t& len)
   {
-  const u64 v = src[(size_t)i * arity + c], a = val_at(src, (int64_t)i - 1, arity, c);
-  const u64 x1 = v ^ pred1[i], x2 = v ^ (a + pred2[i]);
+  const u64 v = p[0], a = p[-arity], b = p[-2 * arity], b3 = p[-3 * arity], b4 = p[-4 * arity];
+  const bool first1 = i == 0u || key_from<0>(a, b, 0ull) != key_from<0>(b, b3, 0ull);
+  const bool first2 = i == 0u || key_from<1>(a, b, b3) != key_from<1>(b, b3, b4);
+  const u64 p1 = first1 ? pred1[i] : a, p2 = first2 ? pred2[i] : a - b;
+  const u64 x1 = v ^ p1, x2 = v ^ (a + p2);
   const uint32_t n1 = blen64(x1);
   uint32_t n2 = blen64(x2);
   n2 = n2 ? n2 : 1u;
@@ -85,84 +426,186 @@ __device__ __forceinline__ uint32_t code_of(const u64* __restrict__ src, uint32_
   return n1;
   }
 
-__global__ void __launch_bounds__(256) k64_sizes(const u64* __restrict__ src, uint32_t n, int arity, int c, const u64* __restrict__ pred1,
-                                                 const u64* __restrict__ pred2, uint32_t ngroups, uint32_t* __restrict__ gsz)
+// 256 groups of two values per workgroup, all components; pred1 / pred2 / gsz / goff of component c at c * n / c * gstride
+__global__ void __launch_bounds__(256) k64_sizes(const u64* __restrict__ src, uint32_t n, int arity, const u64* __restrict__ pred1,
+                                                 const u64* __restrict__ pred2, uint32_t ngroups, uint32_t* __restrict__ gsz, size_t gstride)
   {
-  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  __shared__ u64 vals[(512 + HIST) * 3];
+  const uint32_t g0 = blockIdx.x * 256u, g = g0 + threadIdx.x;
+  stage_values(src, n, arity, 2u * g0, 512u, vals, threadIdx.x, 256u);
+  __syncthreads();
   if (g >= ngroups)
     return;
-  u64 x;
-  uint32_t l0, l1 = 1u;                                        // a missing second value is padded with code 1, one 0x00 byte
-  code_of(src, 2u * g, arity, c, pred1, pred2, x, l0);
-  if (2u * g + 1u < n)
-    code_of(src, 2u * g + 1u, arity, c, pred1, pred2, x, l1);
-  gsz[g] = 1u + l0 + l1;
+  for (int c = 0; c < arity; ++c)
+    {
+    const u64* p = vals + (2u * threadIdx.x + HIST) * arity + c;
+    u64 x;
+    uint32_t l0, l1 = 1u;                                      // a missing second value is padded with code 1, one 0x00 byte
+    code_of(p, arity, 2u * g, pred1 + (size_t)c * n, pred2 + (size_t)c * n, x, l0);
+    if (2u * g + 1u < n)
+      code_of(p + arity, arity, 2u * g + 1u, pred1 + (size_t)c * n, pred2 + (size_t)c * n, x, l1);
+    gsz[(size_t)c * gstride + g] = 1u + l0 + l1;
+    }
   }
 
-__global__ void __launch_bounds__(TILE_T) k64_emit(const u64* __restrict__ src, uint32_t n, int arity, int c, const u64* __restrict__ pred1,
+// TILE_G groups per workgroup, the components one after the other
+__global__ void __launch_bounds__(TILE_T) k64_emit(const u64* __restrict__ src, uint32_t n, int arity, const u64* __restrict__ pred1,
                                                    const u64* __restrict__ pred2, uint32_t ngroups, const uint32_t* __restrict__ goff,
-                                                   const uint32_t* __restrict__ gsz, uint8_t* __restrict__ out, uint32_t* __restrict__ size_out)
+                                                   const uint32_t* __restrict__ gsz, size_t gstride, uint8_t* __restrict__ out, size_t out_stride,
+                                                   uint32_t* __restrict__ size_out)
   {
   __shared__ __attribute__((aligned(16))) uint8_t lds[TILE_BYTES + 16];
+  __shared__ u64 vals[(2 * TILE_G + HIST) * 3];
   const uint32_t g0 = blockIdx.x * TILE_G;
   const uint32_t g1 = g0 + TILE_G < ngroups ? g0 + TILE_G : ngroups;
-  const uint32_t base = goff[g0];
-  const uint32_t end = goff[g1 - 1] + gsz[g1 - 1];
-  for (uint32_t g = g0 + threadIdx.x; g < g1; g += TILE_T)
+  stage_values(src, n, arity, 2u * g0, 2u * TILE_G, vals, threadIdx.x, TILE_T);
+  for (int c = 0; c < arity; ++c)
     {
-    uint8_t* o = lds + (goff[g] - base);
-    u64 x0, x1 = 0;
-    uint32_t l0, l1 = 1u, c1 = 1u;
-    const uint32_t c0 = code_of(src, 2u * g, arity, c, pred1, pred2, x0, l0);
-    if (2u * g + 1u < n)
-      c1 = code_of(src, 2u * g + 1u, arity, c, pred1, pred2, x1, l1);
-    *o++ = (uint8_t)((c1 << 4) | c0);                           // fpsc.c:706
-    for (uint32_t k = l0; k > 0; --k) *o++ = (uint8_t)(x0 >> (8u * (k - 1u)));
-    for (uint32_t k = l1; k > 0; --k) *o++ = (uint8_t)(x1 >> (8u * (k - 1u)));
+    __syncthreads();                                           // (the values are staged; the bytes of the component before are out)
+    const u64* p1 = pred1 + (size_t)c * n;
+    const u64* p2 = pred2 + (size_t)c * n;
+    const uint32_t* go = goff + (size_t)c * gstride;
+    const uint32_t* gs = gsz + (size_t)c * gstride;
+    uint8_t* oc = out + (size_t)c * out_stride;
+    const uint32_t base = go[g0];
+    const uint32_t end = go[g1 - 1] + gs[g1 - 1];
+    for (uint32_t g = g0 + threadIdx.x; g < g1; g += TILE_T)
+      {
+      uint8_t* o = lds + (go[g] - base);
+      const u64* p = vals + (2u * (g - g0) + HIST) * arity + c;
+      u64 x0, x1 = 0;
+      uint32_t l0, l1 = 1u, c1 = 1u;
+      const uint32_t c0 = code_of(p, arity, 2u * g, p1, p2, x0, l0);
+      if (2u * g + 1u < n)
+        c1 = code_of(p + arity, arity, 2u * g + 1u, p1, p2, x1, l1);
+      *o++ = (uint8_t)((c1 << 4) | c0);                         // fpsc.c:706
+      for (uint32_t k = l0; k > 0; --k) *o++ = (uint8_t)(x0 >> (8u * (k - 1u)));
+      for (uint32_t k = l1; k > 0; --k) *o++ = (uint8_t)(x1 >> (8u * (k - 1u)));
+      }
+    __syncthreads();
+    // tile bytes [base, end) of the group area go to out + 5 + base: bytes up to the first aligned dword, then dwords
+    uint8_t* d = oc + 5u + base;
+    const uint32_t len = end - base;
+    const uint32_t head = (uint32_t)((4u - ((uintptr_t)d & 3u)) & 3u);
+    const uint32_t h = head < len ? head : len;
+    if (threadIdx.x < h)
+      d[threadIdx.x] = lds[threadIdx.x];
+    const uint32_t body = (len - h) >> 2;
+    for (uint32_t t = threadIdx.x; t < body; t += TILE_T)
+      {
+      const uint8_t* s = lds + h + 4u * t;
+      ((uint32_t*)(d + h))[t] = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
+      }
+    const uint32_t done = h + 4u * body;
+    if (threadIdx.x < len - done)
+      d[done + threadIdx.x] = lds[done + threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+      {
+      oc[0] = 0xaa;                                              // (20/2) << 4 | (20/2), fpsc.c:610
+      oc[1] = (uint8_t)(n >> 24); oc[2] = (uint8_t)(n >> 16); oc[3] = (uint8_t)(n >> 8); oc[4] = (uint8_t)n;
+      }
+    if (g1 == ngroups && threadIdx.x == 0)
+      size_out[c] = 5u + end;
     }
-  __syncthreads();
-  // tile bytes [base, end) of the group area go to out + 5 + base: bytes up to the first aligned dword, then dwords
-  uint8_t* d = out + 5u + base;
-  const uint32_t len = end - base;
-  const uint32_t head = (uint32_t)((4u - ((uintptr_t)d & 3u)) & 3u);
-  const uint32_t h = head < len ? head : len;
-  if (threadIdx.x < h)
-    d[threadIdx.x] = lds[threadIdx.x];
-  const uint32_t body = (len - h) >> 2;
-  for (uint32_t t = threadIdx.x; t < body; t += TILE_T)
-    {
-    const uint8_t* s = lds + h + 4u * t;
-    ((uint32_t*)(d + h))[t] = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
-    }
-  const uint32_t done = h + 4u * body;
-  if (threadIdx.x < len - done)
-    d[done + threadIdx.x] = lds[done + threadIdx.x];
-  if (blockIdx.x == 0 && threadIdx.x == 0)
-    {
-    out[0] = 0xaa;                                               // (20/2) << 4 | (20/2), fpsc.c:610
-    out[1] = (uint8_t)(n >> 24); out[2] = (uint8_t)(n >> 16); out[3] = (uint8_t)(n >> 8); out[4] = (uint8_t)n;
-    }
-  if (g1 == ngroups && threadIdx.x == 0)
-    *size_out = 5u + end;
   }
 
-struct SortPlan { size_t k1, k1s, k2, k2s, v1s, v2s, pred1, pred2, gsz, goff, tmp, tmp_bytes, total; };
-
-SortPlan plan_for(uint32_t n)
+// values per wave of the partition kernels: ~4096 tiles, 1024 .. 16384 values each
+uint32_t part_tile(uint32_t n)
   {
-  SortPlan p;
+  const uint32_t t = ((n + 4095u) / 4096u + 63u) & ~63u;
+  return t < 1024u ? 1024u : (t > HOME_TILE_MAX ? HOME_TILE_MAX : t);
+  }
+
+struct EncPlan { size_t pred1, pred2, gsz, goff, gstride, hist, res, sink, area, area_bytes, tmp, tmp_bytes, total; uint32_t tile, ntiles; };
+
+EncPlan plan_for(uint32_t n, int arity)
+  {
+  EncPlan p;
   const size_t ng = ((size_t)n + 1) / 2;
   size_t o = 0;
   auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes + 16, 256); return at; };
-  p.k1 = take(4 * (size_t)n); p.k1s = take(4 * (size_t)n); p.k2 = take(4 * (size_t)n); p.k2s = take(4 * (size_t)n);
-  p.v1s = take(4 * (size_t)n); p.v2s = take(4 * (size_t)n);
-  p.pred1 = take(8 * (size_t)n); p.pred2 = take(8 * (size_t)n);
-  p.gsz = take(4 * ng); p.goff = take(4 * ng);
-  const size_t sort_bytes = sort_workspace(n), scan_bytes = scan_workspace((uint32_t)ng);
+  p.tile = part_tile(n);
+  p.ntiles = (n + p.tile - 1) / p.tile;
+  p.pred1 = take(8 * (size_t)n * arity); p.pred2 = take(8 * (size_t)n * arity);
+  p.gstride = align_up(ng + 4, 64);
+  p.gsz = take(4 * p.gstride * arity); p.goff = take(4 * p.gstride * arity);
+  const size_t cells = (size_t)arity * OWNERS * p.ntiles + 1;
+  p.hist = take(4 * cells);
+  p.res = take(64);
+  p.sink = take(sizeof(Op) * (size_t)arity * OWNERS);
+  // the owners' lists of one table, or (skewed streams) keys, sorted keys, sorted indices of one component
+  const size_t lists = 2 * align_up(sizeof(Op) * (size_t)n * arity + 16, 256), sorts = 3 * align_up(4 * (size_t)n + 16, 256);
+  p.area_bytes = lists > sorts ? lists : sorts;
+  p.area = take(p.area_bytes);
+  const size_t sort_bytes = sort_workspace(n), scan_bytes = scan_workspace((uint32_t)(cells > ng ? cells : ng));
   p.tmp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
   p.tmp = take(p.tmp_bytes);
   p.total = o;
   return p;
+  }
+
+// operations in one list from which the table takes the sorting path: the walk of such a list alone (64 operations per step,
+// a step ~1 us with its fetches in flight) would take longer than the sorts of the whole stream
+uint32_t walk_limit(uint32_t n, int arity)
+  {
+  if (const char* e = getenv("TRICO_FPC64_WALK_MAX"))              // tuning knob (0: always sort); changes time, never bytes
+    return (uint32_t)strtoul(e, nullptr, 10);
+  const uint64_t even = 8ull * (uint64_t)n / OWNERS;             // eight times an even share of a stream without runs
+  return even > 262144ull ? (uint32_t)(even > 0xffffffffull ? 0xffffffffull : even) : 262144u;
+  }
+
+template <int T>
+int table_reads(const u64* src, uint32_t n, int arity, const EncPlan& p, uint8_t* d_ws, u64* pred, hipStream_t st)
+  {
+  uint32_t* hist = (uint32_t*)(d_ws + p.hist);
+  uint32_t* res = (uint32_t*)(d_ws + p.res);
+  const uint32_t lists = (uint32_t)arity * OWNERS;
+  const size_t cells = (size_t)lists * p.ntiles + 1;
+  bool walk = (uint64_t)n * (uint64_t)arity < 0xffffffffull && walk_limit(n, arity) != 0u;      // (list positions are 32 bits)
+  if (walk)
+    {
+    const unsigned blocks = (p.ntiles + 3u) / 4u;
+    hipLaunchKernelGGL(k64_part_hist<T>, dim3(blocks), dim3(256), 0, st, src, n, arity, p.tile, p.ntiles, hist);
+    if (!exclusive_scan_u32(hist, hist, (uint32_t)cells, d_ws + p.tmp, p.tmp_bytes))
+      return 0;
+    if (!hip_ok(hipMemsetAsync(res, 0, 8, st), "fpc64 encoder: memset"))
+      return 0;
+    hipLaunchKernelGGL(k64_list_max, dim3((lists + 255u) / 256u), dim3(256), 0, st, hist, lists, p.ntiles, res);
+    uint32_t h[2] = { 0, 0 };
+    if (!hip_ok(hipMemcpyAsync(h, res, 8, hipMemcpyDeviceToHost, st), "fpc64 encoder: list lengths") ||
+        !hip_ok(hipStreamSynchronize(st), "fpc64 encoder: list lengths"))
+      return 0;
+    walk = h[0] <= walk_limit(n, arity);
+    if (walk)
+      {
+      Op* ops = (Op*)(d_ws + p.area);
+      hipLaunchKernelGGL(k64_part_scatter<T>, dim3(blocks), dim3(256), 0, st, src, n, arity, p.tile, p.ntiles, hist, ops);
+      Op* done = (Op*)(d_ws + p.area + align_up(sizeof(Op) * (size_t)n * arity + 16, 256));
+      hipLaunchKernelGGL(k64_walk<T>, dim3(lists), dim3(64), 0, st, ops, done, hist, p.ntiles, (Op*)(d_ws + p.sink));
+      static const bool claimed = hipFuncSetAttribute((const void*)k64_home, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(HOME_TILE_MAX * 8u)) == hipSuccess;
+      if (!claimed)
+        {
+        set_error("fpc64 throughput encoder: cannot claim 128 KiB of LDS");
+        return 0;
+        }
+      hipLaunchKernelGGL(k64_home, dim3(p.ntiles, arity), dim3(1024), p.tile * 8u, st, done, hist, p.ntiles, p.tile, n, pred);
+      }
+    }
+  if (!walk)
+    {
+    const size_t q = align_up(4 * (size_t)n + 16, 256);
+    uint32_t* k = (uint32_t*)(d_ws + p.area); uint32_t* ks = (uint32_t*)(d_ws + p.area + q); uint32_t* vs = (uint32_t*)(d_ws + p.area + 2 * q);
+    const unsigned vb = (n + 255u) / 256u;
+    for (int c = 0; c < arity; ++c)
+      {
+      hipLaunchKernelGGL(k64_keys<T>, dim3(vb), dim3(256), 0, st, src, n, arity, c, k);
+      // values = identity: the sorted value of position p is the index of the p-th value in (hash, index) order
+      if (!radix_sort_pairs(k, nullptr, ks, vs, n, 20, d_ws + p.tmp, p.tmp_bytes))
+        return 0;
+      hipLaunchKernelGGL(k64_pred, dim3(vb), dim3(256), 0, st, ks, vs, src, n, arity, c, T, pred + (size_t)c * n);
+      }
+    }
+  return 1;
   }
 
 } // namespace
@@ -172,57 +615,47 @@ uint32_t fpc64_sorted_threshold()
   static uint32_t t = 0;
   if (!t)
     {
-    const char* e = getenv("TRICO_FPC64_SORT_MIN");              // tuning knob: values per stream from which the sort path is used
+    const char* e = getenv("TRICO_FPC64_SORT_MIN");              // tuning knob: values per stream from which this encoder is used
     t = e ? (uint32_t)strtoul(e, nullptr, 10) : 65536u;
     if (t < 2) t = 2;
     }
   return t;
   }
 
-size_t fpc64_sorted_workspace(uint32_t n)
+size_t fpc64_sorted_workspace(uint32_t n, int arity)
   {
-  return plan_for(n).total;
+  return plan_for(n, arity).total;
   }
 
 int launch_fpc64_encode_sorted(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
                                uint8_t* d_ws, size_t ws_bytes)
   {
-  if (n < 2 || n > 0x7fffffffu)
+  if (n < 2 || n > 0x7fffffffu || arity < 1 || arity > 3)
     {
-    set_error("fpc64 sort encoder: unsupported count");
+    set_error("fpc64 throughput encoder: unsupported count");
     return 0;
     }
-  const SortPlan p = plan_for(n);
+  const EncPlan p = plan_for(n, arity);
   if (p.total > ws_bytes)
     {
-    set_error("fpc64 sort encoder: workspace too small");
+    set_error("fpc64 throughput encoder: workspace too small");
     return 0;
     }
   hipStream_t st = current_stream();
   const u64* src = (const u64*)d_src;
   const uint32_t ng = (n + 1u) / 2u;
-  const unsigned vb = (n + 255u) / 256u, gb = (ng + 255u) / 256u, tiles = (ng + TILE_G - 1) / TILE_G;
-  uint32_t* k1 = (uint32_t*)(d_ws + p.k1); uint32_t* k1s = (uint32_t*)(d_ws + p.k1s);
-  uint32_t* k2 = (uint32_t*)(d_ws + p.k2); uint32_t* k2s = (uint32_t*)(d_ws + p.k2s);
-  uint32_t* v1s = (uint32_t*)(d_ws + p.v1s); uint32_t* v2s = (uint32_t*)(d_ws + p.v2s);
+  const unsigned gb = (ng + 255u) / 256u, tiles = (ng + TILE_G - 1) / TILE_G;
   u64* pred1 = (u64*)(d_ws + p.pred1); u64* pred2 = (u64*)(d_ws + p.pred2);
   uint32_t* gsz = (uint32_t*)(d_ws + p.gsz); uint32_t* goff = (uint32_t*)(d_ws + p.goff);
+  if (!table_reads<0>(src, n, arity, p, d_ws, pred1, st) || !table_reads<1>(src, n, arity, p, d_ws, pred2, st))
+    return 0;
+  hipLaunchKernelGGL(k64_sizes, dim3(gb), dim3(256), 0, st, src, n, arity, pred1, pred2, ng, gsz, p.gstride);
   for (int c = 0; c < arity; ++c)
-    {
-    hipLaunchKernelGGL(k64_keys, dim3(vb), dim3(256), 0, st, src, n, arity, c, k1, k2);
-    // values = identity: the sorted value of position p is the index of the p-th value in (hash, index) order
-    if (!radix_sort_pairs(k1, nullptr, k1s, v1s, n, 20, d_ws + p.tmp, p.tmp_bytes) ||
-        !radix_sort_pairs(k2, nullptr, k2s, v2s, n, 20, d_ws + p.tmp, p.tmp_bytes))
+    if (!exclusive_scan_u32(gsz + (size_t)c * p.gstride, goff + (size_t)c * p.gstride, ng, d_ws + p.tmp, p.tmp_bytes))
       return 0;
-    hipLaunchKernelGGL(k64_pred, dim3(vb), dim3(256), 0, st, k1s, v1s, src, n, arity, c, 0, pred1);
-    hipLaunchKernelGGL(k64_pred, dim3(vb), dim3(256), 0, st, k2s, v2s, src, n, arity, c, 1, pred2);
-    hipLaunchKernelGGL(k64_sizes, dim3(gb), dim3(256), 0, st, src, n, arity, c, pred1, pred2, ng, gsz);
-    if (!exclusive_scan_u32(gsz, goff, ng, d_ws + p.tmp, p.tmp_bytes))
-      return 0;
-    hipLaunchKernelGGL(k64_emit, dim3(tiles), dim3(TILE_T), 0, st, src, n, arity, c, pred1, pred2, ng, goff, gsz,
-                       d_out + (size_t)c * out_stride, d_sizes + c);
-    }
-  return hip_ok(hipGetLastError(), "fpc64 sort encoder") ? 1 : 0;
+  hipLaunchKernelGGL(k64_emit, dim3(tiles), dim3(TILE_T), 0, st, src, n, arity, pred1, pred2, ng, goff, gsz, p.gstride,
+                     d_out, out_stride, d_sizes);
+  return hip_ok(hipGetLastError(), "fpc64 throughput encoder") ? 1 : 0;
   }
 
 } // namespace trico

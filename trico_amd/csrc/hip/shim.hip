@@ -508,7 +508,7 @@ int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int
   else if (sorted64)
     {
     // large streams: the table lookups become sorts (k_fpc64_sort.hip); the tables themselves are not needed
-    const size_t ws = fpc64_sorted_workspace(n);
+    const size_t ws = fpc64_sorted_workspace(n, arity);
     if (!ctx->ws.reserve(ws))
       return 0;
     if (!launch_fpc64_encode_sorted(d_src, n, arity, ctx->out.p, stride, d_sizes, ctx->ws.p, ctx->ws.cap))
@@ -632,7 +632,7 @@ int fpc_selfcheck_launch(const void* d_vals, uint32_t n, int arity, int width, c
     }
   const size_t stride = align_up(fpc_bound(n, 8), 256);
   const bool sorted = n >= fpc64_sorted_threshold() && n <= 0x7fffffffu;
-  const size_t wsb = sorted ? fpc64_sorted_workspace(n) : (size_t)arity * 2 * ((size_t)1 << 20) * 8;
+  const size_t wsb = sorted ? fpc64_sorted_workspace(n, arity) : (size_t)arity * 2 * ((size_t)1 << 20) * 8;
   if (!vws.reserve(stride * arity + wsb + 256))
     return 0;
   uint8_t* out = vws.p;
