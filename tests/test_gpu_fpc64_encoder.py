@@ -30,9 +30,9 @@ def _data(kind, n, rng):
         return np.repeat(v, rng.integers(1, 200, v.size))[:n].copy()
     if kind == "quantised":                   # a normal's component: 1024 levels, noisy
         return (rng.integers(0, 1024, n) - 512) / 512.0
-    if kind == "owner0":                      # noisy, but every FCM hash has its low 10 bits clear: one owner holds every operation
+    if kind == "owner0":                      # noisy, but the two halves of every FCM hash are equal: one owner holds every FCM operation
         b = rng.integers(0, 2**64, n, dtype=np.uint64)
-        return (b & ~np.uint64(0x3ff << 44)).view(np.float64)
+        return ((b & ~np.uint64(0x3ff << 44)) | (((b >> np.uint64(54)) & np.uint64(0x3ff)) << np.uint64(44))).view(np.float64)
     raise ValueError(kind)
 
 

@@ -12,8 +12,8 @@
 //     from the input.  Only the FIRST value of a run of equal hashes reads the table and only the LAST one's write is
 //     ever read, so a run is at most two table operations.  Smooth components (a grid's x and y, a constant normal)
 //     are almost nothing but runs.
-//   * owners: the hash's low 10 bits name one of 1024 owners per component, the other 10 bits an entry of the owner's
-//     table (8 KiB: LDS).  k64_part_hist / k64_part_scatter write every owner's operations, in value order, into its
+//   * owners: ten bits of the hash (FCM: its two halves xor-ed, DFCM: the lower half) name one of 1024 owners per
+//     component, the upper half an entry of the owner's table (8 KiB: LDS).  k64_part_hist / k64_part_scatter write every owner's operations, in value order, into its
 //     list (a stable one-digit partition: count matrix, scan, ballots for the order inside a step - one launch per
 //     table for all components, the source is read as whole vertices); an operation is 16 bytes: value index, table
 //     entry, read / write flags, and the payload it writes.
@@ -157,7 +157,9 @@ __device__ __forceinline__ u64 op_of(const u64* p, uint32_t i, uint32_t n, int a
   const u64 v3 = T ? p[-3 * arity] : 0ull, v4 = T ? p[-4 * arity] : 0ull;
   const uint32_t k = key_from<T>(v1, v2, v3), kprev = key_from<T>(v2, v3, v4), knext = key_from<T>(v0, v1, v2);
   const bool first = i == 0u || k != kprev, last = i + 1u == n || knext != k;
-  owner = k & (OWNERS - 1u);
+  // FCM: sign and upper exponent bits folded onto the mantissa bits (quantised data often varies in one half only); the DFCM hash
+  // is a mix of two strides already - folded again, a constant second difference puts most of a stream into a few lists
+  owner = (T ? k : k ^ (k >> OWN_BITS)) & (OWNERS - 1u);
   pay = T ? v0 - v1 : v0;
   return (first || last) ? ((u64)i | ((u64)(k >> OWN_BITS) << 32) | (first ? OP_READ : 0ull) | (last ? OP_WRITE : 0ull)) : 0ull;
   }
@@ -342,13 +344,21 @@ __global__ void __launch_bounds__(64) k64_walk(const Op* __restrict__ ops, Op* _
     for (int k = 0; k < 4; ++k)
       {
       const uint32_t q = p + 64u * k + lane;
-      Op* dst = q < e ? done + q : sink + l;
+      Op* dst = q < e ? done + q : sink + 8u * l;
       *dst = Op{ ops4[k].w, prior[k] ? ((u64)hi[k] << 32 | lo[k]) : word[k] };
       }
     };
+  // (the stores of zeros make the queue of memory operations look at the loop's entry as it does at its end - two fetches with four
+  // stores after each - so that the wait the compiler puts at the loop's head leaves the younger fetch in flight there too)
   Op oa[4], ob[4], oc[4];
   fetch(b, oa);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    sink[8u * l + k] = Op{ 0ull, 0ull };
   fetch(b + 256u, ob);
+#pragma unroll
+  for (int k = 4; k < 8; ++k)
+    sink[8u * l + k] = Op{ 0ull, 0ull };
 #pragma unroll 1
   for (uint32_t p = b;; p += 768u)
     {
@@ -375,22 +385,40 @@ __global__ void __launch_bounds__(1024) k64_home(const Op* __restrict__ ops, con
                                                  uint32_t n, u64* __restrict__ pred)
   {
   extern __shared__ __attribute__((aligned(16))) u64 win[];
+  __shared__ uint32_t run[OWNERS][2];                          // where the tile's run begins and ends in every list
   const uint32_t t = blockIdx.x, c = blockIdx.y, sub = threadIdx.x >> 4, l16 = threadIdx.x & 15u;
   const uint32_t i0 = t * tile, cnt = n - i0 < tile ? n - i0 : tile;
-  int found = 0;
-  for (uint32_t o = sub; o < OWNERS; o += 64u)
     {
-    const size_t cell = ((size_t)c * OWNERS + o) * ntiles + t;
-    const uint32_t b = offs[cell], e = offs[cell + 1];
-    for (uint32_t q = b + l16; q < e; q += 16u)
+    const size_t cell = ((size_t)c * OWNERS + threadIdx.x) * ntiles + t;
+    run[threadIdx.x][0] = offs[cell];
+    run[threadIdx.x][1] = offs[cell + 1];
+    }
+  __syncthreads();
+  int found = 0;
+  // a quarter wave per run, four runs in flight
+  for (uint32_t o = sub; o < OWNERS; o += 256u)
+    {
+    uint32_t b[4], e[4];
+    Op op[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
       {
-      const Op op = ops[q];
-      if (op.w & OP_READ)
-        {
-        win[(uint32_t)op.w - i0] = op.pay;
-        found = 1;
-        }
+      b[k] = run[o + 64u * k][0] + l16;
+      e[k] = run[o + 64u * k][1];
+      if (b[k] < e[k])
+        op[k] = ops[b[k]];
       }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      for (uint32_t q = b[k]; q < e[k]; q += 16u)
+        {
+        const Op x = q == b[k] ? op[k] : ops[q];
+        if (x.w & OP_READ)
+          {
+          win[(uint32_t)x.w - i0] = x.pay;
+          found = 1;
+          }
+        }
     }
   if (!__syncthreads_or(found))
     return;
@@ -532,7 +560,7 @@ EncPlan plan_for(uint32_t n, int arity)
   const size_t cells = (size_t)arity * OWNERS * p.ntiles + 1;
   p.hist = take(4 * cells);
   p.res = take(64);
-  p.sink = take(sizeof(Op) * (size_t)arity * OWNERS);
+  p.sink = take(8 * sizeof(Op) * (size_t)arity * OWNERS);
   // the owners' lists of one table, or (skewed streams) keys, sorted keys, sorted indices of one component
   const size_t lists = 2 * align_up(sizeof(Op) * (size_t)n * arity + 16, 256), sorts = 3 * align_up(4 * (size_t)n + 16, 256);
   p.area_bytes = lists > sorts ? lists : sorts;
