@@ -417,10 +417,14 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
 //   * the UNIFORM step (the step before had no run start and only exact hits: the rows of a grid, flat parts of a scan) checks
 //     that this one is the same (9 vector instructions) and stores a constant pattern; the table is brought up to date when such
 //     a stretch ends (SW_LEAVE).  A general step without run starts looks whether the next one may try (SW_ENTRY);
-//   * the staging area leaves in blocks of 512 bytes - at most one per step, so there is no second case: the two LDS reads are
-//     issued at the end of every step, used at the start of the next under exec = "a block is full", no branch;
-//   * EVERY step issues exactly four vector memory instructions (prefetch load, block store, two record stores; the stores run
-//     with exec = 0 when there is nothing to store), so "the load of this step has arrived" is exactly s_waitcnt vmcnt(4 * 6);
+//   * the staging area leaves in blocks of 512 bytes - at most one per step, so there is no second case.  Whether a block is full
+//     is a scalar compare at the end of the step (the staging position is kept as an LDS address); only then are the two LDS reads
+//     issued and the bookkeeping done, and the stores follow at the start of the next step under exec = "a block is pending";
+//   * loads and stores share one in-order queue.  EVERY step issues its prefetch load and the block store (exec = 0 when no block is
+//     pending; the four-step piece issues four loads and four stores), so when step j waits, at least twelve memory instructions are
+//     younger than the load of six steps ago that it needs: s_waitcnt vmcnt(12) guarantees that load.  The two record stores are
+//     issued only where there is a record; they make the wait a little longer than necessary.  (The variant in which every step
+//     issued them too, with exec = 0, and waited for exactly vmcnt(24), was slower: 326 against 276 us.)
 //   * eight value registers rotate (value of the step, of the step before, six loads in flight): the loop body is eight steps;
 //   * a record is 15 vector instructions (the header's position comes from two DPP moves, not from a cross-lane read).
 // Hazards the assembler does not see (gfx950): a DPP source written by a vector instruction needs two instructions in between,
@@ -1837,8 +1841,6 @@ int launch_fpc32_sweep(const uint32_t* d_src, uint32_t n, int arity, const Plan&
   const uint32_t sabotage = 0u;
 #endif
   constexpr bool HOOK = SWEEP_HOOK;
-#ifdef TRICO_SWEEP_DIAG
-#endif
   if (use_asm)
     hipLaunchKernelGGL((k_fpc32_sweep<HOOK, true>), dim3(p.S + G), dim3(threads), lds, st, d_src, n, arity, p.L, p.S, outT,
                        slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, sabotage, seed, gslots, grecs, gmeta, diag, rblocks);
