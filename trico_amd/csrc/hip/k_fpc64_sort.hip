@@ -544,7 +544,7 @@ uint32_t part_tile(uint32_t n)
   return t < 1024u ? 1024u : (t > HOME_TILE_MAX ? HOME_TILE_MAX : t);
   }
 
-struct EncPlan { size_t pred1, pred2, gsz, goff, gstride, hist, res, sink, area, area_bytes, tmp, tmp_bytes, total; uint32_t tile, ntiles; };
+struct EncPlan { size_t pred1, pred2, gsz, goff, gstride, hist[2], res, sink, area[3], tmp, tmp_bytes, total; uint32_t tile, ntiles; };
 
 EncPlan plan_for(uint32_t n, int arity)
   {
@@ -558,13 +558,14 @@ EncPlan plan_for(uint32_t n, int arity)
   p.gstride = align_up(ng + 4, 64);
   p.gsz = take(4 * p.gstride * arity); p.goff = take(4 * p.gstride * arity);
   const size_t cells = (size_t)arity * OWNERS * p.ntiles + 1;
-  p.hist = take(4 * cells);
+  p.hist[0] = take(4 * cells);
+  p.hist[1] = take(4 * cells);
   p.res = take(64);
-  p.sink = take(8 * sizeof(Op) * (size_t)arity * OWNERS);
-  // the owners' lists of one table, or (skewed streams) keys, sorted keys, sorted indices of one component
-  const size_t lists = 2 * align_up(sizeof(Op) * (size_t)n * arity + 16, 256), sorts = 3 * align_up(4 * (size_t)n + 16, 256);
-  p.area_bytes = lists > sorts ? lists : sorts;
-  p.area = take(p.area_bytes);
+  p.sink = take(2 * 8 * sizeof(Op) * (size_t)arity * OWNERS);
+  // three areas of one table's operations each: FCM operations / FCM results / DFCM operations, DFCM results where the FCM operations
+  // were; a table that is sorted keeps keys, sorted keys and sorted indices of one component in the first
+  for (int i = 0; i < 3; ++i)
+    p.area[i] = take(sizeof(Op) * (size_t)n * arity);
   const size_t sort_bytes = sort_workspace(n), scan_bytes = scan_workspace((uint32_t)(cells > ng ? cells : ng));
   p.tmp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
   p.tmp = take(p.tmp_bytes);
@@ -582,58 +583,152 @@ uint32_t walk_limit(uint32_t n, int arity)
   return even > 262144ull ? (uint32_t)(even > 0xffffffffull ? 0xffffffffull : even) : 262144u;
   }
 
+// operations per list of table T: count matrix, its scan, the longest list -> res[0] (and the number of operations -> res[1])
 template <int T>
-int table_reads(const u64* src, uint32_t n, int arity, const EncPlan& p, uint8_t* d_ws, u64* pred, hipStream_t st)
+int table_count(const u64* src, uint32_t n, int arity, const EncPlan& p, uint32_t* hist, uint32_t* res, uint8_t* tmp, size_t tmp_bytes, hipStream_t st)
   {
-  uint32_t* hist = (uint32_t*)(d_ws + p.hist);
-  uint32_t* res = (uint32_t*)(d_ws + p.res);
   const uint32_t lists = (uint32_t)arity * OWNERS;
   const size_t cells = (size_t)lists * p.ntiles + 1;
-  bool walk = (uint64_t)n * (uint64_t)arity < 0xffffffffull && walk_limit(n, arity) != 0u;      // (list positions are 32 bits)
-  if (walk)
+  const unsigned blocks = (p.ntiles + 3u) / 4u;
+  hipLaunchKernelGGL(k64_part_hist<T>, dim3(blocks), dim3(256), 0, st, src, n, arity, p.tile, p.ntiles, hist);
+  if (!exclusive_scan_u32(hist, hist, (uint32_t)cells, tmp, tmp_bytes))
+    return 0;
+  hipLaunchKernelGGL(k64_list_max, dim3((lists + 255u) / 256u), dim3(256), 0, st, hist, lists, p.ntiles, res);
+  return 1;
+  }
+
+// the lists of table T written, walked, the results taken home to pred.  Events (each may be null): recorded behind the scatter and
+// behind the walk; waited for in front of the walk and in front of the way home.
+struct Marks { hipEvent_t scattered, walked, before_walk, before_home; };
+template <int T>
+int table_walk(const u64* src, uint32_t n, int arity, const EncPlan& p, const uint32_t* hist, Op* ops, Op* done, Op* sink, u64* pred,
+               hipStream_t st, const Marks& m)
+  {
+  static const bool claimed = hipFuncSetAttribute((const void*)k64_home, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(HOME_TILE_MAX * 8u)) == hipSuccess;
+  if (!claimed)
     {
-    const unsigned blocks = (p.ntiles + 3u) / 4u;
-    hipLaunchKernelGGL(k64_part_hist<T>, dim3(blocks), dim3(256), 0, st, src, n, arity, p.tile, p.ntiles, hist);
-    if (!exclusive_scan_u32(hist, hist, (uint32_t)cells, d_ws + p.tmp, p.tmp_bytes))
-      return 0;
-    if (!hip_ok(hipMemsetAsync(res, 0, 8, st), "fpc64 encoder: memset"))
-      return 0;
-    hipLaunchKernelGGL(k64_list_max, dim3((lists + 255u) / 256u), dim3(256), 0, st, hist, lists, p.ntiles, res);
-    uint32_t h[2] = { 0, 0 };
-    if (!hip_ok(hipMemcpyAsync(h, res, 8, hipMemcpyDeviceToHost, st), "fpc64 encoder: list lengths") ||
-        !hip_ok(hipStreamSynchronize(st), "fpc64 encoder: list lengths"))
-      return 0;
-    walk = h[0] <= walk_limit(n, arity);
-    if (walk)
-      {
-      Op* ops = (Op*)(d_ws + p.area);
-      hipLaunchKernelGGL(k64_part_scatter<T>, dim3(blocks), dim3(256), 0, st, src, n, arity, p.tile, p.ntiles, hist, ops);
-      Op* done = (Op*)(d_ws + p.area + align_up(sizeof(Op) * (size_t)n * arity + 16, 256));
-      hipLaunchKernelGGL(k64_walk<T>, dim3(lists), dim3(64), 0, st, ops, done, hist, p.ntiles, (Op*)(d_ws + p.sink));
-      static const bool claimed = hipFuncSetAttribute((const void*)k64_home, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(HOME_TILE_MAX * 8u)) == hipSuccess;
-      if (!claimed)
-        {
-        set_error("fpc64 throughput encoder: cannot claim 128 KiB of LDS");
-        return 0;
-        }
-      hipLaunchKernelGGL(k64_home, dim3(p.ntiles, arity), dim3(1024), p.tile * 8u, st, done, hist, p.ntiles, p.tile, n, pred);
-      }
+    set_error("fpc64 throughput encoder: cannot claim 128 KiB of LDS");
+    return 0;
     }
-  if (!walk)
+  const uint32_t lists = (uint32_t)arity * OWNERS;
+  const unsigned blocks = (p.ntiles + 3u) / 4u;
+  hipLaunchKernelGGL(k64_part_scatter<T>, dim3(blocks), dim3(256), 0, st, src, n, arity, p.tile, p.ntiles, hist, ops);
+  if (m.scattered && !hip_ok(hipEventRecord(m.scattered, st), "hipEventRecord"))
+    return 0;
+  if (m.before_walk && !hip_ok(hipStreamWaitEvent(st, m.before_walk, 0), "hipStreamWaitEvent"))
+    return 0;
+  hipLaunchKernelGGL(k64_walk<T>, dim3(lists), dim3(64), 0, st, ops, done, hist, p.ntiles, sink);
+  if (m.walked && !hip_ok(hipEventRecord(m.walked, st), "hipEventRecord"))
+    return 0;
+  if (m.before_home && !hip_ok(hipStreamWaitEvent(st, m.before_home, 0), "hipStreamWaitEvent"))
+    return 0;
+  hipLaunchKernelGGL(k64_home, dim3(p.ntiles, arity), dim3(1024), p.tile * 8u, st, done, hist, p.ntiles, p.tile, n, pred);
+  return 1;
+  }
+
+// the path of round 2 for table T (current_stream()): sorted (hash, index) pairs, predecessor = table read
+template <int T>
+int table_sort(const u64* src, uint32_t n, int arity, const EncPlan& p, uint8_t* d_ws, u64* pred)
+  {
+  hipStream_t st = current_stream();
+  const size_t q = align_up(4 * (size_t)n + 16, 256);
+  uint32_t* k = (uint32_t*)(d_ws + p.area[0]); uint32_t* ks = (uint32_t*)(d_ws + p.area[0] + q); uint32_t* vs = (uint32_t*)(d_ws + p.area[0] + 2 * q);
+  const unsigned vb = (n + 255u) / 256u;
+  for (int c = 0; c < arity; ++c)
     {
-    const size_t q = align_up(4 * (size_t)n + 16, 256);
-    uint32_t* k = (uint32_t*)(d_ws + p.area); uint32_t* ks = (uint32_t*)(d_ws + p.area + q); uint32_t* vs = (uint32_t*)(d_ws + p.area + 2 * q);
-    const unsigned vb = (n + 255u) / 256u;
-    for (int c = 0; c < arity; ++c)
-      {
-      hipLaunchKernelGGL(k64_keys<T>, dim3(vb), dim3(256), 0, st, src, n, arity, c, k);
-      // values = identity: the sorted value of position p is the index of the p-th value in (hash, index) order
-      if (!radix_sort_pairs(k, nullptr, ks, vs, n, 20, d_ws + p.tmp, p.tmp_bytes))
-        return 0;
-      hipLaunchKernelGGL(k64_pred, dim3(vb), dim3(256), 0, st, ks, vs, src, n, arity, c, T, pred + (size_t)c * n);
-      }
+    hipLaunchKernelGGL(k64_keys<T>, dim3(vb), dim3(256), 0, st, src, n, arity, c, k);
+    // values = identity: the sorted value of position p is the index of the p-th value in (hash, index) order
+    if (!radix_sort_pairs(k, nullptr, ks, vs, n, 20, d_ws + p.tmp, p.tmp_bytes))
+      return 0;
+    hipLaunchKernelGGL(k64_pred, dim3(vb), dim3(256), 0, st, ks, vs, src, n, arity, c, T, pred + (size_t)c * n);
     }
   return 1;
+  }
+
+// A second stream per host thread.  What a table costs is four kernels of different kinds: the count and the scatter are bound by
+// memory and instruction issue, the walk is 3072 chains of rounds with the machine mostly waiting, the way home wants the LDS.  With
+// both tables walked, the FCM table's walk runs beside the DFCM table's scatter, and its way home beside the DFCM table's walk.
+struct Side
+  {
+  hipStream_t st = nullptr;
+  hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+  int device = -1;
+  bool ok = false, tried = false;
+  bool ready()
+    {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess)
+      return false;
+    if (tried)
+      return ok && dev == device;
+    tried = true;
+    device = dev;
+    ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < 4; ++i)
+      ok = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok)
+      (void)hipGetLastError();
+    return ok;
+    }
+  };
+
+int both_tables(const u64* src, uint32_t n, int arity, const EncPlan& p, uint8_t* d_ws, u64* pred1, u64* pred2)
+  {
+  hipStream_t A = current_stream();
+  uint32_t* hist0 = (uint32_t*)(d_ws + p.hist[0]); uint32_t* hist1 = (uint32_t*)(d_ws + p.hist[1]);
+  uint32_t* res = (uint32_t*)(d_ws + p.res);
+  Op* X = (Op*)(d_ws + p.area[0]); Op* Y = (Op*)(d_ws + p.area[1]); Op* Z = (Op*)(d_ws + p.area[2]);
+  Op* sink0 = (Op*)(d_ws + p.sink); Op* sink1 = sink0 + 8u * arity * OWNERS;
+  bool walk0 = false, walk1 = false;
+  if ((uint64_t)n * (uint64_t)arity < 0xffffffffull && walk_limit(n, arity) != 0u)      // (list positions are 32 bits)
+    {
+    // both tables counted, then the host waits once for the two longest lists
+    uint32_t h[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (!hip_ok(hipMemsetAsync(res, 0, 32, A), "fpc64 encoder: memset") ||
+        !table_count<0>(src, n, arity, p, hist0, res, d_ws + p.tmp, p.tmp_bytes, A) ||
+        !table_count<1>(src, n, arity, p, hist1, res + 4, d_ws + p.tmp, p.tmp_bytes, A) ||
+        !hip_ok(hipMemcpyAsync(h, res, 32, hipMemcpyDeviceToHost, A), "fpc64 encoder: list lengths") ||
+        !hip_ok(hipStreamSynchronize(A), "fpc64 encoder: list lengths"))
+      return 0;
+    walk0 = h[0] <= walk_limit(n, arity);
+    walk1 = h[4] <= walk_limit(n, arity);
+    }
+  static thread_local Side side;
+  const Marks none = { nullptr, nullptr, nullptr, nullptr };
+  if (!(walk0 && walk1 && side.ready()))
+    {
+    // one after the other on this stream (the DFCM table's results go where the FCM table's operations were)
+    if (!(walk0 ? table_walk<0>(src, n, arity, p, hist0, X, Y, sink0, pred1, A, none) : table_sort<0>(src, n, arity, p, d_ws, pred1)))
+      return 0;
+    return walk1 ? table_walk<1>(src, n, arity, p, hist1, Z, X, sink1, pred2, A, none) : table_sort<1>(src, n, arity, p, d_ws, pred2);
+    }
+  hipStream_t B = side.st;
+  hipEvent_t scattered0 = side.ev[0], walked0 = side.ev[1], scattered1 = side.ev[2], home1 = side.ev[3];
+  // this stream: scatter 0, walk 0, (scatter 1 done) home 0; the side stream: (scatter 0 done) scatter 1, (walk 0 done) walk 1, home 1
+  // (the launches are issued in the order the device should start them)
+  int ok = 1;
+  const uint32_t lists = (uint32_t)arity * OWNERS;
+  const unsigned blocks = (p.ntiles + 3u) / 4u;
+  static const bool claimed = hipFuncSetAttribute((const void*)k64_home, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(HOME_TILE_MAX * 8u)) == hipSuccess;
+  if (!claimed)
+    {
+    set_error("fpc64 throughput encoder: cannot claim 128 KiB of LDS");
+    return 0;
+    }
+  hipLaunchKernelGGL(k64_part_scatter<0>, dim3(blocks), dim3(256), 0, A, src, n, arity, p.tile, p.ntiles, hist0, X);
+  ok = ok && hip_ok(hipEventRecord(scattered0, A), "hipEventRecord") && hip_ok(hipStreamWaitEvent(B, scattered0, 0), "hipStreamWaitEvent");
+  hipLaunchKernelGGL(k64_walk<0>, dim3(lists), dim3(64), 0, A, X, Y, hist0, p.ntiles, sink0);
+  ok = ok && hip_ok(hipEventRecord(walked0, A), "hipEventRecord");
+  hipLaunchKernelGGL(k64_part_scatter<1>, dim3(blocks), dim3(256), 0, B, src, n, arity, p.tile, p.ntiles, hist1, Z);
+  ok = ok && hip_ok(hipEventRecord(scattered1, B), "hipEventRecord") && hip_ok(hipStreamWaitEvent(A, scattered1, 0), "hipStreamWaitEvent");
+  hipLaunchKernelGGL(k64_home, dim3(p.ntiles, arity), dim3(1024), p.tile * 8u, A, Y, hist0, p.ntiles, p.tile, n, pred1);
+  ok = ok && hip_ok(hipStreamWaitEvent(B, walked0, 0), "hipStreamWaitEvent");      // (its results go where the FCM operations were)
+  hipLaunchKernelGGL(k64_walk<1>, dim3(lists), dim3(64), 0, B, Z, X, hist1, p.ntiles, sink1);
+  hipLaunchKernelGGL(k64_home, dim3(p.ntiles, arity), dim3(1024), p.tile * 8u, B, X, hist1, p.ntiles, p.tile, n, pred2);
+  ok = ok && hip_ok(hipEventRecord(home1, B), "hipEventRecord") && hip_ok(hipStreamWaitEvent(A, home1, 0), "hipStreamWaitEvent");
+  if (!ok)
+    (void)hipStreamSynchronize(B);
+  return ok;
   }
 
 } // namespace
@@ -675,7 +770,7 @@ int launch_fpc64_encode_sorted(const void* d_src, uint32_t n, int arity, uint8_t
   const unsigned gb = (ng + 255u) / 256u, tiles = (ng + TILE_G - 1) / TILE_G;
   u64* pred1 = (u64*)(d_ws + p.pred1); u64* pred2 = (u64*)(d_ws + p.pred2);
   uint32_t* gsz = (uint32_t*)(d_ws + p.gsz); uint32_t* goff = (uint32_t*)(d_ws + p.goff);
-  if (!table_reads<0>(src, n, arity, p, d_ws, pred1, st) || !table_reads<1>(src, n, arity, p, d_ws, pred2, st))
+  if (!both_tables(src, n, arity, p, d_ws, pred1, pred2))
     return 0;
   hipLaunchKernelGGL(k64_sizes, dim3(gb), dim3(256), 0, st, src, n, arity, pred1, pred2, ng, gsz, p.gstride);
   for (int c = 0; c < arity; ++c)
