@@ -188,7 +188,7 @@ def encoder_variants(W, H):
             except Exception as e:      # noqa: BLE001
                 rows.append({"mesh": mesh, "coder": coder, "error": repr(e)[:200]})
     return {"what": "float-vertex encoder alone on both meshes: the library's choice (one sweep) against the two-sweep coders it also "
-                    "contains (environment switches, measurements only); traffic of the default on both meshes: profiles/r04_*",
+                    "contains (environment switches, measurements only); traffic of the default on both meshes: profiles/r05_fpc32_encode_hbm_traffic_pmc.txt",
             "rows": rows}
 
 
@@ -781,10 +781,18 @@ def config3_block(api, meshgen, dev, W, H, grid_dev=None, with_cpu=True):
     dbl_pay = sum(comp_sizes[0]) + sum(comp_sizes[1])
     if enc64_ms:
         gb = (dbl_raw + dbl_pay) / (enc64_ms * 1e-3) / 1e9
-        roof = {"kernel": "double encoder (k_fpc64_sort.hip over k_sort.hip: hashes, two radix sorts, predictions, codes, scan, pack), the two vec3 "
-                          "double streams of the mesh", "bound": "hbm", "achieved": round(gb, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(gb / HBM_PEAK_GBPS, 5), "traffic": None, "algorithmic_bytes": dbl_raw + dbl_pay, "launch_ms": round(enc64_ms, 3),
-                "what_bounds_it": "about 25 passes over 12 bytes per value and table: the sorts move (hash, index) pairs, the predictions gather and scatter 8 bytes at random"}
+        # traffic: not collected live; the committed PMC summary of the same two streams at full size (profiles/r05_fpc64_encode_hbm_traffic_pmc.txt:
+        # FETCH_SIZE x 2 + WRITE_SIZE over the kernels of both streams), scaled by the value count when the mesh is another
+        full = 50_000_000
+        roof = {"kernel": "double encoder (k_fpc64_sort.hip: runs of equal hashes, 1024 owners per component and table, operations partitioned "
+                          "into their lists, LDS walk, results home by tile, codes, scan, pack), the two vec3 double streams of the mesh",
+                "bound": "hbm", "achieved": round(gb, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(gb / HBM_PEAK_GBPS, 5), "traffic": int(65.4e9 * n / full),
+                "traffic_source": "profiles/r05_fpc64_encode_hbm_traffic_pmc.txt (separate --pmc passes over tools/perf_fpc64.py, not this run)",
+                "algorithmic_bytes": dbl_raw + dbl_pay, "launch_ms": round(enc64_ms, 3),
+                "what_bounds_it": "memory traffic 18 x the algorithmic bytes at ~3 TB/s: a table operation is 16 bytes written into one of 3072 lists per "
+                                  "wave (no line is written whole: the counters show twice the bytes), read by the walk, written as a result, read "
+                                  "again by tile; predictions are written once and read by the size and the pack kernel"}
     twin = None
     if with_cpu:
         from oracle import oracle as O

@@ -5,7 +5,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(set)
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(k_\w+|__amd\w+)", r["Kernel_Name"]); k = m.group(1) if m else r["Kernel_Name"][:40]
+        m = re.search(r"(k\d*_\w+(<[\w, ]+>)?|__amd\w+)", r["Kernel_Name"]); k = m.group(1) if m else r["Kernel_Name"][:40]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[k].add(r["Dispatch_Id"])
 for k in acc:
