@@ -85,3 +85,35 @@ def test_one_long_list_takes_the_sorting_path(api, monkeypatch):
     assert write_archive(api, streams) == want
     monkeypatch.setenv("TRICO_FPC64_WALK_MAX", "4000000")         # ... and walked all the same
     assert write_archive(api, streams) == want
+
+
+def test_threads_write_double_archives_at_the_same_time(api):
+    """One archive handle per thread (the reference's threading model), five threads: every thread's encoder has its own side stream,
+    the host arrays (14 MB and more each) go through the one ring of pinned chunks in turns.  Bytes as the oracle's, three times over."""
+    import threading
+    kinds = ["noisy", "few", "steps", "quantised", "ramp"]
+    sets = []
+    for k, kind in enumerate(kinds):
+        n = 200003 + 40000 * k
+        rng = np.random.default_rng(77 + k)
+        a3 = np.empty(3 * n)
+        for c in range(3):
+            a3[c::3] = _data(kind if c != 1 else "noisy", n, rng)
+        streams = [("vertices_double", a3, n), ("vertex_normals_double", a3[::-1].copy(), n)]
+        sets.append((streams, oracle_archive(streams)))
+    gate = threading.Barrier(len(sets))
+    bad = []
+
+    def work(k):
+        streams, want = sets[k]
+        gate.wait()
+        for _ in range(3):
+            if write_archive(api, streams) != want:
+                bad.append(k)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(sets))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not bad, bad
