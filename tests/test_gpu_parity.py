@@ -448,7 +448,8 @@ def test_lz4_short_sequence_regimes(api, kind, n):
     assert back.tobytes() == data.tobytes()
 
 
-@pytest.mark.parametrize("kind", ["period30k", "period_drift", "two_regimes", "random_then_zero", "short_sequences", "ramp_u32_plane"])
+@pytest.mark.parametrize("kind", ["period30k", "period_drift", "two_regimes", "random_then_zero", "short_sequences", "ramp_u32_plane",
+                                  "long_runs", "many_long_runs", "open_match_ends", "long_period"])
 def test_lz4_chunked_compressor_regimes(api, kind):
     """planes above the 4 MiB threshold of the chunk-speculative compressor (k_lz4_chunked.hip): long periodic matches whose
     speculative chunks get rejected (parallel alternative parses, adoption by the stitch walk), literal runs above 1 MiB (the
@@ -478,6 +479,34 @@ def test_lz4_chunked_compressor_regimes(api, kind):
     elif kind == "short_sequences":
         steps = rng.integers(-1, 2, n)
         data = (np.cumsum(steps) & 31).astype(np.uint8)
+    elif kind == "long_runs":
+        # constant runs of 0.3 .. 3.5 MiB: matches longer than a chunk are left open by the parse and counted by k_lz4_extend, several
+        # per plane, some ending inside the 1 MiB a wave counts itself
+        parts, pos = [], 0
+        while pos < n:
+            ln = int(rng.integers(300000, 3500000))
+            parts.append(np.full(ln, int(rng.integers(0, 256)), np.uint8))
+            pos += ln
+        data = np.concatenate(parts)[:n].copy()
+    elif kind == "many_long_runs":
+        # fifty open matches in one plane: every workgroup of k_lz4_extend must hold the same list of them, in the same order
+        parts = [np.full(int(rng.integers(1150000, 1700000)), v % 251, np.uint8) for v in range(50)]
+        data = np.concatenate(parts)
+        n = data.size
+    elif kind == "open_match_ends":
+        # periodic stretches that end 0, 1, 15, 16, 17 ... bytes behind the point where the parse leaves the match open, and around
+        # the 64 KiB slices k_lz4_extend counts in
+        parts = []
+        for delta in (0, 1, 3, 4, 5, 15, 16, 17, 65535, 65536, 65537):
+            per = rng.integers(0, 256, 777, dtype=np.uint8)
+            ln = (1 << 20) + 777 + delta
+            parts.append(np.tile(per, ln // 777 + 1)[:ln])
+            parts.append(rng.integers(0, 256, 40, dtype=np.uint8))
+        data = np.concatenate(parts)
+        n = data.size
+    elif kind == "long_period":
+        # one period of 40,000 bytes for the whole plane: one open match with a large offset, running to the block's last bytes
+        data = np.tile(rng.integers(0, 256, 40000, dtype=np.uint8), n // 40000 + 1)[:n].copy()
     else:
         data = (np.arange(n, dtype=np.uint64) * 3 // 7).astype(np.uint8)
     data = np.ascontiguousarray(data)
@@ -491,6 +520,19 @@ def test_lz4_chunked_compressor_regimes(api, kind):
     assert r.read("attributes_uint8", back) == 1, api.last_error()
     r.close()
     assert back.tobytes() == data.tobytes()
+
+
+def test_u64_indices_with_empty_upper_planes(api):
+    """triangles_long of a mesh with fewer than 2^24 vertices: five of the eight byte planes are zeros (one match per plane, left open by
+    the parse of chunk 0 and counted by the whole device), the others as for u32 indices"""
+    nt = 1_600_000
+    rng = np.random.default_rng(31)
+    base = np.arange(3 * nt, dtype=np.uint64) // 3
+    t = (base + rng.integers(0, 50, 3 * nt).astype(np.uint64)) % np.uint64(900_000)
+    streams = [("triangles_long", t, nt)]
+    got = write_archive(api, streams)
+    assert got == oracle_archive(streams)
+    read_back(api, got, streams)
 
 
 @pytest.mark.parametrize("kind", ["ramp", "ramp_across_class", "ramp_wraps_zero", "big_stride", "constant", "constant_then_step",

@@ -45,11 +45,12 @@ __device__ __forceinline__ uint32_t hash5(const uint8_t* p) { return (uint32_t)(
 
 struct Desc { uint32_t lit, ml, off; };    // literal run, match length incl. MINMATCH (0 = final run), offset
 
-enum { END_NONE = 0, END_MATCH = 1, END_FINAL = 2 };
+enum { END_NONE = 0, END_MATCH = 1, END_FINAL = 2, END_OPEN = 3 };   // END_OPEN: the last descriptor's match is still being counted (k_lz4_extend)
+constexpr uint32_t OPEN_ML = 0xffffffffu;
 struct Meta
   {
   uint32_t snap_valid, snap_ip;            // first match end at or after the chunk start (speculative chunks)
-  uint32_t end_kind, end_ip;               // END_MATCH: state after a match ended at end_ip; END_FINAL: block finished
+  uint32_t end_kind, end_ip;               // END_MATCH: state after a match ended at end_ip; END_FINAL: block finished; END_OPEN: end_ip = where the open match starts
   uint32_t ndesc;
   uint32_t accepted;                        // set by the stitch pass
   uint32_t first_in;                        // input position where this chunk's first descriptor starts
@@ -170,12 +171,15 @@ __device__ __forceinline__ uint32_t wave_count(const uint8_t* __restrict__ a, co
 //   fresh: chunk 0 start (lz4.c:865-867: insert position 0, ip = 1)
 //   emit_from_start: record descriptors from the first sequence on (chunk 0, re-parse); otherwise wait for
 //                    the first match end >= c_lo, snapshot there, then record
+//   big (>= the chunk's size, 0: none): a recorded match that is still running after `big` bytes is not counted to its end by this
+//                    wave - it ends beyond c_hi, so it is the parse's last sequence whatever its length: the descriptor gets OPEN_ML,
+//                    the table is saved as for any match end and the whole device counts the rest (k_lz4_extend, END_OPEN)
 // Stops at the first match end >= c_hi (END_MATCH) or at the end of the block (END_FINAL).
 template <int NW>
 __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t* tab, uint8_t* dup, uint32_t ip0, bool start_match_end, bool fresh,
                           bool emit_from_start, uint32_t c_lo, uint32_t c_hi, Desc* __restrict__ desc, uint32_t dcap,
                           Meta* __restrict__ meta, uint32_t* __restrict__ snapT, uint32_t* __restrict__ endT, int lane, int wave = 0,
-                          uint32_t* xch = nullptr)
+                          uint32_t* xch = nullptr, uint32_t big = 0u)
   {
   const bool writer = lane == 0 && wave == 0;            // descriptors and chunk meta: one writer (NW > 1: all waves hold the same values)
   const uint32_t mfl1 = n - 11u, mlim = n - 5u;                                    // lz4.c:825-826 (n >= 13 here)
@@ -437,9 +441,21 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
       const uint32_t cap = c_hi - (ip + 4u);
       if (cap < limit) limit = cap;
       }
+    const bool may_open = emit && big != 0u && big < limit;
+    if (may_open)
+      limit = big;
     const uint32_t m = (fast && fast_extra < limit) ? fast_extra : wave_count<NW>(src + ip + 4u, src + cand + 4u, limit, lane, wave, xch);
     if (!emit && limit < room && m >= limit)
       break;                                                                       // ran past c_hi during warm-up
+    if (may_open && m >= limit)
+      {
+      // still equal after `big` bytes
+      if (nd < dcap) { if (writer) { desc[nd].lit = ip - anchor; desc[nd].ml = OPEN_ML; desc[nd].off = ip - cand; } ++nd; }
+      else { overflow = true; break; }
+      end_kind = END_OPEN;
+      end_ip = ip;
+      break;
+      }
     if (emit)
       {
       if (nd < dcap) { if (writer) { desc[nd].lit = ip - anchor; desc[nd].ml = m + 4u; desc[nd].off = ip - cand; } ++nd; }
@@ -450,7 +466,7 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
     at_match_end = true;
     }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  if (end_kind == END_MATCH)
+  if (end_kind == END_MATCH || end_kind == END_OPEN)
     for (int i = lane; i < 4096; i += 64)
       endT[i] = tab[i];
   if (lane == 0)
@@ -464,6 +480,9 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
 
 struct Geom { uint32_t n, chunk, warm, K, dcap; size_t plane_stride; uint32_t alt_rounds, alt_dcap, xchg; };   // xchg: search rounds through one LDS exchange (lz4_parse)
 constexpr uint32_t ALT_R = 4;             // alternative parses kept per chunk (k_lz4_alt)
+// equal bytes after which a recorded match of the parse pass is left to k_lz4_extend: at least a chunk (so that the match is the
+// chunk's last sequence), at least 1 MiB (what a wave counts in ~0.1 ms)
+__host__ __device__ inline uint32_t open_after(const Geom& g) { return g.chunk > (1u << 20) ? g.chunk : (1u << 20); }
 
 __global__ void __launch_bounds__(64) k_lz4_parse(const uint8_t* __restrict__ planes, Geom g, Desc* __restrict__ descs, Meta* __restrict__ metas,
                                                   uint32_t* __restrict__ snapTs, uint32_t* __restrict__ endTs)
@@ -486,7 +505,139 @@ __global__ void __launch_bounds__(64) k_lz4_parse(const uint8_t* __restrict__ pl
   const uint32_t c_lo = k * g.chunk;
   const uint32_t c_hi = (k + 1u == g.K) ? 0xffffffffu : c_lo + g.chunk;
   lz4_parse<1>(src, g.n, tab, g.xchg ? nullptr : dup, k == 0 ? 0u : c_lo - g.warm, false, k == 0, k == 0, c_lo, c_hi, descs + ck * g.dcap, g.dcap, meta,
-            snapTs + ck * 4096, endTs + ck * 4096, lane);
+            snapTs + ck * 4096, endTs + ck * 4096, lane, 0, nullptr, open_after(g));
+  }
+
+// ---- matches longer than a chunk: counted by the whole device ------------------------------------------------------------------
+// One wave counts equal bytes at ~8 GB/s (16 KiB per round trip); the upper byte planes of mesh indices are a handful of runs of
+// tens to hundreds of MB (a plane of zeros is ONE match of 300 MB: 36 ms for the wave of chunk 0, three quarters of the parse pass
+// on u64 indices).  A parse that meets such a match stops with END_OPEN (lz4_parse); here the workgroups of a plane share its open
+// matches: each match gets an equal share of them, a share takes the 64 KiB slices behind the counted part in turns and stops at
+// the first slice that starts behind the best end known (atomicMin on the descriptor's length).  k_lz4_extend_done turns the result
+// into the END_MATCH state the parse would have left.
+constexpr uint32_t EXT_SLICE = 65536, EXT_G = 256;
+
+__global__ void __launch_bounds__(256) k_lz4_extend(const uint8_t* __restrict__ planes, Geom g, Desc* __restrict__ descs, const Meta* __restrict__ metas)
+  {
+  __shared__ uint32_t open_list[1024], nopen, wmin[4], known;
+  const uint32_t p = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint8_t* src = planes + (size_t)p * g.plane_stride;
+  const Meta* pm = metas + (size_t)p * g.K;
+  const uint32_t big = open_after(g), mlim = g.n - 5u;
+  for (uint32_t k0 = 0; k0 < g.K; k0 += 1024u)                   // (a plane has a few hundred chunks: one batch)
+    {
+    // the open chunks of this batch in chunk order - the same list in every workgroup, which is what shares the work out
+    {
+    uint32_t mine[4], cnt = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; ++q)
+      {
+      const uint32_t k = k0 + 4u * tid + q;
+      mine[q] = (k < g.K && pm[k].end_kind == END_OPEN) ? 1u : 0u;
+      cnt += mine[q];
+      }
+    uint32_t incl = cnt;                                        // inclusive scan over the wave, then over the four waves
+#pragma unroll
+    for (int s2 = 1; s2 < 64; s2 <<= 1)
+      {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, s2);
+      if ((int)lane >= s2) incl += up;
+      }
+    if (lane == 63u) wmin[wave] = incl;
+    __syncthreads();
+    uint32_t at = incl - cnt;
+    for (uint32_t w2 = 0; w2 < wave; ++w2)
+      at += wmin[w2];
+    if (tid == 255u) nopen = at + cnt;
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; ++q)
+      if (mine[q])
+        open_list[at++] = k0 + 4u * tid + q;
+    __syncthreads();
+    }
+    const uint32_t C = nopen;
+    if (C != 0u)
+      {
+      const uint32_t share = C <= gridDim.x ? gridDim.x / C : 1u;                  // workgroups per open match
+      for (uint32_t i = blockIdx.x / share; i < C; i += (gridDim.x + share - 1u) / share)
+        {
+        if (C <= gridDim.x && blockIdx.x >= C * share)
+          break;                                                                    // (the remainder of the division has nothing to do)
+        const uint32_t k = open_list[i], rank = blockIdx.x % share;
+        const size_t ck = (size_t)p * g.K + k;
+        Desc* d = descs + ck * g.dcap + (pm[k].ndesc - 1u);
+        const uint32_t ip = pm[k].end_ip, off = d->off;
+        const uint8_t* a = src + ip + 4u;
+        const uint8_t* b = a - off;
+        const uint32_t room = mlim - (ip + 4u);                                     // equal bytes the match may have behind its first four
+        for (uint32_t sl = rank;; sl += share)
+          {
+          const uint64_t o0 = (uint64_t)big + (uint64_t)sl * EXT_SLICE;
+          if (o0 >= room)
+            break;
+          if (tid == 0)
+            known = __hip_atomic_load(&d->ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __syncthreads();
+          const uint32_t best = known;                                              // (one value for the whole workgroup: it decides a barrier)
+          __syncthreads();
+          if (best != OPEN_ML && (uint64_t)best <= o0 + 4u)
+            break;                                                                  // the match ends before this slice
+          const uint32_t lo = (uint32_t)o0, hi = room - lo < EXT_SLICE ? room : lo + EXT_SLICE;
+          uint32_t first = 0xffffffffu;
+          for (uint32_t o = lo + 16u * tid; o < hi; o += 16u * 256u)
+            {
+            if (o + 16u <= hi)
+              {
+              const u32x4 x = ld128(a + o), y = ld128(b + o);
+              const uint64_t d0 = ((uint64_t)(x.y ^ y.y) << 32) | (x.x ^ y.x), d1 = ((uint64_t)(x.w ^ y.w) << 32) | (x.z ^ y.z);
+              if (d0 | d1)
+                first = min(first, o + (d0 ? (uint32_t)__builtin_ctzll(d0) >> 3 : 8u + ((uint32_t)__builtin_ctzll(d1) >> 3)));
+              }
+            else
+              {
+              uint32_t q = o;
+              while (q < hi && a[q] == b[q]) ++q;
+              if (q < hi)
+                first = min(first, q);
+              }
+            }
+#pragma unroll
+          for (int s2 = 32; s2 > 0; s2 >>= 1)
+            first = min(first, (uint32_t)__shfl_xor((int)first, s2));
+          if (lane == 0) wmin[wave] = first;
+          __syncthreads();
+          first = min(min(wmin[0], wmin[1]), min(wmin[2], wmin[3]));
+          __syncthreads();
+          if (first != 0xffffffffu)
+            {
+            if (tid == 0)
+              atomicMin(&d->ml, first + 4u);
+            break;
+            }
+          }
+        }
+      }
+    __syncthreads();
+    }
+  }
+
+// one thread per chunk: an open match that nobody found the end of runs to the limit; the chunk ends where the match does
+__global__ void __launch_bounds__(256) k_lz4_extend_done(Geom g, Desc* __restrict__ descs, Meta* __restrict__ metas)
+  {
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x, p = blockIdx.y;
+  if (k >= g.K)
+    return;
+  Meta* m = metas + (size_t)p * g.K + k;
+  if (m->end_kind != END_OPEN)
+    return;
+  Desc* d = descs + ((size_t)p * g.K + k) * g.dcap + (m->ndesc - 1u);
+  const uint32_t ip = m->end_ip, room = (g.n - 5u) - (ip + 4u);
+  uint32_t ml = d->ml;
+  if (ml == OPEN_ML || ml > room + 4u)
+    ml = room + 4u;
+  d->ml = ml;
+  m->end_ip = ip + ml;
+  m->end_kind = END_MATCH;
   }
 
 // ---- which geometry?  -----------------------------------------------------------------------------------------------------
@@ -1111,6 +1262,8 @@ int launch_lz4_encode_chunked(const uint8_t* d_planes, size_t plane_stride, uint
   uint32_t* cbytes = (uint32_t*)(d_ws + p.off_cbytes);
   uint32_t* coff = (uint32_t*)(d_ws + p.off_coff);
   hipLaunchKernelGGL(k_lz4_parse, dim3(p.g.K, nplanes), dim3(64), 0, st, d_planes, p.g, descs, metas, snapTs, endTs);
+  hipLaunchKernelGGL(k_lz4_extend, dim3(EXT_G, nplanes), dim3(256), 0, st, d_planes, p.g, descs, metas);
+  hipLaunchKernelGGL(k_lz4_extend_done, dim3((p.g.K + 255u) / 256u, nplanes), dim3(256), 0, st, p.g, descs, metas);
   Desc* altDescs = (Desc*)(d_ws + p.off_altdesc);
   Meta* altMetas = (Meta*)(d_ws + p.off_altmeta);
   uint32_t* altEndTs = (uint32_t*)(d_ws + p.off_altend);
