@@ -21,11 +21,13 @@
  *   - double uv readers accept tags 6/8 per the enum while the writers emit 5/7 like the reference;
  *   - the next-stream tag is read into a byte, integers are little-endian by construction.
  */
+#define _DEFAULT_SOURCE                /* madvise */
 #include "trico/trico.h"
 #include "trico/trico_hip.h"
 
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 
 struct trico_archive
   {
@@ -75,6 +77,23 @@ static trico_hip_ctx* arch_ctx(struct trico_archive* a)
 
 /* ---- write primitives (trico.c:26-63) ---------------------------------------------------- */
 
+/* A host archive of hundreds of MB is written once, front to back, into memory that has never been touched: with 4 KiB pages the
+ * page faults of a 450 MB buffer cost ~10 ms of a 57 ms encode.  Asking for transparent huge pages (where the kernel offers them on
+ * request; elsewhere the call does nothing) leaves a few hundred faults. */
+static void advise_huge(uint8_t* p, uint64_t size)
+  {
+#ifdef MADV_HUGEPAGE
+  const uintptr_t two = (uintptr_t)2 << 20;
+  if (!p || size < 16u * two)
+    return;
+  const uintptr_t b = ((uintptr_t)p + two - 1) & ~(two - 1), e = ((uintptr_t)p + size) & ~(two - 1);
+  if (e > b)
+    (void)madvise((void*)b, (size_t)(e - b), MADV_HUGEPAGE);
+#else
+  (void)p; (void)size;
+#endif
+  }
+
 static int reserve(struct trico_archive* a, uint64_t extra)
   {
   if (!a->writable)
@@ -104,6 +123,7 @@ static int reserve(struct trico_archive* a, uint64_t extra)
     if (!nb)
       return 0;
     a->buffer = nb;
+    advise_huge(nb, cap);
     }
   a->buffer_size = cap;
   return 1;
@@ -244,7 +264,10 @@ static void* open_for_writing(uint64_t initial_buffer_size, int on_device)
   if (on_device)
     a->buffer = (uint8_t*)trico_hip_device_alloc(initial_buffer_size ? initial_buffer_size : 8);
   else
+    {
     a->buffer = (uint8_t*)malloc(initial_buffer_size ? initial_buffer_size : 1);
+    advise_huge(a->buffer, initial_buffer_size);
+    }
   if (!a->buffer)
     {
     free(a);
