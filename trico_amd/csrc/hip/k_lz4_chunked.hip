@@ -85,7 +85,8 @@ __device__ __forceinline__ uint32_t batch_count(const uint8_t* __restrict__ a, c
 // NW > 1: NW waves of a workgroup run the SAME parse redundantly (every wave its own table) and share the work of counting a
 // long match: wave w takes slice w of every round and the waves exchange their results through `xch` (every wave calls
 // this function with the same arguments, so the barriers match).
-template <int NW>
+// QL: KiB of a long round per wave (16: 128 registers of loads in flight; the parse pass takes 8 to fit two waves on a SIMD)
+template <int NW, int QL = 16>
 __device__ __forceinline__ uint32_t wave_count(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint32_t limit, int lane, int wave,
                                                uint32_t* xch)
   {
@@ -113,16 +114,16 @@ __device__ __forceinline__ uint32_t wave_count(const uint8_t* __restrict__ a, co
     }
   done = 512u;
   }
-  // long matches: 4 KiB first, then 16 KiB per iteration and wave (the loop is bound by the latency of one round of loads,
+  // long matches: 4 KiB first, then QL KiB per iteration and wave (the loop is bound by the latency of one round of loads,
   // and periodic byte planes consist of matches of tens of KiB)
-  for (int Q = 4; done < limit; Q = 16)
+  for (int Q = 4; done < limit; Q = QL)
     {
     uint32_t first = 0xffffffffu;
-    if (done + 16384u * NW > limit)
+    if (done + 1024u * QL * NW > limit)
       Q = 4;
     const uint32_t base = done + 1024u * (uint32_t)(Q * wave);          // my wave's slice of this round
     if (base + 1024u * (uint32_t)Q <= limit)
-      first = Q == 16 ? batch_count<16>(a, b, base + 16u * (uint32_t)lane) : batch_count<4>(a, b, base + 16u * (uint32_t)lane);
+      first = Q == QL ? batch_count<QL>(a, b, base + 16u * (uint32_t)lane) : batch_count<4>(a, b, base + 16u * (uint32_t)lane);
     else
 #pragma unroll 4
     for (int q = 0; q < Q; ++q)
@@ -175,7 +176,7 @@ __device__ __forceinline__ uint32_t wave_count(const uint8_t* __restrict__ a, co
 //                    wave - it ends beyond c_hi, so it is the parse's last sequence whatever its length: the descriptor gets OPEN_ML,
 //                    the table is saved as for any match end and the whole device counts the rest (k_lz4_extend, END_OPEN)
 // Stops at the first match end >= c_hi (END_MATCH) or at the end of the block (END_FINAL).
-template <int NW>
+template <int NW, int QL = 16>
 __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t* tab, uint8_t* dup, uint32_t ip0, bool start_match_end, bool fresh,
                           bool emit_from_start, uint32_t c_lo, uint32_t c_hi, Desc* __restrict__ desc, uint32_t dcap,
                           Meta* __restrict__ meta, uint32_t* __restrict__ snapT, uint32_t* __restrict__ endT, int lane, int wave = 0,
@@ -444,7 +445,7 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
     const bool may_open = emit && big != 0u && big < limit;
     if (may_open)
       limit = big;
-    const uint32_t m = (fast && fast_extra < limit) ? fast_extra : wave_count<NW>(src + ip + 4u, src + cand + 4u, limit, lane, wave, xch);
+    const uint32_t m = (fast && fast_extra < limit) ? fast_extra : wave_count<NW, QL>(src + ip + 4u, src + cand + 4u, limit, lane, wave, xch);
     if (!emit && limit < room && m >= limit)
       break;                                                                       // ran past c_hi during warm-up
     if (may_open && m >= limit)
@@ -478,19 +479,26 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
     }
   }
 
-struct Geom { uint32_t n, chunk, warm, K, dcap; size_t plane_stride; uint32_t alt_rounds, alt_dcap, xchg; };   // xchg: search rounds through one LDS exchange (lz4_parse)
+struct Geom { uint32_t n, chunk, warm, K, dcap; size_t plane_stride; uint32_t alt_rounds, alt_dcap, xchg; uint8_t order[8]; };   // xchg: search rounds through one LDS exchange (lz4_parse); order: the planes as the parse pass takes them, slowest first
 constexpr uint32_t ALT_R = 4;             // alternative parses kept per chunk (k_lz4_alt)
 // equal bytes after which a recorded match of the parse pass is left to k_lz4_extend: at least a chunk (so that the match is the
 // chunk's last sequence), at least 1 MiB (what a wave counts in ~0.1 ms)
 __host__ __device__ inline uint32_t open_after(const Geom& g) { return g.chunk > (1u << 20) ? g.chunk : (1u << 20); }
 
+// (count rounds of 8 KiB, not 16: with the 280 registers of the wider round a compute unit holds four chunks instead of ten, and what a
+// plane of short sequences costs is how many of its chunks run at once; matches of a MiB and more are k_lz4_extend's anyway)
 __global__ void __launch_bounds__(64) k_lz4_parse(const uint8_t* __restrict__ planes, Geom g, Desc* __restrict__ descs, Meta* __restrict__ metas,
                                                   uint32_t* __restrict__ snapTs, uint32_t* __restrict__ endTs)
   {
-  __shared__ uint32_t tab[4096];
-  __shared__ uint8_t dup[4096];                  // scoreboard of the batched search loop
+  // (dynamic: 16 KiB of table, and 4 KiB of scoreboard for the batched search loop where the exchange is not used - ten chunks per
+  // compute unit instead of eight)
+  extern __shared__ __attribute__((aligned(16))) uint32_t parse_lds[];
+  uint32_t* tab = parse_lds;
+  uint8_t* dup = (uint8_t*)(parse_lds + 4096);
   const int lane = threadIdx.x;
-  const uint32_t k = blockIdx.x, p = blockIdx.y;
+  // the chunks of the plane with the shortest sequences are dispatched first: they take longest, and what decides the pass is when
+  // the last of them starts
+  const uint32_t k = blockIdx.x, p = g.order[blockIdx.y];
   for (int i = lane; i < 4096; i += 64)
     tab[i] = 0u;
   __syncthreads();
@@ -504,8 +512,8 @@ __global__ void __launch_bounds__(64) k_lz4_parse(const uint8_t* __restrict__ pl
   const uint8_t* src = planes + (size_t)p * g.plane_stride;
   const uint32_t c_lo = k * g.chunk;
   const uint32_t c_hi = (k + 1u == g.K) ? 0xffffffffu : c_lo + g.chunk;
-  lz4_parse<1>(src, g.n, tab, g.xchg ? nullptr : dup, k == 0 ? 0u : c_lo - g.warm, false, k == 0, k == 0, c_lo, c_hi, descs + ck * g.dcap, g.dcap, meta,
-            snapTs + ck * 4096, endTs + ck * 4096, lane, 0, nullptr, open_after(g));
+  lz4_parse<1, 8>(src, g.n, tab, g.xchg ? nullptr : dup, k == 0 ? 0u : c_lo - g.warm, false, k == 0, k == 0, c_lo, c_hi, descs + ck * g.dcap, g.dcap, meta,
+                  snapTs + ck * 4096, endTs + ck * 4096, lane, 0, nullptr, open_after(g));
   }
 
 // ---- matches longer than a chunk: counted by the whole device ------------------------------------------------------------------
@@ -645,9 +653,12 @@ __global__ void __launch_bounds__(256) k_lz4_extend_done(Geom g, Desc* __restric
 // re-parses grow with the number of chunks and shrink with the warm-up; a plane of short sequences (a real mesh's second
 // index plane: one sequence per 7 bytes) is bound by the ~1.5 us a wave needs per sequence, i.e. by how many chunk waves the
 // GPU holds at once, and its table state converges within a few KiB.  Measured on the MI355X (4 x 300 MB planes):
-//     chunk / warm-up        grid      walk
+//     chunk / warm-up        grid      walk                      (round 3, four chunks per compute unit)
 //     1 MiB / 384 KiB        70 ms    294 ms
 //     384 KiB / 96 KiB      136 ms    164 ms
+// Round 5, ten chunks per compute unit (count rounds of 8 KiB: 126 registers instead of 280) and the densest plane's chunks
+// dispatched first: walk 384 KiB / 96 KiB 100 ms, 256 KiB / 70,000 B 74 ms, 192 KiB / 70,000 B 63 ms, 128 KiB / 70,000 B 79 ms
+// (chunk sizes that are not multiples of 64 KiB: ~20 % slower than their neighbours); before: 88 ms at 384 KiB / 96 KiB.
 // So the launcher looks first: PROBE_S windows of PROBE_W bytes per plane are parsed as stand-alone blocks, and the densest
 // plane's bytes per sequence decide.  The choice never changes the output, only the time.
 constexpr uint32_t PROBE_S = 8, PROBE_W = 4096, PROBE_DCAP = PROBE_W / 4 + 16;
@@ -1142,7 +1153,7 @@ static bool lz4_use_xchg()
 
 struct Plan { Geom g; size_t off_desc, off_meta, off_snap, off_end, off_cbytes, off_coff, off_altdesc, off_altmeta, off_altend, total; };
 
-// mode 0: long matches (1 MiB chunks, 384 KiB warm-up), mode 1: short sequences (384 KiB / 96 KiB); TRICO_LZ4_CHUNK / TRICO_LZ4_WARM
+// mode 0: long matches (1 MiB chunks, 384 KiB warm-up), mode 1: short sequences (192 KiB / 70,000 B); TRICO_LZ4_CHUNK / TRICO_LZ4_WARM
 // fix one geometry for both (tuning knobs)
 static bool geometry_forced() { return getenv("TRICO_LZ4_CHUNK") || getenv("TRICO_LZ4_WARM"); }
 
@@ -1164,8 +1175,8 @@ Plan make_plan(uint32_t n, int nplanes, size_t plane_stride, int mode)
     }();
   const uint32_t env_chunk = env.chunk, env_warm = env.warm;
   const bool forced = env.forced;
-  const uint32_t chunk = forced || mode == 0 ? env_chunk : (384u << 10);
-  const uint32_t warm = forced || mode == 0 ? env_warm : (96u << 10);
+  const uint32_t chunk = forced || mode == 0 ? env_chunk : (192u << 10);
+  const uint32_t warm = forced || mode == 0 ? env_warm : 70000u;
   Plan p;
   p.g.n = n;
   p.g.chunk = chunk;
@@ -1234,34 +1245,42 @@ int launch_lz4_encode_chunked(const uint8_t* d_planes, size_t plane_stride, uint
     }
   hipStream_t st = current_stream();
   int mode = 0;
-  if (!geometry_forced())
+  uint8_t order[8] = { 0, 1, 2, 3, 4, 5, 6, 7 };
+  {
+  // look before parsing: bytes per sequence of every plane (see k_lz4_probe)
+  uint8_t* pa = d_ws + plans_bytes(n, nplanes, plane_stride);
+  Meta* pm = (Meta*)pa;
+  Desc* pd = (Desc*)(pa + align_up((size_t)nplanes * PROBE_S * sizeof(Meta), 256));
+  hipLaunchKernelGGL(k_lz4_probe, dim3(PROBE_S, nplanes), dim3(64), 0, st, d_planes, n, plane_stride, pd, pm, lz4_use_xchg() ? 1u : 0u);
+  Meta h[8 * PROBE_S];
+  if (!hip_ok(hipMemcpyAsync(h, pm, (size_t)nplanes * PROBE_S * sizeof(Meta), hipMemcpyDeviceToHost, st), "lz4 probe readback") ||
+      !hip_ok(hipStreamSynchronize(st), "lz4 probe"))
+    return 0;
+  uint32_t nds[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  for (int pl = 0; pl < nplanes; ++pl)
     {
-    // look before parsing: bytes per sequence of the densest plane (see k_lz4_probe)
-    uint8_t* pa = d_ws + plans_bytes(n, nplanes, plane_stride);
-    Meta* pm = (Meta*)pa;
-    Desc* pd = (Desc*)(pa + align_up((size_t)nplanes * PROBE_S * sizeof(Meta), 256));
-    hipLaunchKernelGGL(k_lz4_probe, dim3(PROBE_S, nplanes), dim3(64), 0, st, d_planes, n, plane_stride, pd, pm, lz4_use_xchg() ? 1u : 0u);
-    Meta h[8 * PROBE_S];
-    if (!hip_ok(hipMemcpyAsync(h, pm, (size_t)nplanes * PROBE_S * sizeof(Meta), hipMemcpyDeviceToHost, st), "lz4 probe readback") ||
-        !hip_ok(hipStreamSynchronize(st), "lz4 probe"))
-      return 0;
-    for (int pl = 0; pl < nplanes; ++pl)
-      {
-      uint32_t nd = 0;
-      for (uint32_t k = 0; k < PROBE_S; ++k)
-        nd += h[pl * PROBE_S + k].ndesc;
-      if ((uint64_t)nd * 48u > (uint64_t)PROBE_S * PROBE_W)                 // fewer than 48 bytes per sequence
-        mode = 1;
-      }
+    for (uint32_t k = 0; k < PROBE_S; ++k)
+      nds[pl] += h[pl * PROBE_S + k].ndesc;
+    if ((uint64_t)nds[pl] * 48u > (uint64_t)PROBE_S * PROBE_W)                 // fewer than 48 bytes per sequence
+      mode = 1;
     }
-  const Plan p = make_plan(n, nplanes, plane_stride, mode);
+  // planes by sequences per byte, densest first (insertion sort of at most eight)
+  for (int i = 1; i < nplanes; ++i)
+    for (int j = i; j > 0 && nds[order[j]] > nds[order[j - 1]]; --j)
+      {
+      const uint8_t t = order[j]; order[j] = order[j - 1]; order[j - 1] = t;
+      }
+  }
+  Plan p = make_plan(n, nplanes, plane_stride, mode);
+  for (int i = 0; i < 8; ++i)
+    p.g.order[i] = order[i];
   Desc* descs = (Desc*)(d_ws + p.off_desc);
   Meta* metas = (Meta*)(d_ws + p.off_meta);
   uint32_t* snapTs = (uint32_t*)(d_ws + p.off_snap);
   uint32_t* endTs = (uint32_t*)(d_ws + p.off_end);
   uint32_t* cbytes = (uint32_t*)(d_ws + p.off_cbytes);
   uint32_t* coff = (uint32_t*)(d_ws + p.off_coff);
-  hipLaunchKernelGGL(k_lz4_parse, dim3(p.g.K, nplanes), dim3(64), 0, st, d_planes, p.g, descs, metas, snapTs, endTs);
+  hipLaunchKernelGGL(k_lz4_parse, dim3(p.g.K, nplanes), dim3(64), p.g.xchg ? 16384u : 20480u, st, d_planes, p.g, descs, metas, snapTs, endTs);
   hipLaunchKernelGGL(k_lz4_extend, dim3(EXT_G, nplanes), dim3(256), 0, st, d_planes, p.g, descs, metas);
   hipLaunchKernelGGL(k_lz4_extend_done, dim3((p.g.K + 255u) / 256u, nplanes), dim3(256), 0, st, p.g, descs, metas);
   Desc* altDescs = (Desc*)(d_ws + p.off_altdesc);
