@@ -76,7 +76,7 @@ inline Plan make_plan(uint32_t n, int arity)
   p.off_gslots = o;    o += align_up((size_t)GUARD_WGS * arity * GUARD_SLOT, 256);
   p.off_grecs = o;     o += align_up((size_t)GUARD_WGS * arity * RCAP * RECW * 4, 256);
   p.off_gmeta = o;     o += align_up((size_t)GUARD_WGS * 3 * 16, 256);
-  p.off_diag = o;      o += 512;                 // diagnostic builds (-DTRICO_SWEEP_DIAG): clocks of one wave per component
+  p.off_diag = o;      o += 512;                 // diagnostic builds (-DTRICO_SWEEP_DIAG): clocks of one wave per component; from byte 256: records per component (offsets -> gather)
   p.off_slots = o;     o += p.slot_stride * arity;
   p.total = o + 256;
   return p;

@@ -789,26 +789,34 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
 // ---- offsets: exclusive scan of segment sizes per component (one workgroup per component) -------------
 // sizes[c] = payload bytes of component c; sizes[3 + c] = the flags its waves raised (FLAG_*; they travel in the upper half of the
 // record counts, so that nothing has to be zeroed before a sweep), read back with the sizes.
+// rectot[c] = the records (deferred values) of component c: the gather takes the components in the order of these.
 __global__ void __launch_bounds__(1024) k_fpc32_offsets(const uint32_t* __restrict__ segbytes, uint32_t S, int arity, uint32_t* __restrict__ segoff,
-                                                        uint32_t* __restrict__ sizes, const uint32_t* __restrict__ nrec)
+                                                        uint32_t* __restrict__ sizes, const uint32_t* __restrict__ nrec, uint32_t* __restrict__ rectot)
   {
   __shared__ uint32_t part[1024];
-  __shared__ uint32_t fl;
+  __shared__ uint32_t fl, recs;
   const uint32_t c = blockIdx.x;
   if (threadIdx.x == 0)
+    {
     fl = 0u;
+    recs = 0u;
+    }
   const uint32_t per = (S + 1023u) / 1024u;
   const uint32_t g0 = threadIdx.x * per, g1 = (g0 + per < S) ? g0 + per : S;
-  uint32_t sum = 0, f = 0;
+  uint32_t sum = 0, f = 0, h = 0;
   for (uint32_t g = g0; g < g1; ++g)
     {
     sum += segbytes[(size_t)c * S + g];
-    f |= nrec[(size_t)g * arity + c] >> 16;
+    const uint32_t w = nrec[(size_t)g * arity + c];
+    f |= w >> 16;
+    h += w & 0xffffu;
     }
   part[threadIdx.x] = sum;
   __syncthreads();
   if (f)
     atomicOr(&fl, f);
+  if (h)
+    atomicAdd(&recs, h);
   __syncthreads();
   for (uint32_t o = 1; o < 1024u; o <<= 1)
     {
@@ -827,6 +835,7 @@ __global__ void __launch_bounds__(1024) k_fpc32_offsets(const uint32_t* __restri
     {
     sizes[c] = part[1023];
     sizes[3u + c] = fl;
+    rectot[c] = recs;
     }
   }
 
@@ -1014,7 +1023,7 @@ int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
     {
     if (!launch_fpc32_sweep(src, n, arity, p, d_ws))
       return 0;
-    hipLaunchKernelGGL(k_fpc32_offsets, dim3(arity), dim3(1024), 0, st, segbytes, p.S, arity, segoff, d_sizes, nrec);
+    hipLaunchKernelGGL(k_fpc32_offsets, dim3(arity), dim3(1024), 0, st, segbytes, p.S, arity, segoff, d_sizes, nrec, (uint32_t*)(d_ws + p.off_diag + 256));
     return hip_ok(hipGetLastError(), "k_fpc32_offsets") ? 1 : 0;
     }
   const uint32_t prio_mode = 8u | (1u << 8);      // priority by progress, at most one block of lag between the component waves (measured in round 3)
@@ -1034,7 +1043,7 @@ int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
   else
     hipLaunchKernelGGL(k_fpc32_code<M_BALLOT>, dim3(p.S), dim3(threads), (size_t)arity * LDSW_C * 4 + 16, st,
                        src, n, arity, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes, prio_mode);
-  hipLaunchKernelGGL(k_fpc32_offsets, dim3(arity), dim3(1024), 0, st, segbytes, p.S, arity, segoff, d_sizes, nrec);
+  hipLaunchKernelGGL(k_fpc32_offsets, dim3(arity), dim3(1024), 0, st, segbytes, p.S, arity, segoff, d_sizes, nrec, (uint32_t*)(d_ws + p.off_diag + 256));
   return hip_ok(hipGetLastError(), "fpc32 encode kernels") ? 1 : 0;
   }
 

@@ -1440,9 +1440,24 @@ __device__ __forceinline__ void copy_shifted(uint8_t* __restrict__ dd, const uin
 __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap, uint32_t S,
                                                       const uint32_t* __restrict__ segbytes, const uint32_t* __restrict__ rawbytes,
                                                       const uint32_t* __restrict__ segoff, GatherDst dst, const uint32_t* __restrict__ nrec,
-                                                      const uint32_t* __restrict__ recs, int arity, int c0)
+                                                      const uint32_t* __restrict__ recs, int arity, int c0, const uint32_t* __restrict__ rectot)
   {
-  const uint32_t g = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+  const uint32_t g = blockIdx.x, tid = threadIdx.x;
+  // The components in the order of their records (k_fpc32_offsets counts them), most first: a component full of them (a grid's z:
+  // three quarters of the bytes, every sub-chunk through the slow path) takes its workgroups several times as long as the others,
+  // and dispatched last its second round of workgroups was the kernel's tail (same box, benchmark mesh: 180-187 -> 156 us; by payload
+  // bytes 157, simply reversed 161; the walk mesh, whose components are alike, does not care: 139-141).
+  uint32_t c = blockIdx.y;
+  if (gridDim.y > 1u)
+    {
+    uint32_t tot[3] = { 0u, 0u, 0u }, ord[3] = { 0u, 1u, 2u };    // (stable: equal counts keep their order)
+    for (uint32_t k = 0; k < gridDim.y; ++k)
+      tot[k] = rectot[(uint32_t)c0 + k];
+    if (tot[ord[1]] > tot[ord[0]]) { const uint32_t t = ord[0]; ord[0] = ord[1]; ord[1] = t; }
+    if (gridDim.y > 2u && tot[ord[2]] > tot[ord[1]]) { const uint32_t t = ord[1]; ord[1] = ord[2]; ord[2] = t; }
+    if (tot[ord[1]] > tot[ord[0]]) { const uint32_t t = ord[0]; ord[0] = ord[1]; ord[1] = t; }
+    c = ord[blockIdx.y];
+    }
   const uint32_t cc = (uint32_t)c0 + c;                                           // component in the workspace's numbering
   const uint32_t len = segbytes[(size_t)cc * S + g];
   const uint8_t* s = slots + (size_t)cc * slot_stride + (size_t)g * segcap;       // 256-byte aligned, segcap has 280 bytes of slack
@@ -1882,7 +1897,7 @@ int launch_fpc32_gather_rec(const Plan& p, int arity, int c0, int count, const u
   GatherDst dst = { { d_dst[0], count > 1 ? d_dst[1] : nullptr, count > 2 ? d_dst[2] : nullptr } };
   hipLaunchKernelGGL(k_fpc32_gather, dim3(p.S, count), dim3(256), 0, current_stream(), d_ws + p.off_slots, p.slot_stride, p.segcap, p.S,
                      (const uint32_t*)(d_ws + p.off_segbytes), (const uint32_t*)(d_ws + p.off_rawbytes), (const uint32_t*)(d_ws + p.off_segoff),
-                     dst, (const uint32_t*)(d_ws + p.off_nrec), (const uint32_t*)(d_ws + p.off_recs), arity, c0);
+                     dst, (const uint32_t*)(d_ws + p.off_nrec), (const uint32_t*)(d_ws + p.off_recs), arity, c0, (const uint32_t*)(d_ws + p.off_diag + 256));
   return hip_ok(hipGetLastError(), "k_fpc32_gather") ? 1 : 0;
   }
 
