@@ -103,7 +103,7 @@ def _pmc_file_traffic(path):
             continue
         if section != "grid":
             continue
-        m = re.match(r"^(\S+) dispatches (\d+)", line)
+        m = re.match(r"^(\S.*?) dispatches (\d+)", line)          # (a template kernel's name has its arguments: "k_fpc32_sweep<false, true>")
         if m:
             kernel = m.group(1)
             disp[kernel] = int(m.group(2))
@@ -111,7 +111,7 @@ def _pmc_file_traffic(path):
         m = re.match(r"^\s+(FETCH_SIZE|WRITE_SIZE)\s+(\d+) per dispatch", line)
         if m and kernel and kernel.startswith("k_fpc32"):
             (fetch if m.group(1) == "FETCH_SIZE" else write)[kernel] = float(m.group(2)) * disp[kernel]
-    launches = disp.get("k_fpc32_sweep", 0) or disp.get("k_fpc32_code", 0)
+    launches = sum(v for k, v in disp.items() if k.startswith("k_fpc32_sweep")) or sum(v for k, v in disp.items() if k.startswith("k_fpc32_code"))
     if not fetch or not write or not launches:
         return None
     return int((2.0 * sum(fetch.values()) + sum(write.values())) * 1024.0 / launches)

@@ -54,3 +54,15 @@ def test_decode_mixed_rank_body(ranks, native_libs):
     raw = [n * 12 + 2 * n * 12, n * 12 + 2 * n * 12, 2 * n * 24 + n * 8 + 2 * n * 24]
     assert j["config"]["decoded_bytes_all_ranks"] == sum(raw[:ranks])
     assert j["config"]["parity_rank0"] == "sha256 == reference golden"
+
+
+def test_committed_pmc_summary_parses():
+    """roofline.traffic comes from a tools/pmc_summary.py text (live, or the newest committed one): the parser must read the
+    summaries under profiles/, template kernel names included"""
+    import glob
+    sys.path.insert(0, ROOT)
+    import bench
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_fpc32_encode_hbm_traffic_pmc.txt")))
+    assert files
+    t = bench._pmc_file_traffic(files[-1])
+    assert t and 1.2e9 < t < 3e9, t
