@@ -1,6 +1,6 @@
 """The throughput encoder for doubles (trico_amd/csrc/hip/k_fpc64_sort.hip) against the oracle: the owners' walk (runs of equal
 hashes, lanes that share a table entry inside one step, lists of very different lengths), and the sorting path that skewed
-streams take instead.  Streams of 65,536 values and more take this encoder (TRICO_FPC64_SORT_MIN)."""
+streams take instead.  Streams of 8,192 values and more take this encoder (TRICO_FPC64_SORT_MIN)."""
 import numpy as np
 import pytest
 
@@ -58,7 +58,7 @@ def test_vec3_streams_vs_oracle(api, monkeypatch, kind, mode):
     read_back(api, got, streams)
 
 
-@pytest.mark.parametrize("n", [65536, 65537, 66001, 131072 + 63, 300000])
+@pytest.mark.parametrize("n", [8192, 8193, 9001, 20000, 65536, 65537, 66001, 131072 + 63, 300000])
 def test_scalar_and_uv_streams_vs_oracle(api, n):
     """arity 1 (attributes) and 2 (uv) through the same kernels; counts around the tile and step sizes"""
     rng = np.random.default_rng(n)
