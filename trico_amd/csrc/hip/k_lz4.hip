@@ -1,4 +1,4 @@
-// k_lz4.hip — LZ4 block compressor for planes below 4 MiB, one 1024-thread workgroup per byte plane
+// k_lz4.hip — LZ4 block compressor for planes below 256 KiB (TRICO_LZ4_CHUNKED_MIN; 4 MiB until round 5), one 1024-thread workgroup per byte plane
 // (larger planes: k_lz4_chunked.hip; decompressor: k_lz4_decode.hip).
 //
 // Compressor: byte-exact with LZ4 1.9.2's LZ4_compress_default as Trico calls it (trico.c:343-368 ->

@@ -1175,7 +1175,19 @@ Plan make_plan(uint32_t n, int nplanes, size_t plane_stride, int mode)
     }();
   const uint32_t env_chunk = env.chunk, env_warm = env.warm;
   const bool forced = env.forced;
-  const uint32_t chunk = forced || mode == 0 ? env_chunk : (192u << 10);
+  // mode > 0: that many planes of short sequences.  Their chunks should all run at once (~2048 of them, see k_lz4_parse) and a chunk
+  // costs its own bytes + the warm-up at ~0.17 us per byte: 64 KiB steps (other sizes are slower, see the table at k_lz4_probe)
+  // between 64 KiB - middle-sized meshes: a 5 MB plane took the 44 ms of ONE 192 KiB chunk - and the 192 KiB measured best at 300 MB.
+  uint32_t short_chunk = 192u << 10;
+  if (mode > 0)
+    {
+    const uint64_t per_plane = 2048u / (uint32_t)mode;
+    const uint64_t want = ((uint64_t)n + per_plane - 1) / per_plane;
+    short_chunk = (uint32_t)(((want + 65535u) >> 16) << 16);
+    if (short_chunk < (64u << 10)) short_chunk = 64u << 10;
+    if (short_chunk > (192u << 10)) short_chunk = 192u << 10;
+    }
+  const uint32_t chunk = forced || mode == 0 ? env_chunk : short_chunk;
   const uint32_t warm = forced || mode == 0 ? env_warm : 70000u;
   Plan p;
   p.g.n = n;
@@ -1211,8 +1223,10 @@ size_t probe_bytes(int nplanes)
   }
 size_t plans_bytes(uint32_t n, int nplanes, size_t plane_stride)
   {
-  const size_t a = make_plan(n, nplanes, plane_stride, 0).total, b = make_plan(n, nplanes, plane_stride, 1).total;
-  return align_up(a > b ? a : b, 256);
+  // (the long-match geometry, and the short-sequence one with the smallest and the largest chunks it may choose)
+  const size_t a = make_plan(n, nplanes, plane_stride, 0).total, b = make_plan(n, nplanes, plane_stride, 1).total, c = make_plan(n, nplanes, plane_stride, nplanes).total;
+  const size_t m = a > b ? a : b;
+  return align_up(m > c ? m : c, 256);
   }
 
 } // namespace
@@ -1224,7 +1238,7 @@ uint32_t lz4_chunked_threshold()
   if (!t)
     {
     const char* e = getenv("TRICO_LZ4_CHUNKED_MIN");
-    t = e ? (uint32_t)atoi(e) : (4u << 20);
+    t = e ? (uint32_t)atoi(e) : (256u << 10);             // (measured: at 300 KB the chunked path is level with the one-workgroup compressor, at 2.4 MB 2.5 x (long matches) and 7 x (short sequences) faster)
     if (t < 65547u) t = 65547u;
     }
   return t;
@@ -1262,7 +1276,7 @@ int launch_lz4_encode_chunked(const uint8_t* d_planes, size_t plane_stride, uint
     for (uint32_t k = 0; k < PROBE_S; ++k)
       nds[pl] += h[pl * PROBE_S + k].ndesc;
     if ((uint64_t)nds[pl] * 48u > (uint64_t)PROBE_S * PROBE_W)                 // fewer than 48 bytes per sequence
-      mode = 1;
+      ++mode;
     }
   // planes by sequences per byte, densest first (insertion sort of at most eight)
   for (int i = 1; i < nplanes; ++i)
