@@ -21,5 +21,19 @@ for W, H in ((100, 100), (250, 200), (500, 350), (800, 500), (1000, 800), (1500,
         assert L.trico_hip_int_encode(ctx, d.data_ptr(), n, 4, sizes) == 1, api.last_error()
         L.trico_hip_synchronize()
         best = min(best, time.perf_counter() - t0)
-    print("plane bytes %9d  best %.3f ms  sizes %s" % (n, best * 1e3, list(sizes)[:4]), flush=True)
+    pay = [torch.empty(sizes[c], dtype=torch.uint8, device="cuda") for c in range(4)]
+    for c in range(4):
+        assert L.trico_hip_fetch_payload(ctx, c, pay[c].data_ptr()) == 1
+    out = torch.empty_like(d)
+    pp = (ctypes.c_void_p * 8)(*[p.data_ptr() for p in pay] + [None] * 4)
+    ss = (ctypes.c_uint32 * 8)(*[sizes[c] for c in range(4)] + [0] * 4)
+    dbest = 1e9
+    for it in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        assert L.trico_hip_int_decode(ctx, pp, ss, 4, n, out.data_ptr()) == 1, api.last_error()
+        L.trico_hip_synchronize()
+        dbest = min(dbest, time.perf_counter() - t0)
+    assert torch.equal(out, d)
+    print("plane bytes %9d  encode %.3f ms  decode %.3f ms  sizes %s" % (n, best * 1e3, dbest * 1e3, list(sizes)[:4]), flush=True)
 L.trico_hip_ctx_destroy(ctx)
