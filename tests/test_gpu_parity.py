@@ -448,6 +448,26 @@ def test_lz4_short_sequence_regimes(api, kind, n):
     assert back.tobytes() == data.tobytes()
 
 
+@pytest.mark.parametrize("n", [262143, 262144, 262145, 300001, 700000, 1048576 + 7, 3999999])
+@pytest.mark.parametrize("kind", ["markov", "period777", "zeros_tail"])
+def test_lz4_planes_around_the_chunked_threshold(api, kind, n):
+    """planes of 256 KiB and more take the chunk-speculative compressor (a single chunk at first, 64 KiB chunks on short sequences),
+    smaller ones the one-workgroup compressor: the reference's bytes on both sides of the threshold"""
+    rng = np.random.default_rng(n + len(kind))
+    if kind == "markov":
+        data = (np.cumsum(rng.integers(-1, 2, n)) & 15).astype(np.uint8)
+    elif kind == "period777":
+        data = np.tile(rng.integers(0, 256, 777, dtype=np.uint8), n // 777 + 1)[:n].copy()
+        data[rng.integers(0, n, 25)] ^= 0x3c
+    else:
+        data = np.concatenate([rng.integers(0, 256, n // 3, dtype=np.uint8), np.zeros(n - n // 3, np.uint8)])
+    data = np.ascontiguousarray(data)
+    streams = [("attributes_uint8", data, n)]
+    got = write_archive(api, streams)
+    assert got == oracle_archive(streams)
+    read_back(api, got, streams)
+
+
 @pytest.mark.parametrize("kind", ["period30k", "period_drift", "two_regimes", "random_then_zero", "short_sequences", "ramp_u32_plane",
                                   "long_runs", "many_long_runs", "open_match_ends", "long_period"])
 def test_lz4_chunked_compressor_regimes(api, kind):
