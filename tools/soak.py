@@ -48,6 +48,8 @@ for case in range(cases):
     streams = []
     for _ in range(int(rng.integers(1, 4))):
         n = int(rng.choice([1, 2, 7, 8, 9, 63, 64, 65, 1000, 4097, 65536, 70001, int(rng.integers(1, int(os.environ.get("SOAK_MAXN", "300000"))))]))
+        if os.environ.get("SOAK_BIG"):                  # middle-sized streams only: the thresholds between the small and the throughput kernels
+            n = int(rng.integers(6000, int(os.environ.get("SOAK_MAXN", "300000"))))
         if rng.random() < 0.6:
             name, arity, dt = FP[int(rng.integers(len(FP)))]
             data = np.stack([reals(int(rng.integers(8)), n, dt) for _ in range(arity)], -1).reshape(-1)
