@@ -13,21 +13,23 @@
 //     ever read, so a run is at most two table operations.  Smooth components (a grid's x and y, a constant normal)
 //     are almost nothing but runs.
 //   * owners: ten bits of the hash (FCM: its two halves xor-ed, DFCM: the lower half) name one of 1024 owners per
-//     component, the upper half an entry of the owner's table (8 KiB: LDS).  k64_part_hist / k64_part_scatter write every owner's operations, in value order, into its
-//     list (a stable one-digit partition: count matrix, scan, ballots for the order inside a step - one launch per
-//     table for all components, the source is read as whole vertices); an operation is 16 bytes: value index, table
-//     entry, read / write flags, and the payload it writes.
+//     component, the upper half an entry of the owner's table (8 KiB: LDS).  k64_part_hist / k64_part_scatter write
+//     every owner's operations, in value order, into its list (a stable one-digit partition: count matrix, scan,
+//     ballots for the order inside a step - one launch per table for all components, whole vertices staged through
+//     LDS); an operation is 16 bytes: value index, table entry, read / write flags, and the payload it writes.
 //   * walk (k64_walk): one wave per owner streams through its list 64 operations at a time and applies them to its LDS
 //     table in list order: the lanes of a step that share an entry find each other with ballots, a read takes the
 //     payload of the nearest lower writer among them or the table's word, the last writer writes the table.  A read's
 //     result goes to the operation's place in a second list.
-//   * home (k64_home): the lists hold a tile's operations as 1024 short runs per component; one workgroup per tile
-//     collects them and stores the results to pred[value index] - all inside the tile's window of pred, which the
-//     L2 of the workgroup's XCD turns into whole lines.  (Storing the results from the walk itself, one 8-byte store
-//     per operation anywhere in pred, and fetching the payloads from the source the same way, cost 35-80 ps per
-//     operation on this machine - as much as the sort it replaces.)
-//   * sizes, scan, emit as before (all components in one launch each); a value inside a run takes its prediction from
-//     its neighbour instead of pred[].
+//   * home (k64_home): the lists hold a tile's operations as 1024 short runs per component; one workgroup per tile and
+//     component collects them, builds the tile's window of pred[] in LDS and writes it out whole.  (Storing the
+//     results from the walk itself, one 8-byte store per operation anywhere in pred, and fetching the payloads from
+//     the source the same way, cost 35-80 ps per operation on this machine - as much as the sort it replaces.)
+//   * sizes (k64_sizes), scan, emit (k64_emit): code selection -> bytes per group of two values -> byte offsets ->
+//     tiles of 512 groups packed in LDS and written with aligned dword stores; all components per launch, vertices
+//     staged through LDS; a value inside a run takes its prediction from its neighbour instead of pred[].
+//   * both tables are counted first (one host wait for the two longest lists); then the FCM table's walk runs beside
+//     the DFCM table's scatter on a second stream, its way home beside the DFCM table's walk (both_tables).
 // A stream whose longest list would make the walk slower than sorting (one owner with most of the operations and no
 // runs: e.g. values alternating between two hashes) takes the path of round 2 for that table instead, which is
 // indifferent to skew:
