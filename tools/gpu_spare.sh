@@ -6,6 +6,6 @@ for sp in "$@"; do
   for m in grid walk; do
     echo "## spare $sp $m"
     TRICO_FPC32_SPARE=$sp timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/enc -- python $R/tools/perf_fpc32.py $m > $O/enc.log 2>&1
-    grep "kernel span" $O/enc.log; python $R/tools/prof_summary.py $O/enc | grep "sweep \|gather\|fixup\|pscan"; rm -rf $O/enc
+    grep "kernel span" $O/enc.log; python $R/tools/prof_summary.py $O/enc | grep "sweep\|gather\|fixup"; rm -rf $O/enc
   done
 done
