@@ -91,10 +91,13 @@ import torch
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def _pmc_file_traffic(path):
-    """(bytes per launch sequence, launches) from a tools/pmc_summary.py text (KB per dispatch; FETCH_SIZE doubled per the
-    gfx950 rule of MI355X_MICROARCH.md, validated for this kernel's reads in profiles/r02_ubench_fetch_size.txt)."""
+def _pmc_file_traffic(path, family="k_fpc32", per_launch_of=("k_fpc32_sweep", "k_fpc32_code")):
+    """bytes per launch sequence from a tools/pmc_summary.py text (KB per dispatch; FETCH_SIZE doubled per the gfx950 rule of
+    MI355X_MICROARCH.md, validated for this kernel's reads in profiles/r02_ubench_fetch_size.txt).  `family`: prefix of the
+    kernels that count (None: every kernel but the runtime's own fills and copies); `per_launch_of`: the kernel whose dispatches
+    count the launch sequences (the first of them the file holds)."""
     import re
+    mine = (lambda k: k.startswith(family)) if family else (lambda k: not k.startswith("__amd"))
     kernel, disp, fetch, write = None, {}, {}, {}
     section = "grid"                                   # (round 4's files hold a "## grid" and a "## walk" section; older ones the grid only)
     for line in open(path):
@@ -109,9 +112,11 @@ def _pmc_file_traffic(path):
             disp[kernel] = int(m.group(2))
             continue
         m = re.match(r"^\s+(FETCH_SIZE|WRITE_SIZE)\s+(\d+) per dispatch", line)
-        if m and kernel and kernel.startswith("k_fpc32"):
+        if m and kernel and mine(kernel):
             (fetch if m.group(1) == "FETCH_SIZE" else write)[kernel] = float(m.group(2)) * disp[kernel]
-    launches = sum(v for k, v in disp.items() if k.startswith("k_fpc32_sweep")) or sum(v for k, v in disp.items() if k.startswith("k_fpc32_code"))
+    launches = 0
+    for pre in per_launch_of:
+        launches = launches or sum(v for k, v in disp.items() if k.startswith(pre))
     if not fetch or not write or not launches:
         return None
     return int((2.0 * sum(fetch.values()) + sum(write.values())) * 1024.0 / launches)
@@ -784,13 +789,23 @@ def config3_block(api, meshgen, dev, W, H, grid_dev=None, with_cpu=True):
         # traffic: not collected live; the committed PMC summary of the same two streams at full size (profiles/r05_fpc64_encode_hbm_traffic_pmc.txt:
         # FETCH_SIZE x 2 + WRITE_SIZE over the kernels of both streams), scaled by the value count when the mesh is another
         full = 50_000_000
+        import glob
+        t64, src64 = None, "no committed profiles/*_fpc64_encode_hbm_traffic_pmc.txt"
+        files64 = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_fpc64_encode_hbm_traffic_pmc.txt")))
+        files64 = [f for f in files64 if "_before_" not in f]
+        if files64:
+            per_stream = _pmc_file_traffic(files64[-1], family=None, per_launch_of=("k64_sizes",))
+            if per_stream:
+                t64 = int(2 * per_stream * n / full)
+                src64 = os.path.relpath(files64[-1], ROOT) + " (separate --pmc passes over tools/perf_fpc64.py at full size, NOT this run; scaled by the value count)"
+        ratio64 = ("%.0f x" % (t64 / (dbl_raw + dbl_pay))) if t64 else "many times"
         roof = {"kernel": "double encoder (k_fpc64_sort.hip: runs of equal hashes, 1024 owners per component and table, operations partitioned "
                           "into their lists, LDS walk, results home by tile, codes, scan, pack), the two vec3 double streams of the mesh",
                 "bound": "hbm", "achieved": round(gb, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(gb / HBM_PEAK_GBPS, 5), "traffic": int(65.4e9 * n / full),
-                "traffic_source": "profiles/r05_fpc64_encode_hbm_traffic_pmc.txt (separate --pmc passes over tools/perf_fpc64.py, not this run)",
+                "frac": round(gb / HBM_PEAK_GBPS, 5), "traffic": t64,
+                "traffic_source": src64,
                 "algorithmic_bytes": dbl_raw + dbl_pay, "launch_ms": round(enc64_ms, 3),
-                "what_bounds_it": "memory traffic 18 x the algorithmic bytes at ~3 TB/s: a table operation is 16 bytes written into one of 3072 lists per "
+                "what_bounds_it": "memory traffic " + ratio64 + " the algorithmic bytes at ~3 TB/s: a table operation is 16 bytes written into one of 3072 lists per "
                                   "wave (no line is written whole: the counters show twice the bytes), read by the walk, written as a result, read "
                                   "again by tile; predictions are written once and read by the size and the pack kernel"}
     twin = None
@@ -818,6 +833,53 @@ def config3_block(api, meshgen, dev, W, H, grid_dev=None, with_cpu=True):
             "encode_GBps": round(raw / res["encode_s"] / 1e9, 3), "decode_GBps": round(raw / res["decode_s"] / 1e9, 3),
             "encode_s": res["encode_s"], "decode_s": res["decode_s"],
             "value": round(raw / (res["encode_s"] + res["decode_s"]) / 1e9, 4), "roofline": roof, "cpu_twin": twin, "config5_mixed": mixed}
+
+
+def rank_report(dist, rank, local_rank, world, dev, host_only, facts):
+    """What a reader of an N > 1 line needs to see that N ranks really ran on N devices: per rank its device ordinal, PCI bus id, name
+    and the facts it hands in (archive verdict, bytes); and what the collective backend itself says about the job (backend name, its
+    world size, the RCCL version).  Gathered with all_gather_object outside the timed region; returned on every rank."""
+    me = {"rank": rank, "local_rank": local_rank, "pid": os.getpid()}
+    if not host_only:
+        pr = torch.cuda.get_device_properties(dev)
+        me.update(device_ordinal=dev.index, device=pr.name, cus=pr.multi_processor_count,
+                  pci="%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+                  uuid=str(getattr(pr, "uuid", "")))
+    me.update(facts)
+    rows = [me]
+    backend = {"backend": None, "world_size_as_reported": 1}
+    if dist is not None:
+        rows = [None] * world
+        dist.all_gather_object(rows, me)
+        backend = {"backend": dist.get_backend(), "world_size_as_reported": dist.get_world_size()}
+        if not host_only:
+            try:
+                backend["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception as e:
+                backend["rccl_version"] = "unknown (%s)" % repr(e)[:80]
+    distinct = len(set((r.get("pci"), r.get("device_ordinal")) for r in rows)) if not host_only else None
+    return {"collective": backend, "distinct_devices": distinct, "per_rank": rows}
+
+
+def _gathered_bytes(g):
+    """bytes the exchange delivered to this rank: (tensor, sizes) from gather_archives on the root, a count from the C-ABI gather, None elsewhere"""
+    if g is None:
+        return 0
+    if isinstance(g, tuple):
+        return int(sum(g[1]))
+    try:
+        return int(g)
+    except Exception:
+        return int(getattr(g, "numel", lambda: 0)())
+
+
+def _headline_last(out):
+    """The driver keeps the TAIL of stdout: the keys of the contract go to the end of the line, the bulky blocks in front of them."""
+    head = ["ranks", "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "config", "encode_GBps", "decode_GBps", "gather_ms", "roofline", "cpu_baseline"]
+    ordered = {k: v for k, v in out.items() if k not in head}
+    ordered.update({k: out[k] for k in head if k in out})
+    return ordered
 
 
 def decode_mixed(args, api, meshgen, dev, sync, dist, rank, world, real_stdout, host_only):
@@ -878,6 +940,9 @@ def decode_mixed(args, api, meshgen, dev, sync, dist, rank, world, real_stdout, 
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    ranks = rank_report(dist, rank, int(os.environ.get("LOCAL_RANK", "0")), world, dev, host_only,
+                        {"kind": kind, "archive_bytes": int(a.get_size()), "archive_sha256": sha[:16], "parity": parity, "decoded_bytes": int(raw),
+                         "rank_ms_per_step": round((t1 - t0) / args.steps * 1e3, 3)})
     if rank == 0:
         step_s = el.item() / args.steps
         out = {"metric": "decode GB/s (output bytes), mixed archives", "value": round(tot.item() / step_s / 1e9, 4), "unit": "GB/s",
@@ -888,9 +953,9 @@ def decode_mixed(args, api, meshgen, dev, sync, dist, rank, world, real_stdout, 
                                       "triangles / double vertices + double normals + float uv + u64 triangles - built on the GPU, decoded into HBM" % (W, H),
                           "mode": "decode-mixed", "kind_rank0": kind, "decoded_bytes_all_ranks": int(tot.item()), "parity_rank0": parity,
                           "parallelism": "1 process per GPU, %d independent archives, no collective in the timed region" % world},
-               "decode_GBps": round(tot.item() / step_s / 1e9, 4)}
+               "decode_GBps": round(tot.item() / step_s / 1e9, 4), "ranks": ranks}
         sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        os.write(real_stdout, (json.dumps(_headline_last(out)) + "\n").encode())
     a.close()
     if dist is not None:
         dist.barrier()
@@ -1073,6 +1138,14 @@ def main():
     if dist is not None:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = elapsed.tolist()
+    ranks = None
+    if world > 1 or dist is not None:
+        ranks = rank_report(dist, rank, local_rank, world, dev, host_only,
+                            {"mesh_seed": "%08x" % seed, "archive_bytes": int(state.get("archive_bytes") or 0), "archive_sha256": (state.get("sha256") or "")[:16],
+                             "parity": ("sha256 == reference golden" if (golden is not None and state["sha256"] is not None) else "unchecked (no golden / not the framing rank)"),
+                             "roundtrip_ok": bool(state["roundtrip_ok"]), "gathered_bytes_seen": _gathered_bytes(state.get("gathered_bytes")),
+                             "rank_ms_per_step": round((t1 - t0) / args.steps * 1e3, 3), "rank_encode_ms": round(enc / args.steps * 1e3, 3),
+                             "rank_gather_ms": round(gat / args.steps * 1e3, 3), "rank_decode_ms": round(dec / args.steps * 1e3, 3)})
 
     spans = ctypes.c_uint64(0)
     kms = {}
@@ -1133,6 +1206,8 @@ def main():
             "roofline_all": roofline_all,
             "kernels": kms,
         }
+        if ranks is not None:
+            out["ranks"] = ranks
         Ks = [int(k) for k in args.concurrent.split(",") if k.strip()]
         if world == 1 and not args.no_extras and not args.quick:
             out["decode_model"] = decode_model(api, d_v, d_t, nv, nt, raw_bytes)
@@ -1162,8 +1237,12 @@ def main():
             out["decode_concurrent"]["vs_cpu_all_cores"] = [
                 {"archives": K, "gpu_decode_GBps": g, "cpu_decode_GBps": cpu_rows[K]["decode_GBps"], "cpu_threads": cpu_rows[K]["threads"],
                  "gpu_over_cpu": round(g / cpu_rows[K]["decode_GBps"], 3)} for K, g in sorted(best.items())]
+        if "cpu_baseline" in out:
+            cb = out["cpu_baseline"]
+            out["cpu_baseline_detail"] = {k: cb[k] for k in ("streams_parallel", "all_cores", "nproc", "encode_GBps", "decode_GBps") if k in cb}
+            out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample") if k in cb}
         sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        os.write(real_stdout, (json.dumps(_headline_last(out)) + "\n").encode())
     if unit_encoder is not None:
         unit_encoder.close()
     if comm is not None:

@@ -74,6 +74,10 @@ TRICO_API int trico_hip_int_encode(trico_hip_ctx* ctx, const void* src, uint32_t
 TRICO_API int trico_hip_int_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[8], const uint32_t sizes[8],
                                    int width, uint32_t count, void* dst);
 
+/* Decoded size of ONE LZ4 block whose size the caller only knows an upper bound of (what LZ4_decompress_safe's dstCapacity is,
+ * lz4/lz4.h:153-158): the sequences are walked on the device without moving a byte.  0: malformed, or more than `capacity` bytes. */
+TRICO_API int trico_hip_lz4_decoded_size(trico_hip_ctx* ctx, const void* payload, uint32_t size, uint32_t capacity, uint32_t* out_size);
+
 /* ---- batched decode: one launch for all chains -------------------------------------------------
  * The format leaves ONE serial chain per floating-point component (fpsc.c:308-326), so decode throughput is the number of
  * chains in flight.  A job is one stream (what one trico_read_* call decodes, trico.c:943-1668); a batch may hold the streams
@@ -93,7 +97,7 @@ typedef struct trico_hip_decode_job
   uint32_t sizes[8];
   void* dst;
   int32_t ok;              /* out: 1, 0 or -1, see above */
-  int32_t reserved;
+  int32_t other_writer;    /* out: 1 if the stream was delivered although the reference's encoder would not have written its payload (trico_hip_set_strict) */
   } trico_hip_decode_job;
 TRICO_API int trico_hip_decode_jobs(trico_hip_decode_job* jobs, int count);
 /* allocates (and keeps) the device workspaces a batch of this shape needs, without decoding: takes the allocation out of the
@@ -228,6 +232,22 @@ TRICO_API int trico_hip_fpc32_code_sweep(void);
  * sampled step of the one-sweep coder found the LDS exchange out of lane order (the device is not asked again afterwards),
  * out[1] = because a value or stride equal to the coder's "never written" table mark was stored (2^-32 per value on random bits). */
 TRICO_API void trico_hip_encode_stats(uint32_t out[2]);
+/* Opt-in FULL verification of the float encoder (process-wide; -1 returns to what TRICO_HIP_ENCODE_VERIFY=1 says, default off).
+ * Every float stream of the API's table sizes is coded a second time by the two-sweep coder with ballots and the payloads are
+ * compared byte for byte on the device before the call returns (about +1 ms per 50 M vertices of device time, and the payload is
+ * gathered to the context first).  A difference is counted, printed on stderr, and the ballot coder's payload is used.
+ * out[0] = streams verified, out[1] = values verified, out[2] = streams that differed (never seen so far). */
+TRICO_API void trico_hip_set_encode_verify(int on);
+TRICO_API void trico_hip_encode_verify_stats(uint64_t out[3]);
+/* Reader policy for a float / double payload that decodes but that the reference's encoder would not have written (its values,
+ * decoded in reference order, do not code back to it: another writer chose other, equally decodable codes - or the archive is
+ * corrupt in a way that still parses).  Default (0, or -1 = what TRICO_HIP_STRICT says): the values are delivered and counted
+ * (trico_hip_last_stats word 3, trico_hip_archive_other_writer_streams, trico_hip_decode_job::other_writer).  1: the read fails.
+ * A caller that wrote its archives with this library or with the reference can treat every such stream as corruption. */
+TRICO_API void trico_hip_set_strict(int on);
+/* streams of this context / of this read archive handle that were delivered under the "another writer" rule above */
+TRICO_API uint32_t trico_hip_ctx_other_writer_streams(const trico_hip_ctx* ctx);
+TRICO_API uint32_t trico_hip_archive_other_writer_streams(void* archive);
 TRICO_API void trico_hip_profile_enable(int on);
 TRICO_API void trico_hip_profile_reset(void);
 /* returns accumulated milliseconds and number of timed spans for kernel id `k` (syncs first) */

@@ -93,6 +93,33 @@ def test_truncated_archive_fails_cleanly(native_libs, gold_dir):
     r.close()
 
 
+def test_exports_the_lz4_entry_points(native_libs):
+    """include/lz4/lz4.h: the block API Trico's callers use (lz4.h:127-171 of the reference; trico.tests/int_compression.cpp:75-187)"""
+    text = open(os.path.join(ROOT, "include", "lz4", "lz4.h")).read()
+    names = re.findall(r"TRICO_API[^;(]*?\b(LZ4_\w+)\s*\(", text)
+    assert sorted(names) == ["LZ4_compressBound", "LZ4_compress_default", "LZ4_decompress_safe", "LZ4_initStream"]
+    L = ctypes.CDLL(native_libs.LIB_PATH)
+    for n in names + ["trico_read_vec2_double"]:          # (the latter: exported by the reference's shared library, in no header)
+        assert hasattr(L, n), n
+    L.LZ4_compressBound.restype = ctypes.c_int
+    for n in (0, 1, 254, 255, 65547, 0x7E000000):
+        assert L.LZ4_compressBound(n) == n + n // 255 + 16
+    assert L.LZ4_compressBound(0x7E000001) == 0 and L.LZ4_compressBound(-1) == 0
+    # the stream state callers put on their stack (trico.c:339-341): size and alignment rules of lz4.c:1408-1420
+    L.LZ4_initStream.restype = ctypes.c_void_p
+    L.LZ4_initStream.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    buf = (ctypes.c_uint64 * 2052)()
+    assert L.LZ4_initStream(buf, 2052 * 8) == ctypes.addressof(buf)
+    assert L.LZ4_initStream(buf, 2052 * 8 - 1) is None
+    assert L.LZ4_initStream(ctypes.addressof(buf) + 4, 2051 * 8 + 4) is None
+    if not L.trico_hip_available():
+        # no device: the codec fails, it does not fall back
+        src = (ctypes.c_char * 64)()
+        dst = (ctypes.c_char * 128)()
+        assert L.LZ4_compress_default(src, dst, 64, 128) == 0
+        assert L.LZ4_decompress_safe(src, dst, 10, 128) < 0
+
+
 def test_writers_fail_loudly_without_gpu(native_libs):
     L = native_libs.lib()
     if L.trico_hip_available():

@@ -39,6 +39,19 @@ def test_rank_body_world2(shard, native_libs):
     assert j["config"]["parity"] == "sha256 == reference golden", j["config"]
     golden = json.load(open(os.path.join(ROOT, "tests", "golden", "hashes.json")))["grid_1000x1000"]
     assert j["config"]["archive_bytes_rank0"] == golden["bytes"] if "bytes" in golden else True
+    # the self-diagnosis of an N > 1 line: what the backend says about the job, one row per rank
+    rk = j["ranks"]
+    assert rk["collective"]["backend"] == "gloo" and rk["collective"]["world_size_as_reported"] == 2
+    assert [r["rank"] for r in rk["per_rank"]] == [0, 1] and len({r["pid"] for r in rk["per_rank"]}) == 2
+    for r in rk["per_rank"]:
+        assert r["roundtrip_ok"] is True and r["rank_ms_per_step"] > 0
+        assert {"mesh_seed", "archive_bytes", "archive_sha256", "parity", "gathered_bytes_seen", "rank_encode_ms", "rank_gather_ms", "rank_decode_ms"} <= set(r)
+    if shard == "meshes":
+        assert rk["per_rank"][0]["archive_sha256"] == golden["sha256"][:16] and rk["per_rank"][0]["mesh_seed"] != rk["per_rank"][1]["mesh_seed"]
+        assert rk["per_rank"][0]["gathered_bytes_seen"] >= rk["per_rank"][0]["archive_bytes"] + rk["per_rank"][1]["archive_bytes"]
+    # the keys of the driver's contract close the line (its stdout_tail keeps the end)
+    keys = list(j)
+    assert keys.index("value") > keys.index("kernels") and keys[-1] in ("roofline", "cpu_baseline")
 
 
 @pytest.mark.parametrize("ranks", [2, 3])
@@ -54,6 +67,10 @@ def test_decode_mixed_rank_body(ranks, native_libs):
     raw = [n * 12 + 2 * n * 12, n * 12 + 2 * n * 12, 2 * n * 24 + n * 8 + 2 * n * 24]
     assert j["config"]["decoded_bytes_all_ranks"] == sum(raw[:ranks])
     assert j["config"]["parity_rank0"] == "sha256 == reference golden"
+    rk = j["ranks"]
+    assert rk["collective"]["world_size_as_reported"] == ranks and [r["rank"] for r in rk["per_rank"]] == list(range(ranks))
+    assert [r["kind"] for r in rk["per_rank"]] == ["grid", "walk", "multi"][:ranks]
+    assert all(r["parity"] == "sha256 == reference golden" for r in rk["per_rank"])
 
 
 def test_committed_pmc_summary_parses():
@@ -66,3 +83,8 @@ def test_committed_pmc_summary_parses():
     assert files
     t = bench._pmc_file_traffic(files[-1])
     assert t and 1.2e9 < t < 3e9, t
+    # the double encoder's summary (config3.roofline.traffic): every kernel of the stream, per k64_sizes dispatch
+    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_fpc64_encode_hbm_traffic_pmc.txt"))) if "_before_" not in f]
+    assert files
+    t = bench._pmc_file_traffic(files[-1], family=None, per_launch_of=("k64_sizes",))
+    assert t and 5e9 < t < 60e9, t

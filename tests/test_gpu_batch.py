@@ -209,13 +209,29 @@ def test_payload_of_another_writer_is_decoded_and_counted(api):
     stats = (ctypes.c_uint32 * 4)()
     api.lib().trico_hip_last_stats(stats)
     before = stats[3]
+    L = api.lib()
+    L.trico_hip_archive_other_writer_streams.restype = ctypes.c_uint32
+    L.trico_hip_archive_other_writer_streams.argtypes = [ctypes.c_void_p]
     r = api.Archive.open_for_reading(blob)
+    assert L.trico_hip_archive_other_writer_streams(r.h) == 0
     got = r.read_alloc("attributes_float", 8, np.float32)
     assert got is not None, api.last_error()
     assert got.tolist() == [1.0] * 8
+    assert L.trico_hip_archive_other_writer_streams(r.h) == 1      # the per-handle query: no environment variable needed to see it
     r.close()
     api.lib().trico_hip_last_stats(stats)
     assert stats[3] == before + 1
+    # a strict reader (trico_hip_set_strict, the programmatic TRICO_HIP_STRICT=1) refuses the stream instead
+    L.trico_hip_set_strict(1)
+    try:
+        r = api.Archive.open_for_reading(blob)
+        assert r.read_alloc("attributes_float", 8, np.float32) is None
+        assert "strict" in api.last_error()
+        r.close()
+    finally:
+        L.trico_hip_set_strict(-1)
+    api.lib().trico_hip_last_stats(stats)
+    before += 1
     # the canonical payload of the same values raises no flag
     pay = bytes.fromhex("25" "00000008" "00002c" "3f800000" "00")
     blob = struct.pack("<II", 0x6f637254, 0) + bytes([15]) + struct.pack("<I", 8) + struct.pack("<I", len(pay)) + pay

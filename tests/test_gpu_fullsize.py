@@ -51,6 +51,32 @@ def test_config2_full_size(api, hashes):
     assert _repeats(api) == before            # the chains were right by themselves: the self-check had nothing to repeat
 
 
+def test_config2_vertices_full_size_with_full_encode_verification(api, hashes):
+    """The same 50 M vertices with trico_hip_set_encode_verify(1): all 150 M values coded a second time by the ballot coder and compared
+    byte for byte on the device - the exchange coder and the ballot coder agree on every one of them (the write-side
+    guard alone samples 0.04 %)."""
+    import ctypes
+    L = api.lib()
+    L.trico_hip_encode_verify_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+    before = (ctypes.c_uint64 * 3)()
+    after = (ctypes.c_uint64 * 3)()
+    L.trico_hip_encode_verify_stats(before)
+    dev = _device_streams(mesh_streams("grid", 10000, 5000))
+    L.trico_hip_set_encode_verify(1)
+    try:
+        a = api.Archive.open_for_writing(1 << 20, device=True)
+        for name, d, cnt in dev:
+            assert a.write(name, d, cnt) == 1, api.last_error()
+        blob = a.tobytes()
+        a.close()
+    finally:
+        L.trico_hip_set_encode_verify(-1)
+    L.trico_hip_encode_verify_stats(after)
+    g = hashes["grid_10000x5000"]
+    assert len(blob) == g["size"] and hashlib.sha256(blob).hexdigest() == g["sha256"]
+    assert after[0] - before[0] == 1 and after[1] - before[1] == 150_000_000 and after[2] == before[2]
+
+
 class _Full:
     """One full-size archive kept on the device for the tests below: (device inputs, archive handle)."""
     cache = {}

@@ -181,3 +181,38 @@ print("SENT", out[0], out[1], L.trico_hip_fpc32_code_sweep())
 """
     out = subprocess.run([sys.executable, "-c", child % {"root": ROOT}], env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "SENT 0 1 3" in out.stdout, out.stdout + out.stderr
+
+
+VERIFY_TAIL = r"""
+import ctypes
+vs = (ctypes.c_uint64 * 3)()
+api.lib().trico_hip_encode_verify_stats(vs)
+print("VERIFY", vs[0], vs[1], vs[2])
+"""
+
+
+def test_full_encode_verification_agrees_on_every_value():
+    """trico_hip_set_encode_verify / TRICO_HIP_ENCODE_VERIFY=1: every float stream of the stress archive above is coded a second time by
+    the ballot coder and compared byte for byte on the device: the exchange coder and the ballot coder agree on 100 %% of the values
+    (the write-side guard samples 0.04 %%), and the archive is still the reference's."""
+    env = dict(os.environ)
+    env["TRICO_HIP_ENCODE_VERIFY"] = "1"
+    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "mode": 3} + VERIFY_TAIL], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "ONESWEEP OK" in out.stdout, out.stdout + out.stderr
+    streams, values, differed = [int(x) for x in out.stdout.split("VERIFY")[1].split()[:3]]
+    assert streams >= 38 and values > 5_000_000 and differed == 0, (streams, values, differed)
+
+
+def test_full_encode_verification_catches_what_the_sampling_guard_is_told_to_ignore():
+    """Test-hooks library: the exchange sabotaged (TRICO_HIP_ENCODE_SABOTAGE=1) AND the guard's flags ignored (TRICO_HIP_ENCODE_KEEP_FLAGGED):
+    the one-sweep coder's wrong payload would reach the archive.  With the full verification on, the comparison with the ballot coder
+    notices, the ballot coder's payload is written, and every archive is the reference's."""
+    child = GUARD_CHILD + VERIFY_TAIL
+    env = dict(os.environ)
+    env["TRICO_AMD_LIB"] = os.path.join(ROOT, "tests", "_build", "libtrico_testhooks.so")
+    env.update({"TRICO_HIP_ENCODE_SABOTAGE": "1", "TRICO_HIP_ENCODE_KEEP_FLAGGED": "1", "TRICO_HIP_ENCODE_VERIFY": "1"})
+    out = subprocess.run([sys.executable, "-c", child % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "VERIFY" in out.stdout, out.stdout + out.stderr
+    streams, values, differed = [int(x) for x in out.stdout.split("VERIFY")[1].split()[:3]]
+    assert streams >= 1 and differed >= 1, (streams, values, differed)
+    assert "ENCODE VERIFICATION FAILED" in out.stderr

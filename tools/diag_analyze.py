@@ -61,3 +61,14 @@ gi = (main // arity)
 for lo in range(0, S, max(1, S // 8)):
     m = main[(gi >= lo) & (gi < lo + max(1, S // 8))]
     print("  segments %5d..: loop time median %.1f us, end median %.1f" % (lo, np.median((l1 - l0)[m]), np.median(end[m])))
+# by order of arrival on the compute unit (blockIdx / number of units): loop time and end of the slow component's waves
+z = np.arange(S) * arity + slow
+order = {}
+k = np.zeros(S, int)
+for g in range(S):
+    u = int(cuid[z[g]])
+    k[g] = order.get(u, 0)
+    order[u] = k[g] + 1
+print("  by arrival on the unit, loop time median: " + " ".join("%d:%.0f" % (kk, np.median((l1 - l0)[z][k == kk])) for kk in range(k.max() + 1)))
+print("  by arrival on the unit, end median:       " + " ".join("%d:%.0f" % (kk, np.median(end[z][k == kk])) for kk in range(k.max() + 1)))
+print("  by arrival on the unit, end max:          " + " ".join("%d:%.0f" % (kk, np.max(end[z][k == kk])) for kk in range(k.max() + 1)))

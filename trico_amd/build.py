@@ -26,7 +26,7 @@ CC = os.environ.get("CC", "gcc")
 ARCH = "gfx950"
 EXTRA = os.environ.get("TRICO_HIPCC_FLAGS", "").split()      # experiments: extra compiler flags for the HIP sources (e.g. -DTRICO_PF=4)
 
-HOST_C = ["host/archive.c", "host/lowlevel.c"]
+HOST_C = ["host/archive.c", "host/lowlevel.c", "host/lz4_api.c"]
 HIP_SRC = sorted(f for f in os.listdir(os.path.join(CSRC, "hip")) if f.endswith(".hip"))
 HIP_HDR = sorted(f for f in os.listdir(os.path.join(CSRC, "hip")) if f.endswith((".hpp", ".inc")))      # (.inc: generated chain bodies)
 
@@ -56,7 +56,7 @@ def _stale(target, deps):
 def build(force=False, verbose=True, test_hooks=False):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
-    headers = [os.path.join(INCLUDE, "trico", h) for h in ("trico.h", "trico_hip.h")]
+    headers = [os.path.join(INCLUDE, "trico", h) for h in ("trico.h", "trico_hip.h")] + [os.path.join(INCLUDE, "lz4", "lz4.h")]
     headers += [os.path.join(CSRC, "hip", h) for h in HIP_HDR]
     objs = []
     hook_objs = {}

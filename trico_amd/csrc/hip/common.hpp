@@ -69,6 +69,7 @@ struct trico_hip_ctx
   // the decode the self-check belongs to (it may have to be repeated)
   bool chk_active = false;
   bool other_writer_seen = false;      // a stream of this context decoded to values that do not code back even in reference order
+  uint32_t other_writer_streams = 0;   // how many (trico_hip_ctx_other_writer_streams)
   const uint8_t* chk_pay[3] = { nullptr, nullptr, nullptr };
   uint32_t chk_sizes[3] = { 0, 0, 0 };
   int chk_arity = 0, chk_width = 0;
@@ -208,6 +209,7 @@ int launch_lz4_encode_wave(const uint8_t* d_planes, size_t plane_stride, uint32_
 
 
 // LDS-window LZ4 decompressor (k_lz4_decode.hip): one workgroup per plane
+int launch_lz4_measure(const uint8_t* d_payload, uint32_t size, uint32_t capacity, uint32_t* d_out);      // decoded size of one block (k_lz4_decode.hip)
 int launch_lz4_decode_lds(const uint8_t* const d_payloads[8], const uint32_t sizes[8], int nplanes,
                           uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, uint32_t* d_status);
 

@@ -252,7 +252,7 @@ bool reserve_all(const Plan& p, int count)
   }
 
 // the single-stream path with its ladder (shim.hip), on a context of its own: for jobs the batch could not settle
-int redo_single(const trico_hip_decode_job& j, const uint8_t* const d_pay[8], void* d_dst, int first_attempt)
+int redo_single(trico_hip_decode_job& j, const uint8_t* const d_pay[8], void* d_dst, int first_attempt)
   {
   trico_hip_ctx* ctx = trico_hip_ctx_create();
   if (!ctx)
@@ -261,6 +261,7 @@ int redo_single(const trico_hip_decode_job& j, const uint8_t* const d_pay[8], vo
   const int ok = j.is_int ? trico_hip_int_decode(ctx, d_pay, j.sizes, j.width, j.n, d_dst)
                           : trico_hip_fpc_decode(ctx, d_pay, j.sizes, j.arity, j.width, j.n, d_dst);
   set_first_attempt(0);
+  j.other_writer = trico_hip_ctx_other_writer_streams(ctx) ? 1 : 0;
   trico_hip_ctx_destroy(ctx);
   return ok;
   }
@@ -327,6 +328,7 @@ static int run_batch(trico_hip_decode_job* jobs, int count)
     {
     kind[i] = classify(jobs[i]);
     jobs[i].ok = kind[i] == K_SKIP ? 1 : 0;
+    jobs[i].other_writer = 0;
     }
   const Plan plan = make_plan(jobs, count, kind);
   hipStream_t user = current_stream();
@@ -593,6 +595,7 @@ int trico_hip_decode_jobs(trico_hip_decode_job* jobs, int count)
         for (int i = 0; i < w->count; ++i)
           {
           w->jobs[i].ok = all[at + i].ok;
+          w->jobs[i].other_writer = all[at + i].other_writer;
           attempted = attempted && all[at + i].ok >= 0;
           }
         // the combined batch could not be launched (its workspaces are the sum of everybody's): one caller's resource problem is

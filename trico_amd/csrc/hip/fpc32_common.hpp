@@ -31,13 +31,28 @@ constexpr uint32_t FLAG_ORDER = FPC32_FLAG_ORDER, FLAG_SENTINEL = FPC32_FLAG_SEN
 //   w2 the value   w3 its predecessor   w4 the prediction that IS known (one open class), else 0
 //   w5 4 * DFCM class of the value      w6 residual, w7 length | code << 4  (written by the fix-up)
 // gi = index in the group; ft1 / ft2 = the FCM / DFCM prediction is the one the segment does not know (the FCM class is the top
-// four bits of w3).  Slot offsets stay below 2^24: a segment's slot is 4.4 bytes per value of at most n / 2544 values.
+// four bits of w3).  Slot offsets stay below 2^24: make_plan caps the segment length (L_MAX) whatever the device's resident target is.
 constexpr uint32_t REC_POS = 0x00ffffffu, REC_GI_SHIFT = 24, REC_FT1 = 1u << 28, REC_FT2 = 1u << 29;
 constexpr uint32_t REC_CMPW = 6;  // words the sweep writes (what the write-side guard compares)
+
+// Segment lengths by order of dispatch.  The workgroups of the one-sweep coder are all resident at once, a compute unit holds K of
+// them, and the k-th one it was given (blockIdx / number of compute units: the dispatcher hands every unit its k-th workgroup before
+// any gets its k+1-th) is the k-th oldest on its SIMDs: the hardware issues the oldest ready wave first, so with equal segments the
+// youngest workgroups finished 25 % (benchmark mesh) to 58 % (three noisy components) later than the oldest and the last fifth of the
+// kernel ran on a half-empty device (profiles/r06_sweep_stagger.txt).  Hence classes of C consecutive segments whose length falls
+// with the class: everybody ends at about the same time.  Class k: `first[k]` segments of len[k] values, the others 512 fewer,
+// beginning at value index base[k]; every length is a multiple of 512.  K == 0: all segments have Plan::L values.
+constexpr int STAGGER_MAX = 32;
+struct Stagger
+  {
+  uint32_t C, K;
+  uint32_t base[STAGGER_MAX], len[STAGGER_MAX], first[STAGGER_MAX];
+  };
 
 struct Plan
   {
   uint32_t L, S, segcap, nch;
+  Stagger sg;
   size_t rows, slot_stride;
   size_t off_summ, off_inc, off_chmax, off_nrec, off_recs, off_segbytes, off_rawbytes, off_segoff, off_gslots, off_grecs, off_gmeta, off_diag, off_slots, total;
   };
@@ -46,6 +61,8 @@ struct Plan
 // grid resident in ONE round: a workgroup that has to wait for a free place starts when the first ones are done and ends a segment's
 // time later (measured with TRICO_SWEEP_DIAG in round 5: 10 % of the workgroups in a second round were 40 % of the kernel's time).
 int fpc32_sweep_resident_workgroups(int arity);
+int fpc32_sweep_class_size();                 // segments per class of the staggered geometry: the compute units of the current device
+int fpc32_sweep_stagger_permille();           // how much longer than the mean the first class's segments are (the last: shorter), in 1/1000
 
 inline Plan make_plan(uint32_t n, int arity)
   {
@@ -57,10 +74,63 @@ inline Plan make_plan(uint32_t n, int arity)
   uint64_t L = ((uint64_t)n + target - 1) / target;
   L = (L + 511) / 512 * 512;                    // whole blocks of eight steps: the hand-written loop of the sweep takes those, the compiled step the rest
   if (L < 1024) L = 1024;
+  // a record keeps slot offsets in 24 bits (REC_POS): on a device with few compute units (a partition) the resident target would
+  // make the segments of a large stream longer than that - then there are more segments than resident workgroups instead
+  constexpr uint64_t L_MAX = 3800064;           // 7422 blocks of 512 values: 5 + 4.375 L + 296 rounded up to 256 stays below 2^24
+  static_assert(5 + 4 * L_MAX + 3 * (L_MAX / 8) + 16 + 280 + 256 <= (uint64_t)REC_POS + 1, "slot offsets of a record");
+  if (L > L_MAX) L = L_MAX;
   p.L = (uint32_t)L;
   p.S = (uint32_t)(((uint64_t)n + L - 1) / L);
   if (p.S == 0) p.S = 1;
-  p.segcap = (uint32_t)align_up(5 + 4 * (size_t)L + 3 * ((size_t)L / 8) + 16 + 280, 256);
+  // the staggered geometry of the one-sweep coder: the same S segments, the same blocks of 512 values in total
+  p.sg.C = p.sg.K = 0;
+  uint64_t Lmax = L;
+  {
+  const uint32_t C = (uint32_t)fpc32_sweep_class_size();
+  const uint32_t beta = (uint32_t)fpc32_sweep_stagger_permille();
+  const uint32_t K = C ? (p.S + C - 1) / C : 0u;
+  const uint64_t B = ((uint64_t)n + 511) / 512;                       // blocks of the stream
+  if (beta > 0 && K >= 2 && K <= (uint32_t)STAGGER_MAX && B >= 4ull * p.S)
+    {
+    // weight of class k: 1 + beta * (1 - 2 (k + 1/2) / K), normalised over the segments; blocks of the class = its share, rounded so
+    // that the classes add up to B
+    double wsum = 0;
+    double w[STAGGER_MAX];
+    uint32_t cnt[STAGGER_MAX];
+    for (uint32_t k = 0; k < K; ++k)
+      {
+      cnt[k] = k + 1 < K ? C : p.S - k * C;
+      w[k] = 1.0 + (double)beta / 1000.0 * (1.0 - (2.0 * k + 1.0) / (double)K);
+      wsum += w[k] * cnt[k];
+      }
+    uint64_t given = 0, at = 0;
+    double acc = 0;
+    bool ok = true;
+    for (uint32_t k = 0; k < K; ++k)
+      {
+      acc += w[k] * cnt[k] / wsum * (double)B;
+      uint64_t upto = k + 1 < K ? (uint64_t)(acc + 0.5) : B;
+      if (upto > B) upto = B;
+      const uint64_t Tk = upto - given;                                 // blocks of class k
+      given = upto;
+      const uint64_t lk = (Tk + cnt[k] - 1) / cnt[k];                   // blocks of its longer segments
+      if (lk < 3 || lk * 512 > L_MAX) { ok = false; break; }
+      p.sg.base[k] = (uint32_t)(at * 512);
+      p.sg.len[k] = (uint32_t)(lk * 512);
+      p.sg.first[k] = (uint32_t)(cnt[k] - (lk * cnt[k] - Tk));          // the others: one block fewer
+      at += Tk;
+      if (lk * 512 > Lmax) Lmax = lk * 512;
+      }
+    if (ok)
+      {
+      p.sg.C = C;
+      p.sg.K = K;
+      }
+    else
+      Lmax = L;
+    }
+  }
+  p.segcap = (uint32_t)align_up(5 + 4 * (size_t)Lmax + 3 * ((size_t)Lmax / 8) + 16 + 280, 256);
   p.nch = (p.S + CH - 1) / CH;
   p.rows = (size_t)p.S * arity;
   p.slot_stride = (size_t)p.S * p.segcap;
@@ -83,6 +153,21 @@ inline Plan make_plan(uint32_t n, int arity)
   }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// first value and number of values of segment g (the last segment of a stream ends with the stream: the caller clips)
+__host__ __device__ __forceinline__ void segment_range(const Stagger& sg, uint32_t L, uint32_t g, uint32_t& begin, uint32_t& len)
+  {
+  if (sg.K == 0u)
+    {
+    begin = g * L;
+    len = L;
+    return;
+    }
+  const uint32_t k = g / sg.C, j = g - k * sg.C;
+  const uint32_t f = sg.first[k], lk = sg.len[k];
+  begin = sg.base[k] + j * lk - (j > f ? (j - f) * 512u : 0u);
+  len = j < f ? lk : lk - 512u;
+  }
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 __device__ __forceinline__ uint32_t dpp_shr1(uint32_t carry, uint32_t v)

@@ -42,6 +42,7 @@ constexpr int LDSW = 1312;                        // per-wave LDS words: TAB + S
                                                   // at a multiple of 64 bytes (5,248 B: 10 workgroups of 3 waves per CU)
 static_assert(LDSW >= TAB + STAGE / 4 && (LDSW * 4) % 64 == 0 && (TAB * 4) % 8 == 0, "LDS layout of a wave");
 
+constexpr int STAGGER_DEFAULT = 300;                // Stagger (fpc32_common.hpp): first class + 30 %, last class - 30 % (measured: profiles/r06_sweep_stagger.txt)
 constexpr uint32_t GUARD_STEPS = 64;              // steps of a sampled segment the guard codes again
 constexpr uint32_t GUARD_CAP = GUARD_SLOT;        // bytes they can produce (a step: 24 header + 256 residual bytes), rounded
 
@@ -1065,7 +1066,7 @@ __device__ __forceinline__ uint32_t sweep_end(Sweep& sw, uint8_t* __restrict__ s
 struct GuardMeta { uint32_t seg, bytes, nrec, pad; };
 
 template <bool HOOK>
-__device__ __forceinline__ void guard_segment(const uint32_t* __restrict__ src, uint32_t n, uint32_t arity, uint32_t L, uint32_t S, uint32_t j,
+__device__ __forceinline__ void guard_segment(const uint32_t* __restrict__ src, uint32_t n, uint32_t arity, uint32_t L, const Stagger& sg, uint32_t S, uint32_t j,
                                               uint32_t c, uint32_t lane, uint32_t seed, uint32_t* __restrict__ lds, uint8_t* __restrict__ gslots,
                                               uint32_t* __restrict__ grecs, GuardMeta* __restrict__ gmeta, uint32_t rblocks)
   {
@@ -1074,8 +1075,9 @@ __device__ __forceinline__ void guard_segment(const uint32_t* __restrict__ src, 
   uint8_t* stage = (uint8_t*)(T + TAB);
   const uint32_t t1abs = (uint32_t)(uintptr_t)(lds_u8*)T;
   const LaneK lk = lane_constants(lane);
-  const uint32_t i_begin = g * L;
-  const uint32_t seg_end = (n - i_begin < L) ? n : i_begin + L;
+  uint32_t i_begin, Lg;
+  segment_range(sg, L, g, i_begin, Lg);
+  const uint32_t seg_end = (n - i_begin < Lg) ? n : i_begin + Lg;
   const uint32_t i_end = (seg_end - i_begin < 64u * GUARD_STEPS) ? seg_end : i_begin + 64u * GUARD_STEPS;
   const size_t row = (size_t)j * arity + c;
   uint8_t* gbase = gslots + row * GUARD_CAP;
@@ -1105,7 +1107,7 @@ __device__ __forceinline__ void guard_segment(const uint32_t* __restrict__ src, 
 // ASM = false: every step through the compiled code_step (TRICO_FPC32_ASM=0, for A/B runs)
 template <bool HOOK, bool ASM>
 __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8)))
-k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t L, uint32_t S, uint32_t* __restrict__ outT,
+k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t L, const Stagger sg, uint32_t S, uint32_t* __restrict__ outT,
               uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap, uint32_t* __restrict__ segbytes, uint32_t* __restrict__ rawbytes,
               uint32_t* __restrict__ nrec, uint32_t* __restrict__ recs, uint32_t sabotage, uint32_t seed,
               uint8_t* __restrict__ gslots, uint32_t* __restrict__ grecs, GuardMeta* __restrict__ gmeta, uint64_t* __restrict__ diag,
@@ -1119,7 +1121,7 @@ k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t 
 #endif
   if (g >= S)
     {
-    guard_segment<HOOK>(src, n, (uint32_t)arity, L, S, g - S, c, lane, seed, lds, gslots, grecs, gmeta, rblocks);
+    guard_segment<HOOK>(src, n, (uint32_t)arity, L, sg, S, g - S, c, lane, seed, lds, gslots, grecs, gmeta, rblocks);
 #ifdef TRICO_SWEEP_DIAG
     if (lane == 0)
       {
@@ -1135,8 +1137,9 @@ k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t 
   uint8_t* stage = (uint8_t*)(T + TAB);
   const uint32_t t1abs = (uint32_t)(uintptr_t)(lds_u8*)T;                  // LDS address of the wave's tables (a multiple of 64)
   const LaneK lk = lane_constants(lane);
-  const uint32_t i_begin = g * L;
-  const uint32_t i_end = (n - i_begin < L) ? n : i_begin + L;
+  uint32_t i_begin, Lg;
+  segment_range(sg, L, g, i_begin, Lg);
+  const uint32_t i_end = (n - i_begin < Lg) ? n : i_begin + Lg;
   uint8_t* gbase = slots + (size_t)c * slot_stride + (size_t)g * segcap;
   const rsrc_t slot = make_rsrc(gbase, segcap);
   const size_t rowi = (size_t)g * arity + c;
@@ -1822,6 +1825,33 @@ int fpc32_sweep_resident_workgroups(int arity)
   return have;
   }
 
+int fpc32_sweep_class_size()
+  {
+  static std::atomic<int> cache[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16)
+    dev = 0;
+  int have = cache[dev].load();
+  if (have == 0)
+    {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      {
+      (void)hipGetLastError();
+      cus = 256;
+      }
+    have = cus;
+    cache[dev].store(have);
+    }
+  return have;
+  }
+
+int fpc32_sweep_stagger_permille()
+  {
+  static const int beta = [] { const char* e = tune_env("TRICO_FPC32_STAGGER"); const int v = e ? atoi(e) : STAGGER_DEFAULT; return v < 0 ? 0 : v > 800 ? 800 : v; }();
+  return beta;
+  }
+
 int launch_fpc32_sweep(const uint32_t* d_src, uint32_t n, int arity, const Plan& p, uint8_t* d_ws)
   {
   hipStream_t st = current_stream();
@@ -1857,10 +1887,10 @@ int launch_fpc32_sweep(const uint32_t* d_src, uint32_t n, int arity, const Plan&
 #endif
   constexpr bool HOOK = SWEEP_HOOK;
   if (use_asm)
-    hipLaunchKernelGGL((k_fpc32_sweep<HOOK, true>), dim3(p.S + G), dim3(threads), lds, st, d_src, n, arity, p.L, p.S, outT,
+    hipLaunchKernelGGL((k_fpc32_sweep<HOOK, true>), dim3(p.S + G), dim3(threads), lds, st, d_src, n, arity, p.L, p.sg, p.S, outT,
                        slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, sabotage, seed, gslots, grecs, gmeta, diag, rblocks);
   else
-    hipLaunchKernelGGL((k_fpc32_sweep<HOOK, false>), dim3(p.S + G), dim3(threads), lds, st, d_src, n, arity, p.L, p.S, outT,
+    hipLaunchKernelGGL((k_fpc32_sweep<HOOK, false>), dim3(p.S + G), dim3(threads), lds, st, d_src, n, arity, p.L, p.sg, p.S, outT,
                        slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, sabotage, seed, gslots, grecs, gmeta, diag, rblocks);
 #ifdef TRICO_SWEEP_DIAG
   {

@@ -36,6 +36,7 @@
 //   keys    both hashes of every value, and an index array
 //   sort    (k_sort.hip: stable LSD radix sort, two 10-bit passes): (hash, index) pairs, one sort per table
 //   preds   (k64_pred):   sorted neighbour with the same hash -> its payload, scattered back to the value's index
+#include <atomic>
 #include "common.hpp"
 #include <stdlib.h>
 
@@ -599,6 +600,23 @@ int table_count(const u64* src, uint32_t n, int arity, const EncPlan& p, uint32_
   return 1;
   }
 
+// k64_home takes a tile's window of predictions into 128 KiB of dynamic LDS: the attribute belongs to the (function, device) pair, so it
+// is claimed once per device of the process, not once per process
+static bool home_lds_claimed()
+  {
+  static std::atomic<int> state[16];             // 0 not asked, 1 claimed, 2 refused
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16)
+    return hipFuncSetAttribute((const void*)k64_home, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(HOME_TILE_MAX * 8u)) == hipSuccess;
+  int s = state[dev].load();
+  if (s == 0)
+    {
+    s = hipFuncSetAttribute((const void*)k64_home, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(HOME_TILE_MAX * 8u)) == hipSuccess ? 1 : 2;
+    state[dev].store(s);
+    }
+  return s == 1;
+  }
+
 // the lists of table T written, walked, the results taken home to pred.  Events (each may be null): recorded behind the scatter and
 // behind the walk; waited for in front of the walk and in front of the way home.
 struct Marks { hipEvent_t scattered, walked, before_walk, before_home; };
@@ -606,8 +624,7 @@ template <int T>
 int table_walk(const u64* src, uint32_t n, int arity, const EncPlan& p, const uint32_t* hist, Op* ops, Op* done, Op* sink, u64* pred,
                hipStream_t st, const Marks& m)
   {
-  static const bool claimed = hipFuncSetAttribute((const void*)k64_home, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(HOME_TILE_MAX * 8u)) == hipSuccess;
-  if (!claimed)
+  if (!home_lds_claimed())
     {
     set_error("fpc64 throughput encoder: cannot claim 128 KiB of LDS");
     return 0;
@@ -711,8 +728,7 @@ int both_tables(const u64* src, uint32_t n, int arity, const EncPlan& p, uint8_t
   int ok = 1;
   const uint32_t lists = (uint32_t)arity * OWNERS;
   const unsigned blocks = (p.ntiles + 3u) / 4u;
-  static const bool claimed = hipFuncSetAttribute((const void*)k64_home, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(HOME_TILE_MAX * 8u)) == hipSuccess;
-  if (!claimed)
+  if (!home_lds_claimed())
     {
     set_error("fpc64 throughput encoder: cannot claim 128 KiB of LDS");
     return 0;

@@ -514,7 +514,7 @@ __global__ void __launch_bounds__(64) k_lz4_parse(const uint8_t* __restrict__ pl
   const uint8_t* src = planes + (size_t)p * g.plane_stride;
   const uint32_t c_lo = k * g.chunk;
   const uint32_t c_hi = (k + 1u == g.K) ? 0xffffffffu : c_lo + g.chunk;
-  lz4_parse<1, 8>(src, g.n, tab, g.xchg ? nullptr : dup, k == 0 ? 0u : c_lo - g.warm, false, k == 0, k == 0, c_lo, c_hi, descs + ck * g.dcap, g.dcap, meta,
+  lz4_parse<1, 8>(src, g.n, tab, g.xchg ? nullptr : dup, k == 0 || c_lo < g.warm ? 0u : c_lo - g.warm, false, k == 0, k == 0, c_lo, c_hi, descs + ck * g.dcap, g.dcap, meta,
                   snapTs + ck * 4096, endTs + ck * 4096, lane, 0, nullptr, open_after(g));
   }
 
@@ -1190,7 +1190,7 @@ Plan make_plan(uint32_t n, int nplanes, size_t plane_stride, int mode)
     if (short_chunk > (192u << 10)) short_chunk = 192u << 10;
     }
   const uint32_t chunk = forced || mode == 0 ? env_chunk : short_chunk;
-  const uint32_t warm = forced || mode == 0 ? env_warm : 70000u;
+  const uint32_t warm = forced || mode == 0 ? env_warm : (chunk < 70000u ? chunk : 70000u);      // never more than a chunk: k_lz4_parse starts chunk k at k * chunk - warm
   Plan p;
   p.g.n = n;
   p.g.chunk = chunk;

@@ -15,6 +15,7 @@
 //   * copies of 4 KiB and more go to all 16 waves (job + barrier): literals global -> global, matches as
 //     a periodic fill from the LDS ring; both refresh the ring's last 64 KiB.
 // Latency-bound on the chain for short sequences, HBM-bound on long runs.
+#include <atomic>
 #include "common.hpp"
 
 namespace trico {
@@ -374,7 +375,68 @@ __global__ void __launch_bounds__(WG) k_lz4_decode_lds(Lz4DecArgs a, uint8_t* __
   __syncthreads();
   }
 
+// The decoded size of a block, for callers that only know an upper bound (LZ4_decompress_safe's dstCapacity, lz4.h:153-158): one
+// thread follows the sequences as the safe decoder does (lz4.c:1700-1850: token, literal length, literals, offset, match length)
+// without moving a byte.  out[0] = size, out[1] = 0; or out[1] = 1 for a block that leaves its input, decodes to more than
+// `capacity` bytes or has a match reaching before the output's start.  Slow (a memory round trip per sequence) and rare: the archive
+// format always knows the exact size (trico.c:1100-1129), so the decoders are tried with the capacity first.
+__global__ void k_lz4_measure(const uint8_t* __restrict__ src, uint32_t size, uint32_t capacity, uint32_t* __restrict__ out)
+  {
+  uint64_t op = 0;
+  uint32_t ip = 0;
+  uint32_t bad = 0;
+  if (size == 0)
+    bad = 1;
+  while (!bad)
+    {
+    const uint32_t token = src[ip++];
+    uint64_t lit = token >> 4;
+    if (lit == 15)
+      {
+      uint32_t b;
+      do
+        {
+        if (ip >= size) { bad = 1; break; }
+        b = src[ip++];
+        lit += b;
+        } while (b == 255);
+      }
+    if (bad || lit > (uint64_t)(size - ip)) { bad = 1; break; }
+    ip += (uint32_t)lit;
+    op += lit;
+    if (op > capacity) { bad = 1; break; }
+    if (ip == size)
+      break;                                       // the last sequence: literals only
+    if (size - ip < 2) { bad = 1; break; }
+    const uint32_t off = (uint32_t)src[ip] | ((uint32_t)src[ip + 1] << 8);
+    ip += 2;
+    if (off == 0 || off > op) { bad = 1; break; }
+    uint64_t ml = token & 15;
+    if (ml == 15)
+      {
+      uint32_t b;
+      do
+        {
+        if (ip >= size) { bad = 1; break; }
+        b = src[ip++];
+        ml += b;
+        } while (b == 255);
+      }
+    if (bad) break;
+    op += ml + 4;
+    if (op > capacity || ip >= size) { bad = 1; break; }      // (a block never ends with a match: the last five bytes are literals, lz4.c:826)
+    }
+  out[0] = bad ? 0u : (uint32_t)op;
+  out[1] = bad;
+  }
+
 } // namespace
+
+int launch_lz4_measure(const uint8_t* d_payload, uint32_t size, uint32_t capacity, uint32_t* d_out)
+  {
+  hipLaunchKernelGGL(k_lz4_measure, dim3(1), dim3(1), 0, current_stream(), d_payload, size, capacity, d_out);
+  return hip_ok(hipGetLastError(), "k_lz4_measure") ? 1 : 0;
+  }
 
 int launch_lz4_decode_lds(const uint8_t* const d_payloads[8], const uint32_t sizes[8], int nplanes,
                           uint8_t* d_planes, size_t plane_stride, uint32_t plane_bytes, uint32_t* d_status)
@@ -385,13 +447,18 @@ int launch_lz4_decode_lds(const uint8_t* const d_payloads[8], const uint32_t siz
     a.pay[c] = c < nplanes ? d_payloads[c] : nullptr;
     a.size[c] = c < nplanes ? sizes[c] : 0;
     }
-  static bool attr_set = false;
-  if (!attr_set)
+  // (the attribute belongs to the function ON A DEVICE: claimed once per device of the process)
+  static std::atomic<int> attr_set[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16)
+    dev = -1;
+  if (dev < 0 || !attr_set[dev].load())
     {
     if (!hip_ok(hipFuncSetAttribute((const void*)k_lz4_decode_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ORING + CWIN)),
                 "hipFuncSetAttribute(k_lz4_decode_lds)"))
       return 0;
-    attr_set = true;
+    if (dev >= 0)
+      attr_set[dev].store(1);
     }
   hipLaunchKernelGGL(k_lz4_decode_lds, dim3(nplanes), dim3(WG), ORING + CWIN, current_stream(),
                      a, d_planes, plane_stride, plane_bytes, d_status);

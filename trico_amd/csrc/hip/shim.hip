@@ -167,6 +167,27 @@ static int g_device_state = 0;   // 0 unknown, 1 ok, -1 none
 static thread_local uint32_t g_stats[4] = { 0, 0, 0, 0 };      // words 0, 1: the last trico_hip_int_encode of this thread
 static std::atomic<uint32_t> g_repeats{ 0 }, g_other_writer{ 0 };   // words 2, 3: process-wide (a batch may be led by another thread)
 static std::atomic<uint32_t> g_recoded_order{ 0 }, g_recoded_sentinel{ 0 };   // trico_hip_encode_stats
+static std::atomic<int> g_strict{ -1 };                     // trico_hip_set_strict: -1 = what TRICO_HIP_STRICT says
+static std::atomic<int> g_verify{ -1 };                     // trico_hip_set_encode_verify: -1 = what TRICO_HIP_ENCODE_VERIFY says
+static std::atomic<uint64_t> g_verified_streams{ 0 }, g_verified_values{ 0 }, g_verify_mismatch{ 0 };
+
+static bool strict_reader()
+  {
+  const int s = g_strict.load();
+  if (s >= 0)
+    return s != 0;
+  static const bool env = [] { const char* e = getenv("TRICO_HIP_STRICT"); return e && e[0] == '1'; }();
+  return env;
+  }
+
+static bool encode_verify_on()
+  {
+  const int s = g_verify.load();
+  if (s >= 0)
+    return s != 0;
+  static const bool env = [] { const char* e = getenv("TRICO_HIP_ENCODE_VERIFY"); return e && e[0] == '1'; }();
+  return env;
+  }
 
 void stats_count_repeat() { g_repeats += 1; }
 void set_current_stream(hipStream_t s) { g_stream = s; }
@@ -568,6 +589,48 @@ int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int
       }
     for (int c = 0; c < arity; ++c)
       ctx->out_sizes[c] = six[c];
+    if (encode_verify_on() && fpc32_code_sweep_mode() != 0)
+      {
+      // Opt-in full verification (trico_hip_set_encode_verify): the write-side guard above samples 16 segments x 64 steps of the
+      // one-sweep coder; here EVERY value is coded again by the two-sweep coder with ballots - which rests neither on the order the
+      // LDS unit applies an exchange in nor on the table mark - in a workspace of its own, and the payloads are compared byte for
+      // byte on the device.  A difference is counted, reported on stderr, and the ballot coder's payload is what the stream gets.
+      uint8_t* pay[3] = { nullptr, nullptr, nullptr };
+      const uint8_t* cpay[3] = { nullptr, nullptr, nullptr };
+      for (int c = 0; c < arity; ++c)
+        cpay[c] = pay[c] = ctx->out.p + (size_t)c * stride;
+      if (!launch_fpc32_gather_all(n, arity, ctx->tmp.p, pay))
+        return 0;
+      for (int c = 0; c < arity; ++c)
+        ctx->out_materialized[c] = true;
+      uint32_t* d_vstatus = (uint32_t*)ctx->aux.p + 32;
+      uint32_t* d_vsizes = (uint32_t*)ctx->aux.p + 64;
+      TRICO_HIP_TRY(hipMemsetAsync(d_vstatus, 0, 4, current_stream()));
+      const size_t vws = fpc32_encode_workspace(n, arity);
+      uint32_t verdict = 0;
+      if (!ctx->vws.reserve(vws) ||
+          !launch_fpc32_encode(d_src, n, arity, nullptr, 0, d_vsizes, ctx->vws.p, ctx->vws.cap, FPC32_CODER_BALLOT) ||
+          !launch_fpc32_compare(n, arity, ctx->vws.p, d_vsizes, cpay, ctx->out_sizes, d_vstatus, 0x100u) ||
+          !read_back_words(ctx, d_vstatus, 1, &verdict))
+        return 0;
+      g_verified_streams += 1;
+      g_verified_values += (uint64_t)n * (uint64_t)arity;
+      if (verdict != 0)
+        {
+        g_verify_mismatch += 1;
+        fprintf(stderr, "trico_hip: ENCODE VERIFICATION FAILED (components 0x%x of a stream of %u x %d floats): the one-sweep coder and the ballot "
+                        "coder disagree; writing the ballot coder's payload\n", verdict >> 8, n, arity);
+        fpc32_distrust_lane_order();
+        if (!launch_fpc32_encode(d_src, n, arity, ctx->out.p, stride, d_sizes, ctx->tmp.p, ctx->tmp.cap, FPC32_CODER_BALLOT) ||
+            !read_back_words(ctx, d_sizes, 6, six))
+          return 0;
+        for (int c = 0; c < arity; ++c)
+          {
+          ctx->out_sizes[c] = six[c];
+          ctx->out_materialized[c] = false;
+          }
+        }
+      }
     }
   else if (!read_back_words(ctx, d_sizes, arity, ctx->out_sizes))
     return 0;
@@ -895,14 +958,14 @@ static int decode_complete(trico_hip_ctx* ctx, const char* what)
       // trico_hip_last_stats counts the stream so that a caller can see it.
       g_other_writer += 1;
       ctx->other_writer_seen = true;
-      static const bool strict = [] { const char* e = getenv("TRICO_HIP_STRICT"); return e && e[0] == '1'; }();
-      if (strict)
+      ctx->other_writer_streams += 1;
+      if (strict_reader())
         {
-        // TRICO_HIP_STRICT=1: a caller that only ever reads archives of the reference's own writer (or this library's) wants to hear
-        // about it instead of getting values
+        // trico_hip_set_strict(1) / TRICO_HIP_STRICT=1: a caller that only ever reads archives of the reference's own writer (or this
+        // library's) wants to hear about it instead of getting values
         ctx->chk_active = false;
         set_error("trico decode: the payload decodes, but the reference's encoder would not have written it (the values, decoded in "
-                  "reference order, do not code back to it); refused because TRICO_HIP_STRICT=1");
+                  "reference order, do not code back to it); refused because the reader is strict (trico_hip_set_strict / TRICO_HIP_STRICT=1)");
         return 0;
         }
       st = 0;
@@ -1115,6 +1178,32 @@ int trico_hip_int_decode(trico_hip_ctx* ctx, const uint8_t* const payloads[8], c
   return 1;
   }
 
+int trico_hip_lz4_decoded_size(trico_hip_ctx* ctx, const void* payload, uint32_t size, uint32_t capacity, uint32_t* out_size)
+  {
+  if (!ctx || !device_ready() || !payload || !out_size || size == 0 || capacity > 0x7E000000u)
+    {
+    if (ctx)
+      set_error("trico_hip_lz4_decoded_size: bad arguments");
+    return 0;
+    }
+  if (!trico_hip_pointer_is_device(payload) && !ctx->in.reserve((size_t)size + 16))
+    return 0;
+  const uint8_t* d_pay = (const uint8_t*)stage_in(ctx->in, payload, size);
+  if (!d_pay)
+    return 0;
+  uint32_t* d_out = (uint32_t*)ctx->aux.p;
+  uint32_t two[2] = { 0u, 1u };
+  if (!launch_lz4_measure(d_pay, size, capacity, d_out) || !read_back_words(ctx, d_out, 2, two))
+    return 0;
+  if (two[1])
+    {
+    set_error("trico_hip_lz4_decoded_size: malformed LZ4 block, or one that decodes to more than the capacity");
+    return 0;
+    }
+  *out_size = two[0];
+  return 1;
+  }
+
 // ---- stand-alone transposes (the reference's transpose_aos_to_soa.h) ------------------------------
 // The coders above fuse the transposes; these exist for callers of the reference's low-level API.
 
@@ -1290,6 +1379,16 @@ void trico_hip_encode_stats(uint32_t out[2])
   {
   out[0] = g_recoded_order.load();
   out[1] = g_recoded_sentinel.load();
+  }
+
+void trico_hip_set_strict(int on) { g_strict.store(on < 0 ? -1 : on != 0); }
+uint32_t trico_hip_ctx_other_writer_streams(const trico_hip_ctx* ctx) { return ctx ? ctx->other_writer_streams : 0u; }
+void trico_hip_set_encode_verify(int on) { g_verify.store(on < 0 ? -1 : on != 0); }
+void trico_hip_encode_verify_stats(uint64_t out[3])
+  {
+  out[0] = g_verified_streams.load();
+  out[1] = g_verified_values.load();
+  out[2] = g_verify_mismatch.load();
   }
 
 void trico_hip_profile_enable(int on) { g_prof_on = on != 0; }

@@ -11,9 +11,11 @@
 // here at all (shim.hip: stage_in, trico_hip_copy).
 #include "common.hpp"
 
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#include <pthread.h>
 #include <string.h>
 #include <thread>
 #include <vector>
@@ -108,9 +110,16 @@ struct Pipe
       threads = atoi(e);
     else
       {
-      const unsigned hw = std::thread::hardware_concurrency();
-      threads = hw >= 16 ? 7 : 0;                 // + the calling thread; with 3 the runtime's own staging is faster, 15 gain nothing (profiles/r05_host_pointers.txt)
+      // + the calling thread; with 3 the runtime's own staging is faster, 15 gain nothing (profiles/r05_host_pointers.txt).  The ranks
+      // of a node share its cores: each takes its share of them (LOCAL_WORLD_SIZE, as torchrun and mpirun export it)
+      unsigned hw = std::thread::hardware_concurrency();
+      if (const char* lw = getenv("LOCAL_WORLD_SIZE"))
+        if (atoi(lw) > 1)
+          hw /= (unsigned)atoi(lw);
+      threads = hw >= 16 ? 7 : 0;
       }
+    if (threads > 32)
+      threads = 32;                               // (an upper bound whatever the variable says)
     if (threads <= 0)
       return false;                               // (0: the runtime's own staging, as before)
     if (hipGetDevice(&device) != hipSuccess)
@@ -140,9 +149,24 @@ struct Pipe
 
 // (on the heap and never destroyed: the pool's threads wait on its condition variable for as long as the process lives, and the
 // destructor of a condition variable waits for its waiters - a global would hang every exit)
+// A forked child has none of the pool's threads (fork copies the calling thread only) and may not touch the parent's HIP objects:
+// its pipe is a new one that has not been tried (what the parent's object held stays allocated; the child never looks at it).
+static std::atomic<Pipe*> g_pipe{ nullptr };
+static void pipe_forget_in_child() { g_pipe.store(nullptr); }
+
 Pipe& the_pipe()
   {
-  static Pipe* p = new Pipe;
+  static const int hooked = pthread_atfork(nullptr, nullptr, pipe_forget_in_child);
+  (void)hooked;
+  Pipe* p = g_pipe.load();
+  if (!p)
+    {
+    Pipe* fresh = new Pipe;
+    if (g_pipe.compare_exchange_strong(p, fresh))
+      p = fresh;
+    else
+      delete fresh;
+    }
   return *p;
   }
 

@@ -46,6 +46,7 @@ struct trico_archive
   uint8_t next_stream_type;
   int writable;
   trico_hip_ctx* ctx;   /* created on first use */
+  uint32_t other_writer_streams;   /* streams delivered although the reference's encoder would not have written their payload (trico_hip_set_strict) */
   /* read-ahead: streams that were decoded ahead as one batch, keyed by the cursor position of their count field */
   struct ra_entry* ra;
   int ra_n;
@@ -768,6 +769,8 @@ static void start_readahead(struct trico_archive* a, void* out)
     for (int i = 0; i < n; ++i)
       {
       ra[i].ok = jobs[i].ok > 0;
+      if (jobs[i].ok > 0 && jobs[i].other_writer)
+        a->other_writer_streams += 1;
       if (jobs[i].ok < 0)
         release_entry(&ra[i]);                       /* not attempted (no memory for the batch, a launch that failed): the stream's own
                                                         read call decodes it alone, as if there had been no read-ahead */
@@ -901,6 +904,16 @@ int trico_read_uv_per_vertex_double(void* a, double** uv)
   { return read_fp_stream(a, trico_uv_per_vertex_double_stream, (void**)uv, 2, 8, 0); }
 int trico_read_uv_per_triangle_double(void* a, double** uv)
   { return read_fp_stream(a, trico_uv_per_triangle_double_stream, (void**)uv, 2, 8, 0); }
+/* Not in trico.h: the reference's shared library happens to export the helper behind the two readers above (trico.c, the sibling of its
+ * static trico_read_vec2_float at :1247 was left non-static), so a program linked against it may hold the name.  Same meaning: the
+ * next stream must be the double uv stream type `st`. */
+TRICO_API int trico_read_vec2_double(void* a, double** uv, enum trico_stream_type st);
+int trico_read_vec2_double(void* a, double** uv, enum trico_stream_type st)
+  {
+  if (st != trico_uv_per_vertex_double_stream && st != trico_uv_per_triangle_double_stream)
+    return 0;
+  return read_fp_stream(a, st, (void**)uv, 2, 8, 0);
+  }
 int trico_read_attributes_float(void* a, float** p)
   { return read_fp_stream(a, trico_attribute_float_stream, (void**)p, 1, 4, 1); }
 int trico_read_attributes_double(void* a, double** p)
@@ -1027,6 +1040,8 @@ int trico_hip_read_archives(void* const* archives, int count, void* const* const
         all = 0;
         break;
         }
+      if (jobs[at + s_].other_writer)
+        a->other_writer_streams += 1;
       if (a->ra_started)
         drop_readahead(a);
       a->pos = ends[at + s_];
@@ -1038,6 +1053,15 @@ int trico_hip_read_archives(void* const* archives, int count, void* const* const
   free(ends);
   free(parsed);
   return all;
+  }
+
+uint32_t trico_hip_archive_other_writer_streams(void* archive)
+  {
+  const struct trico_archive* a = (const struct trico_archive*)archive;
+  if (!a || a->writable)
+    return 0;
+  /* batch decodes report per job; streams decoded alone by this handle's own context are counted there */
+  return a->other_writer_streams + (a->ctx ? trico_hip_ctx_other_writer_streams(a->ctx) : 0u);
   }
 
 /* trico.c:1670-1698 */
