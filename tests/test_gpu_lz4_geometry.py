@@ -63,19 +63,22 @@ def test_geometry_changes_time_not_bytes():
 CHILD_SHORT = r"""
 import ctypes, sys
 sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r + "/tests")
 import numpy as np
 from trico_amd import api
 from oracle import oracle as O
-rng = np.random.default_rng(7)
-a = rng.integers(0, 3, 300000, dtype=np.uint8)          # sequences of a few bytes: the short-sequence geometry, 64 KiB chunks
+from streams import mesh_streams
+# the index planes of a small random-walk mesh: 301,056 bytes each, sequences of a few bytes in the lower planes - the
+# short-sequence geometry with 64 KiB chunks (a warm-up as long as a chunk: chunk 1 speculates from the plane's first bytes)
+name, t, count = [x for x in mesh_streams("walk", 224, 224) if x[0] == "triangles"][0]
 w = api.Archive.open_for_writing(1 << 16)
-assert w.write("attributes_uint8", a, a.size) == 1, api.last_error()
+assert w.write(name, t, count) == 1, api.last_error()
 got = w.tobytes()
 w.close()
 st = (ctypes.c_uint32 * 4)()
 api.lib().trico_hip_last_stats(st)
 o = O.OracleArchive()
-o.write("attributes_uint8", a, a.size)
+o.write(name, t, count)
 want = o.tobytes()
 o.close()
 print("RESULT", int(got == want), st[0], st[1])
@@ -83,9 +86,10 @@ print("RESULT", int(got == want), st[0], st[1])
 
 
 @pytest.mark.gpu
-def test_short_sequence_plane_of_300_kb_speculates_from_inside_the_plane():
+def test_short_sequence_planes_of_300_kb_speculate_from_inside_the_plane():
     # (round 5's advisor: with 64 KiB chunks the 70,000-byte warm-up reached before the plane's start: chunk 1 began at a wrapped
-    # position, its speculation was thrown away; the bytes were right all the same - so this test looks at the re-parse count)
+    # position and its speculation was thrown away; the bytes were right all the same - so this test looks at the re-parse count.
+    # Round 6 found the second half: a speculative start at position 0 tests position 0 against itself, k_lz4_chunked.hip: spec_start)
     env = dict(os.environ)
     for k in ("TRICO_LZ4_CHUNK", "TRICO_LZ4_WARM", "TRICO_LZ4_CHUNKED_MIN"):
         env.pop(k, None)
@@ -93,4 +97,4 @@ def test_short_sequence_plane_of_300_kb_speculates_from_inside_the_plane():
     assert out.returncode == 0, out.stdout + out.stderr
     same, accepted, reparsed = [int(x) for x in [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()[1:]]
     assert same == 1
-    assert accepted == 5 and reparsed == 0, (accepted, reparsed)
+    assert accepted >= 4 and reparsed == 0, (accepted, reparsed)

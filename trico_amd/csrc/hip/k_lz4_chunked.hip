@@ -489,6 +489,16 @@ __host__ __device__ inline uint32_t open_after(const Geom& g) { return g.chunk >
 
 // (count rounds of 8 KiB, not 16: with the 280 registers of the wider round a compute unit holds four chunks instead of ten, and what a
 // plane of short sequences costs is how many of its chunks run at once; matches of a MiB and more are k_lz4_extend's anyway)
+// Where the speculative parse of chunk k begins: `warm` bytes in front of the chunk, but never at position 0 - an empty table says
+// "candidate = position 0" for every hash, and position 0 tested against itself is a match the reference never makes (it enters its
+// loop at position 1 with position 0 in the table, lz4.c:866-867: exactly the state a speculative start at 1 has).
+__device__ __forceinline__ uint32_t spec_start(uint32_t k, uint32_t c_lo, uint32_t warm)
+  {
+  if (k == 0u)
+    return 0u;
+  return c_lo > warm ? c_lo - warm : 1u;
+  }
+
 __global__ void __launch_bounds__(64) k_lz4_parse(const uint8_t* __restrict__ planes, Geom g, Desc* __restrict__ descs, Meta* __restrict__ metas,
                                                   uint32_t* __restrict__ snapTs, uint32_t* __restrict__ endTs)
   {
@@ -514,7 +524,7 @@ __global__ void __launch_bounds__(64) k_lz4_parse(const uint8_t* __restrict__ pl
   const uint8_t* src = planes + (size_t)p * g.plane_stride;
   const uint32_t c_lo = k * g.chunk;
   const uint32_t c_hi = (k + 1u == g.K) ? 0xffffffffu : c_lo + g.chunk;
-  lz4_parse<1, 8>(src, g.n, tab, g.xchg ? nullptr : dup, k == 0 || c_lo < g.warm ? 0u : c_lo - g.warm, false, k == 0, k == 0, c_lo, c_hi, descs + ck * g.dcap, g.dcap, meta,
+  lz4_parse<1, 8>(src, g.n, tab, g.xchg ? nullptr : dup, spec_start(k, c_lo, g.warm), false, k == 0, k == 0, c_lo, c_hi, descs + ck * g.dcap, g.dcap, meta,
                   snapTs + ck * 4096, endTs + ck * 4096, lane, 0, nullptr, open_after(g));
   }
 
