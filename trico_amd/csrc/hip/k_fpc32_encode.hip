@@ -793,16 +793,10 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
 __global__ void __launch_bounds__(1024) k_fpc32_offsets(const uint32_t* __restrict__ segbytes, uint32_t S, int arity, uint32_t* __restrict__ segoff,
                                                         uint32_t* __restrict__ sizes, const uint32_t* __restrict__ nrec, uint32_t* __restrict__ rectot)
   {
-  __shared__ uint32_t part[1024];
-  __shared__ uint32_t fl, recs;
+  __shared__ uint32_t wsum[16], wfl[16], wrec[16];
   const uint32_t c = blockIdx.x;
-  if (threadIdx.x == 0)
-    {
-    fl = 0u;
-    recs = 0u;
-    }
   const uint32_t per = (S + 1023u) / 1024u;
-  const uint32_t g0 = threadIdx.x * per, g1 = (g0 + per < S) ? g0 + per : S;
+  const uint32_t g0 = threadIdx.x * per < S ? threadIdx.x * per : S, g1 = (g0 + per < S) ? g0 + per : S;
   uint32_t sum = 0, f = 0, h = 0;
   for (uint32_t g = g0; g < g1; ++g)
     {
@@ -811,21 +805,30 @@ __global__ void __launch_bounds__(1024) k_fpc32_offsets(const uint32_t* __restri
     f |= w >> 16;
     h += w & 0xffffu;
     }
-  part[threadIdx.x] = sum;
-  __syncthreads();
-  if (f)
-    atomicOr(&fl, f);
-  if (h)
-    atomicAdd(&recs, h);
-  __syncthreads();
-  for (uint32_t o = 1; o < 1024u; o <<= 1)
+  // (one scan inside the wave, sixteen partial sums through LDS: two barriers instead of the twenty of a ladder over 1024 threads)
+  const uint32_t incl = wave_scan_incl(sum), hin = wave_scan_incl(h);
+  const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint64_t fany = __ballot(f != 0u);
+  uint32_t fw = 0;
+  if (fany)
+    for (uint32_t b = 0; b < 16u; ++b)
+      fw |= __ballot((f >> b) & 1u) ? (1u << b) : 0u;
+  if (lane == 63u)
     {
-    const uint32_t add = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
-    __syncthreads();
-    part[threadIdx.x] += add;
-    __syncthreads();
+    wsum[wv] = incl;
+    wrec[wv] = hin;
+    wfl[wv] = fw;
     }
-  uint32_t run = part[threadIdx.x] - sum;
+  __syncthreads();
+  uint32_t before = 0, total = 0, fl = 0, recs = 0;
+  for (uint32_t w = 0; w < 16u; ++w)
+    {
+    before += w < wv ? wsum[w] : 0u;
+    total += wsum[w];
+    fl |= wfl[w];
+    recs += wrec[w];
+    }
+  uint32_t run = before + incl - sum;
   for (uint32_t g = g0; g < g1; ++g)
     {
     segoff[(size_t)c * S + g] = run;
@@ -833,7 +836,7 @@ __global__ void __launch_bounds__(1024) k_fpc32_offsets(const uint32_t* __restri
     }
   if (threadIdx.x == 1023u)
     {
-    sizes[c] = part[1023];
+    sizes[c] = total;
     sizes[3u + c] = fl;
     rectot[c] = recs;
     }

@@ -1312,52 +1312,100 @@ __device__ __forceinline__ void fixup_rows(int arity, uint32_t S, const uint32_t
     const uint32_t* theirs = (const uint32_t*)(gslots + row * GUARD_CAP);
     const uint32_t H = nrec[rowi] & 0xffffu;
     bool diff = H < m.nrec || rawbytes[(size_t)c * S + m.seg] < m.bytes;      // (rawbytes: the segment's own workgroup may be changing segbytes right now)
-    for (uint32_t t = lane; 4u * t < m.bytes; t += 256u)
+    // (differences are ORed together, not tested one by one: the loads of all rounds are then independent of each other - with
+    // `diff = diff || ...` the up to 18 rounds of a workgroup were 18 dependent pairs of round trips, the tail of the whole kernel)
+    uint32_t acc = 0;
+    const uint32_t nw = (m.bytes + 3u) >> 2;
+#pragma unroll 4
+    for (uint32_t t = lane; t < nw; t += 256u)
       {
       const uint32_t keep = 4u * t + 4u <= m.bytes ? 0xffffffffu : (1u << (8u * (m.bytes & 3u))) - 1u;
-      diff = diff || ((mine[t] ^ theirs[t]) & keep) != 0u;
+      acc |= (mine[t] ^ theirs[t]) & keep;
       }
     const uint32_t* ra = recs + rowi * RCAP * RECW, * rb = grecs + row * RCAP * RECW;
-    for (uint32_t t = lane; t < REC_CMPW * m.nrec && !(H < m.nrec); t += 256u)
-      diff = diff || ra[RECW * (t / REC_CMPW) + t % REC_CMPW] != rb[RECW * (t / REC_CMPW) + t % REC_CMPW];
+    const uint32_t ncmp = H < m.nrec ? 0u : REC_CMPW * m.nrec;
+#pragma unroll 4
+    for (uint32_t t = lane; t < ncmp; t += 256u)
+      acc |= ra[RECW * (t / REC_CMPW) + t % REC_CMPW] ^ rb[RECW * (t / REC_CMPW) + t % REC_CMPW];
+    diff = diff || acc != 0u;
     if (lane == 0 && H > m.nrec)
       diff = diff || (ra[RECW * m.nrec] & REC_POS) < m.bytes;      // a record of the sweep inside the compared bytes that the guard does not have
     if (diff)
       atomicOr(&nrec[rowi], FLAG_ORDER << 16);
     return;
     }
-  const size_t rowi = (size_t)g * arity + c;
+  (void)part;
+  }
+
+// The deferred values of ONE (segment, component) row, by one wave.  What a record needs is three dependent memory round trips -
+// its words, the incoming entry of its class, the store of the result - and nothing else, so a lane takes up to FIX_B records at
+// once: their loads are issued together, then their look-ups, then their stores.  (Round 5 gave every row a workgroup of 256
+// threads: 6,800 workgroups in four rounds of ~5 us on the device, 26 us, for what is three round trips.)
+constexpr uint32_t FIX_B = 8;
+__device__ __forceinline__ void fixup_row_wave(const uint32_t* __restrict__ inc, uint32_t* __restrict__ segbytes, const uint32_t* __restrict__ rawbytes,
+                                               const uint32_t* __restrict__ nrec, uint32_t* __restrict__ recs, uint32_t S, uint32_t arity,
+                                               uint32_t rowi, uint32_t lane)
+  {
   const uint32_t H = nrec[rowi] & 0xffffu;
   if (H == 0u)
     return;
-  uint32_t* list = recs + rowi * RCAP * RECW;
-  const uint32_t* row = inc + rowi * ROW;              // (the segment's incoming tables; parking the row in LDS first is slower)
+  uint32_t* list = recs + (size_t)rowi * RCAP * RECW;
+  const uint32_t* row = inc + (size_t)rowi * ROW;            // the segment's incoming tables
   uint32_t unused = 0;
-  for (uint32_t j = lane; j < H; j += 256u)
+  for (uint32_t base = 0; base < H; base += 64u * FIX_B)
     {
-    const u32x4 w = *(const u32x4*)(list + RECW * j);
-    const uint32_t known = list[RECW * j + 4u];
-    const bool ft1 = (w[0] & REC_FT1) != 0u, ft2 = (w[0] & REC_FT2) != 0u;
-    const uint32_t v = w[2], a = w[3];
-    const uint32_t k1 = a >> 28, k2 = 16u + (list[RECW * j + 5u] >> 2);      // (fpsc.c:96-97: the FCM class is the predecessor's top four bits)
-    const uint32_t p1 = ft1 ? row[k1] : known;
-    const uint32_t p2 = ft2 ? row[k2] : known;
-    const uint32_t x1 = v ^ p1, x2 = v ^ (a + p2);
-    const uint32_t n1 = (39u - (uint32_t)__clz((int)x1)) >> 3;
-    const uint32_t n2 = (39u - (uint32_t)__clz((int)(x2 | 1u))) >> 3;
-    const bool use2 = n2 < n1;
-    const uint32_t len = use2 ? n2 : n1, x = use2 ? x2 : x1, code = use2 ? (n2 | 4u) : n1;
-    list[RECW * j + 6u] = x;
-    list[RECW * j + 7u] = len | (code << 4);
-    unused += 4u - len;
+    u32x4 w[FIX_B];
+    uint32_t known[FIX_B], k2w[FIX_B], p1[FIX_B], p2[FIX_B];
+#pragma unroll
+    for (uint32_t i = 0; i < FIX_B; ++i)
+      {
+      const uint32_t j = base + 64u * i + lane;
+      w[i] = u32x4{ 0u, 0u, 0u, 0u };
+      known[i] = k2w[i] = 0u;
+      if (j < H)
+        {
+        w[i] = *(const u32x4*)(list + RECW * j);
+        const u32x2 t = *(const u32x2*)(list + RECW * j + 4u);
+        known[i] = t[0];
+        k2w[i] = t[1];
+        }
+      }
+#pragma unroll
+    for (uint32_t i = 0; i < FIX_B; ++i)
+      {
+      const uint32_t j = base + 64u * i + lane;
+      const bool ft1 = (w[i][0] & REC_FT1) != 0u, ft2 = (w[i][0] & REC_FT2) != 0u;
+      p1[i] = known[i];
+      p2[i] = known[i];
+      if (j < H)
+        {
+        // (fpsc.c:96-97: the FCM class is the predecessor's top four bits)
+        if (ft1) p1[i] = row[w[i][3] >> 28];
+        if (ft2) p2[i] = row[16u + (k2w[i] >> 2)];
+        }
+      }
+#pragma unroll
+    for (uint32_t i = 0; i < FIX_B; ++i)
+      {
+      const uint32_t j = base + 64u * i + lane;
+      if (j < H)
+        {
+        const uint32_t v = w[i][2], a = w[i][3];
+        const uint32_t x1 = v ^ p1[i], x2 = v ^ (a + p2[i]);
+        const uint32_t n1 = (39u - (uint32_t)__clz((int)x1)) >> 3;
+        const uint32_t n2 = (39u - (uint32_t)__clz((int)(x2 | 1u))) >> 3;
+        const bool use2 = n2 < n1;
+        const uint32_t len = use2 ? n2 : n1, x = use2 ? x2 : x1, code = use2 ? (n2 | 4u) : n1;
+        *(u32x2*)(list + RECW * j + 6u) = u32x2{ x, len | (code << 4) };
+        unused += 4u - len;
+        }
+      }
     }
   const uint32_t incl = wave_scan_incl(unused);
-  if ((lane & 63u) == 63u)
-    part[lane >> 6] = incl;
-  __syncthreads();
-  if (lane == 0)
+  if (lane == 63u)
     {
-    segbytes[(size_t)c * S + g] = rawbytes[(size_t)c * S + g] - (part[0] + part[1] + part[2] + part[3]);
+    const uint32_t c = rowi % arity, g = rowi / arity;
+    segbytes[(size_t)c * S + g] = rawbytes[(size_t)c * S + g] - incl;
     }
   }
 
@@ -1365,12 +1413,21 @@ __global__ void __launch_bounds__(256) k_fpc32_fixup(int arity, uint32_t S, cons
                                                      uint32_t* __restrict__ rawbytes, uint32_t* __restrict__ nrec, uint32_t* __restrict__ recs,
                                                      const uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap,
                                                      const uint8_t* __restrict__ gslots, const uint32_t* __restrict__ grecs,
-                                                     const GuardMeta* __restrict__ gmeta)
+                                                     const GuardMeta* __restrict__ gmeta, uint32_t row_blocks)
   {
   // (The scan of the segment sizes stays a launch of its own, k_fpc32_offsets: done by "the workgroup that finishes last", the 7,700
   // atomic increments of the counter that finds it took 0.4 ms - they are served one after the other.)
+  // Workgroups [0, row_blocks): four rows each, a wave per row.  Behind them one workgroup per (guard row, component).
   __shared__ uint32_t part[4];
-  const uint32_t g = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
+  if (blockIdx.x < row_blocks)
+    {
+    const uint32_t rowi = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (rowi < S * (uint32_t)arity)
+      fixup_row_wave(inc, segbytes, rawbytes, nrec, recs, S, (uint32_t)arity, rowi, threadIdx.x & 63u);
+    return;
+    }
+  const uint32_t q = blockIdx.x - row_blocks;
+  const uint32_t g = S + q / (uint32_t)arity, c = q % (uint32_t)arity, lane = threadIdx.x;
   fixup_rows(arity, S, inc, segbytes, rawbytes, nrec, recs, slots, slot_stride, segcap, gslots, grecs, gmeta, g, c, lane, part);
   }
 
@@ -1917,8 +1974,9 @@ int launch_fpc32_sweep(const uint32_t* d_src, uint32_t n, int arity, const Plan&
   const unsigned colblocks = ((unsigned)arity * TAB + 255u) / 256u;
   hipLaunchKernelGGL(k_fpc32_pscan_a, dim3(colblocks, p.nch), dim3(256), 0, st, outT, p.S, arity, chlast);
   hipLaunchKernelGGL(k_fpc32_pscan_b, dim3(colblocks, p.nch), dim3(256), 0, st, outT, p.S, arity, chlast, inc);
-  hipLaunchKernelGGL(k_fpc32_fixup, dim3(p.S + G, arity), dim3(256), 0, st, arity, p.S, inc, segbytes, rawbytes, nrec, recs,
-                     slots, p.slot_stride, p.segcap, gslots, grecs, gmeta);
+  const unsigned row_blocks = (p.S * (unsigned)arity + 3u) / 4u;
+  hipLaunchKernelGGL(k_fpc32_fixup, dim3(row_blocks + G * (unsigned)arity), dim3(256), 0, st, arity, p.S, inc, segbytes, rawbytes, nrec, recs,
+                     slots, p.slot_stride, p.segcap, gslots, grecs, gmeta, row_blocks);
   return hip_ok(hipGetLastError(), "fpc32 encode kernels (sweep)") ? 1 : 0;
   }
 
