@@ -45,6 +45,16 @@ __device__ __forceinline__ u32x4 ld128(const uint8_t* p) { return ((const u128u*
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ uint32_t hash5(const uint8_t* p) { return (uint32_t)(((ld64(p) << 24) * 889523592379ull) >> 52); }   // lz4.c:643-648
 
+__device__ __forceinline__ bool fast_extra_seen(uint64_t dx, int first) { return __builtin_amdgcn_readlane((int)(dx != 0ull), first) != 0; }
+__device__ __forceinline__ uint32_t hash_w(uint64_t w) { return (uint32_t)(((w << 24) * 889523592379ull) >> 52); }       // hash5 of the 8 bytes w
+
+// ---- source bytes through the SCALAR data cache ---------------------------------------------------------------------------------
+// A plane of short sequences is a chain of ~40 M steps per plane, each of which looks at the bytes at ip and at ONE candidate: the
+// positions are wave-uniform, the data is read-only, and a vector load of it is a round trip of ~0.5 us through the vector memory
+// path that the step has to wait for twice.  A scalar load of the same bytes takes ~40 cycles when the line is in the compute unit's
+// scalar cache - the bytes at ip are read front to back (every line is fetched once), the candidates of such a plane lie a few
+// hundred bytes back - and ~200 from the L2.  The plane is addressed through the constant address space for that (it is not written
+// while the kernel runs; the cache is invalidated when a kernel starts): see the chain of zero-literal sequences in lz4_parse.
 struct Desc { uint32_t lit, ml, off; };    // literal run, match length incl. MINMATCH (0 = final run), offset
 
 enum { END_NONE = 0, END_MATCH = 1, END_FINAL = 2, END_OPEN = 3 };   // END_OPEN: the last descriptor's match is still being counted (k_lz4_extend)
@@ -203,12 +213,108 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
   bool overflow = false;
   for (;;)
     {
+    // (the parse state is wave-uniform, but the compiler cannot see it through the cross-lane reads that produce it: told so here, it
+    // keeps the state in scalar registers and the windows below become scalar loads)
+    ip = uni(ip);
+    anchor = uni(anchor);
+    nd = uni(nd);
     uint32_t cand = 0;
     bool have_match = false;
     bool fast = false;                     // the search round has already seen where the match ends (see the search loop)
     uint32_t fast_extra = 0;               // ... namely this many bytes behind its first four
+    bool fast_seen = false;                // ... and the difference that ends it was among the bytes at hand
     uint8_t tok_lit0 = 0;
     (void)tok_lit0;
+#ifndef TRICO_LZ4_SM
+#define TRICO_LZ4_SM 1
+#endif
+    // ---- a chain of sequences without literals, on the scalar unit ------------------------------------------------------------------
+    // On a plane of short sequences (a mesh's second index plane: 43 M sequences of 7 bytes) nearly every match is followed at once
+    // by the next one (lz4.c:1088-1138: insert ip - 2, test ip, literal length 0).  What such a step cost was not memory but
+    // instructions: ~300 of them through the general code below, issued by a wave that has its SIMD almost to itself at 5-9 cycles
+    // each.  Here the step is a loop of its own with nothing in it but the step: the 24 bytes at ip - 2 and the 24 at the candidate
+    // through the scalar cache (read-only data at wave-uniform positions; the bytes at ip are read front to back, the candidates of
+    // such a plane lie a few hundred bytes back), both hashes on the scalar unit, the three table accesses by one lane.  It ends -
+    // leaving the state exactly as the general code expects it - at the first step that is not of this kind: no match at ip, a match
+    // whose end is not among the 22 bytes at hand, the chunk's or the block's end near, a snapshot due.
+    if (TRICO_LZ4_SM != 0 && at_match_end)
+      {
+      const bool emit_u = uni(emit ? 1u : 0u) != 0u;                                // (uniform, like the rest of the state: see the top of the outer loop)
+      const uint32_t stop = uni(emit_u ? c_hi : c_lo), ndcap = emit_u ? uni(dcap) : 0xffffffffu, nmax = n >= 80u ? uni(n) - 80u : 0u;       // (nmax = 0: no step qualifies, ip >= 8)
+      for (;;)
+        {
+        ip = uni(ip);
+        nd = uni(nd);
+        if (!(ip >= 8u && ip < stop && ip <= nmax && nd < ndcap))
+          break;
+        typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+        typedef __attribute__((address_space(4))) const u32x8 const_u32x8;
+        const uintptr_t a = (uintptr_t)(src + ip - 2u);
+        const u32x8 d = *(const_u32x8*)(a & ~(uintptr_t)3);
+        const uint32_t sh = 8u * (uint32_t)(a & 3u);
+        // dword i of the bytes from ip - 2 on: the low half of (d[i + 1] : d[i]) >> sh
+        uint32_t w[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+          w[i] = (uint32_t)((((uint64_t)d[i + 1] << 32) | d[i]) >> sh);
+        const uint64_t q0 = ((uint64_t)w[1] << 32) | w[0], q1 = ((uint64_t)w[3] << 32) | w[2], q2 = ((uint64_t)w[5] << 32) | w[4];
+        const uint64_t i0 = (q0 >> 16) | (q1 << 48), i1 = (q1 >> 16) | (q2 << 48), i2 = q2 >> 16;      // bytes ip .. ip + 21
+        const uint32_t h2 = hash_w(q0), h = hash_w(i0);
+        uint32_t cnd = 0;
+        if (lane == 0)
+          {
+          tab[h2] = ip - 2u;                                                         // lz4.c:1088
+          cnd = tab[h];                                                              // (the LDS unit keeps one wave's accesses in order)
+          tab[h] = ip;
+          }
+        cnd = uni(cnd);
+        bool hit = false;
+        uint32_t extra = 0;
+        bool seen = false;
+        if (cnd + MAXD >= ip)
+          {
+          const uintptr_t ca = (uintptr_t)(src + cnd);
+          const u32x8 e = *(const_u32x8*)(ca & ~(uintptr_t)3);
+          const uint32_t csh = 8u * (uint32_t)(ca & 3u);
+          uint32_t v[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+            v[i] = (uint32_t)((((uint64_t)e[i + 1] << 32) | e[i]) >> csh);
+          const uint64_t x0 = (((uint64_t)v[1] << 32) | v[0]) ^ i0, x1 = (((uint64_t)v[3] << 32) | v[2]) ^ i1,
+                         x2 = ((((uint64_t)v[5] << 32) | v[4]) ^ i2) & 0xffffffffffffull;
+          hit = (uint32_t)x0 == 0u;
+          seen = true;
+          if (x0 >> 32)
+            extra = (uint32_t)__builtin_ctzll(x0 >> 32) >> 3;
+          else if (x1)
+            extra = 4u + ((uint32_t)__builtin_ctzll(x1) >> 3);
+          else if (x2)
+            extra = 12u + ((uint32_t)__builtin_ctzll(x2) >> 3);
+          else
+            seen = false;
+          }
+        if (!hit)
+          {
+          ++ip;                                                                      // no match at ip: the search loop takes over at ip + 1
+          at_match_end = false;
+          break;
+          }
+        if (!seen)
+          {
+          cand = cnd;                                                                // a longer match: counted by the general code
+          have_match = true;
+          at_match_end = false;
+          break;
+          }
+        if (emit_u)
+          {
+          if (writer) { desc[nd].lit = 0u; desc[nd].ml = extra + 4u; desc[nd].off = ip - cnd; }
+          ++nd;
+          }
+        ip += uni(extra) + 4u;
+        anchor = ip;
+        }
+      }
     if (at_match_end)
       {
       // ---- state: a match ended at ip, anchor == ip ----
@@ -257,6 +363,7 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
         if (dx)
           {
           fast = true;
+          fast_seen = true;
           fast_extra = (uint32_t)__builtin_ctz(dx) >> 3;                           // equal bytes behind the first four: 0 .. 3
           }
         }
@@ -386,6 +493,7 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
             const uint32_t extra = dx ? (uint32_t)__builtin_ctzll(dx) >> 3 : 4u;     // equal bytes behind the first four
             const uint32_t eqb = dp ? (uint32_t)__builtin_clzll(dp) >> 3 : 8u;       // equal bytes right before the two positions
             fast = true;
+            fast_seen = fast_extra_seen(dx, first);
             fast_extra = (uint32_t)__builtin_amdgcn_readlane((int)extra, first);
             fast_eqb = (uint32_t)__builtin_amdgcn_readlane((int)eqb, first);
             fast_pre = __builtin_amdgcn_readlane((int)pre, first) != 0;
@@ -431,7 +539,7 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
       ip -= back;
       cand -= back;
       fast_extra += back;                                                          // equal bytes behind the first four of the moved match
-      fast = fast && fast_extra - back < 4u;                                       // a difference was seen
+      fast = fast && fast_seen;                                                    // (the difference that ends the match was among the bytes at hand)
       }
     // ---- a match starts at ip against cand (lz4.c:1007-1077) ----
     if (!emit && ip + 4u >= c_hi)
