@@ -178,6 +178,23 @@ __device__ __forceinline__ uint32_t wave_count(const uint8_t* __restrict__ a, co
   return limit;
   }
 
+// (for the chain of short sequences in lz4_parse: q0, q1, q2 are the 24 bytes from ip - 2 on)
+constexpr uint32_t KS = 6;                   // attempts of a search made one by one on the scalar unit
+template <int OFF> __device__ __forceinline__ uint64_t bytes_at(uint64_t q0, uint64_t q1, uint64_t q2)
+  {
+  // the 8 bytes at offset OFF (0 .. 16) of the 24
+  if constexpr (OFF == 0) return q0;
+  else if constexpr (OFF < 8) return (q0 >> (8 * OFF)) | (q1 << (64 - 8 * OFF));
+  else if constexpr (OFF == 8) return q1;
+  else if constexpr (OFF < 16) return (q1 >> (8 * (OFF - 8))) | (q2 << (64 - 8 * (OFF - 8)));
+  else return q2;
+  }
+// the 8 bytes behind the 8 at offset t + 3 (attempt t < KS): offset t + 11 .. t + 18 of the 24
+__device__ __forceinline__ uint64_t next_bytes(uint32_t t, uint64_t q1, uint64_t q2)
+  {
+  // offset t + 11: t = 0 .. 4 -> inside q1 / q2, t = 5 -> q2
+  return t < 5u ? (q1 >> (8u * (t + 3u))) | (q2 << (64u - 8u * (t + 3u))) : q2;
+  }
 // The parser.  One wave; `tab` (LDS, 4096 x u32) holds the table for the start state.
 //   start_match_end: true  -> state "a match just ended at ip0" (anchor == ip0), table = tab
 //                    false -> state "search loop starts at ip0" (anchor == ip0), table = tab
@@ -192,7 +209,7 @@ template <int NW, int QL = 16>
 __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t* tab, uint8_t* dup, uint32_t ip0, bool start_match_end, bool fresh,
                           bool emit_from_start, uint32_t c_lo, uint32_t c_hi, Desc* __restrict__ desc, uint32_t dcap,
                           Meta* __restrict__ meta, uint32_t* __restrict__ snapT, uint32_t* __restrict__ endT, int lane, int wave = 0,
-                          uint32_t* xch = nullptr, uint32_t big = 0u)
+                          uint32_t* xch = nullptr, uint32_t big = 0u, int ks0 = 4)
   {
   const bool writer = lane == 0 && wave == 0;            // descriptors and chunk meta: one writer (NW > 1: all waves hold the same values)
   const uint32_t mfl1 = n - 11u, mlim = n - 5u;                                    // lz4.c:825-826 (n >= 13 here)
@@ -211,6 +228,7 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
     at_match_end = false;
     }
   bool overflow = false;
+  int ks_credit = ks0;                       // > 0: searches begin with scalar attempts (see the chain of short sequences below)
   for (;;)
     {
     // (the parse state is wave-uniform, but the compiler cannot see it through the cross-lane reads that produce it: told so here, it
@@ -219,6 +237,7 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
     anchor = uni(anchor);
     nd = uni(nd);
     uint32_t cand = 0;
+    uint32_t t0_chain = 0;                 // attempts of the coming search the chain below has already made
     bool have_match = false;
     bool fast = false;                     // the search round has already seen where the match ends (see the search loop)
     uint32_t fast_extra = 0;               // ... namely this many bytes behind its first four
@@ -295,9 +314,117 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
           }
         if (!hit)
           {
-          ++ip;                                                                      // no match at ip: the search loop takes over at ip + 1
-          at_match_end = false;
-          break;
+          // No match at ip: the search (lz4.c:898-956) from ip + 1, its first KS attempts here - on such a plane a sequence is a few
+          // literals and a match, and a round of 64 attempts of the general code costs two vector round trips and ~400 instructions
+          // whether it needs one attempt or sixty.  Attempt t looks at ip + 1 + t (the first 64 attempts advance by one), reads and
+          // writes the table entry of its hash, tests the candidate; the first hit ends the search - nothing to take back.
+          // Where searches are long (literal runs: the low plane of a regular mesh's indices) the scalar attempts are wasted on top
+          // of the rounds that follow: a search that did not end among them costs three credits, one that did earns one, and
+          // without credit the search goes straight to the general code (and earns one back, so that it is tried again later).
+          ks_credit = (int)uni((uint32_t)ks_credit);
+          if (ks_credit <= 0)
+            {
+            ++ks_credit;
+            ++ip;
+            at_match_end = false;
+            break;
+            }
+          const uint32_t start = ip + 1u;
+          const uint64_t wt[KS] = { bytes_at<3>(q0, q1, q2), bytes_at<4>(q0, q1, q2), bytes_at<5>(q0, q1, q2), bytes_at<6>(q0, q1, q2),
+                                    bytes_at<7>(q0, q1, q2), bytes_at<8>(q0, q1, q2) };                // the 8 bytes at start + t
+          const uint64_t pt[KS] = { q0 << 40, q0 << 32, q0 << 24, q0 << 16, q0 << 8, q0 };            // the t + 3 bytes before them, as the top of a qword
+          bool found = false;
+          uint32_t fpos = 0, fback = 0, fextra = 0;
+          bool fseen = false;
+#pragma unroll
+          for (uint32_t t = 0; t < KS; ++t)
+            {
+            if (found)
+              break;
+            const uint32_t pos = start + t;
+            const uint32_t ht = hash_w(wt[t]);
+            uint32_t c2 = 0;
+            if (lane == 0)
+              {
+              c2 = tab[ht];
+              tab[ht] = pos;
+              }
+            c2 = uni(c2);
+            if (c2 + MAXD >= pos && c2 >= 8u)
+              {
+              // the bytes c2 - 8 .. c2 + 23 of the candidate: one s_load_dwordx16 from the dword below c2 - 8
+              typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+              typedef __attribute__((address_space(4))) const u32x16 const_u32x16;
+              const uintptr_t ca = (uintptr_t)(src + c2 - 8u);
+              const u32x16 e = *(const_u32x16*)(ca & ~(uintptr_t)3);
+              const uint32_t csh = 8u * (uint32_t)(ca & 3u);
+              uint32_t v[8];
+#pragma unroll
+              for (int i = 0; i < 8; ++i)
+                v[i] = (uint32_t)((((uint64_t)e[i + 1] << 32) | e[i]) >> csh);
+              const uint64_t cpre = ((uint64_t)v[1] << 32) | v[0], c0 = ((uint64_t)v[3] << 32) | v[2], c1 = ((uint64_t)v[5] << 32) | v[4];
+              const uint64_t x0 = c0 ^ wt[t];
+              if ((uint32_t)x0 == 0u)
+                {
+                found = true;
+                fpos = pos;
+                cnd = c2;
+                // catch-up (lz4.c:960-961): equal bytes right before the two positions, at most down to the anchor (= ip)
+                const uint64_t dp = cpre ^ pt[t];
+                const uint32_t eqb = dp ? (uint32_t)__builtin_clzll(dp) >> 3 : 8u;
+                fback = eqb < t + 1u ? eqb : t + 1u;
+                // the match's end, if it is among the bytes at hand: the 8 bytes at pos, and the 8 behind them where the window has them
+                fseen = true;
+                if (x0 >> 32)
+                  fextra = (uint32_t)__builtin_ctzll(x0 >> 32) >> 3;
+                else
+                  {
+                  const uint64_t x1 = c1 ^ next_bytes(t, q1, q2);
+                  if (x1)
+                    fextra = 4u + ((uint32_t)__builtin_ctzll(x1) >> 3);
+                  else
+                    fseen = false;
+                  }
+                }
+              }
+            else if (c2 + MAXD >= pos)
+              {
+              // (a candidate in the first eight bytes of the block: the general code makes this attempt, and the ones behind it)
+              if (lane == 0)
+                tab[ht] = c2;                                                        // taken back: it is made again
+              t0_chain = t;
+              fpos = 0xffffffffu;
+              break;
+              }
+            }
+          if (fpos == 0xffffffffu || !found)
+            {
+            ip = start;                                                              // the search goes on in the general code: attempt t0_chain
+            at_match_end = false;
+            if (fpos != 0xffffffffu)
+              t0_chain = KS;
+            ks_credit = ks_credit > -13 ? ks_credit - 3 : -16;
+            break;
+            }
+          ks_credit = ks_credit < 8 ? ks_credit + 1 : 8;
+          const uint32_t mip = fpos - fback, mcand = cnd - fback;
+          if (!fseen)
+            {
+            ip = mip;                                                                // a longer match: counted by the general code
+            cand = mcand;
+            have_match = true;
+            at_match_end = false;
+            break;
+            }
+          const uint32_t ml = 4u + fback + fextra;
+          if (emit_u)
+            {
+            if (writer) { desc[nd].lit = mip - ip; desc[nd].ml = ml; desc[nd].off = mip - mcand; }
+            ++nd;
+            }
+          ip = uni(mip + ml);
+          anchor = ip;
+          continue;
           }
         if (!seen)
           {
@@ -384,7 +511,7 @@ __device__ void lz4_parse(const uint8_t* __restrict__ src, uint32_t n, uint32_t*
       // The first lane that ends the search (match, or the next position beyond mflimitPlusOne) decides; the table
       // writes of the attempts before it (and its own, for a match) are committed.
       const uint32_t start = ip;
-      uint32_t t0 = 0;
+      uint32_t t0 = t0_chain;
       bool final = false;
       // Short sequences (a mesh's second index plane: 7 bytes each) spent two more memory round trips per sequence on the
       // catch-up and on counting a match of 4-7 bytes.  The round that tests the candidates fetches 8 bytes at the candidate
@@ -597,6 +724,11 @@ __host__ __device__ inline uint32_t open_after(const Geom& g) { return g.chunk >
 
 // (count rounds of 8 KiB, not 16: with the 280 registers of the wider round a compute unit holds four chunks instead of ten, and what a
 // plane of short sequences costs is how many of its chunks run at once; matches of a MiB and more are k_lz4_extend's anyway)
+// Scalar attempts at the start of a search (lz4_parse: ks0) only in the short-sequence geometry: in the long-match geometry (the one
+// with alternative parses) a search is a literal run, the attempts are wasted and the code around them costs the match chains time
+// (measured on the benchmark mesh's planes: parse pass 4.97 ms without, 5.37 with credit gating alone, 5.76 ungated).
+__device__ __forceinline__ int scalar_search(const Geom& g) { return g.alt_rounds != 0u ? -(1 << 30) : 4; }
+
 // Where the speculative parse of chunk k begins: `warm` bytes in front of the chunk, but never at position 0 - an empty table says
 // "candidate = position 0" for every hash, and position 0 tested against itself is a match the reference never makes (it enters its
 // loop at position 1 with position 0 in the table, lz4.c:866-867: exactly the state a speculative start at 1 has).
@@ -633,7 +765,7 @@ __global__ void __launch_bounds__(64) k_lz4_parse(const uint8_t* __restrict__ pl
   const uint32_t c_lo = k * g.chunk;
   const uint32_t c_hi = (k + 1u == g.K) ? 0xffffffffu : c_lo + g.chunk;
   lz4_parse<1, 8>(src, g.n, tab, g.xchg ? nullptr : dup, spec_start(k, c_lo, g.warm), false, k == 0, k == 0, c_lo, c_hi, descs + ck * g.dcap, g.dcap, meta,
-                  snapTs + ck * 4096, endTs + ck * 4096, lane, 0, nullptr, open_after(g));
+                  snapTs + ck * 4096, endTs + ck * 4096, lane, 0, nullptr, open_after(g), scalar_search(g));
   }
 
 // ---- matches longer than a chunk: counted by the whole device ------------------------------------------------------------------
@@ -880,7 +1012,7 @@ __global__ void __launch_bounds__(64) k_lz4_alt(const uint8_t* __restrict__ plan
   Meta* am = altMetas + slot;
   const uint32_t c_hi = (j + 1u == g.K) ? 0xffffffffu : (j + 1u) * g.chunk;
   lz4_parse<1>(planes + (size_t)p * g.plane_stride, g.n, tab, g.xchg ? nullptr : dup, ip, true, false, true, j * g.chunk, c_hi, altDescs + slot * g.alt_dcap,
-            g.alt_dcap, am, nullptr, altEndTs + slot * 4096, lane);
+            g.alt_dcap, am, nullptr, altEndTs + slot * 4096, lane, 0, nullptr, 0u, scalar_search(g));
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (lane == 0 && am->end_kind != END_NONE)
     am->snap_valid = 1u;                             // the slot holds a finished parse (END_NONE: descriptor buffer too small)
@@ -978,7 +1110,7 @@ __global__ void __launch_bounds__(64 * STITCH_W) k_lz4_stitch(const uint8_t* __r
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       const uint32_t c_hi = (j + 1u == g.K) ? 0xffffffffu : (j + 1u) * g.chunk;
       lz4_parse<STITCH_W>(src, g.n, tab, g.xchg ? nullptr : dups[wave], ip, true, false, true, j * g.chunk, c_hi, descs + cj * g.dcap, g.dcap, pm + j,
-                          snapTs + cj * 4096, endTs + cj * 4096, lane, wave, xch);
+                          snapTs + cj * 4096, endTs + cj * 4096, lane, wave, xch, 0u, scalar_search(g));
       if (threadIdx.x == 0) pm[j].reparsed = 1u;
       }
     if (threadIdx.x == 0)
