@@ -8,7 +8,7 @@
 #   <tag>_lz4_kernel_stats.txt                        tools/perf_lz4.py grid and walk: per-kernel durations of the LZ4 codec
 #   <tag>_device_archive_open_hip_api.txt             hipMemcpy* calls to walk the framing of a device-resident archive
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
