@@ -21,6 +21,8 @@
 //     (k_pd_gather).
 // Nothing waits on the host: the jump rounds are launched up front and return at once when the previous round left no
 // word open.  Traffic: ~4 B written + 12 B per round and output byte.
+// Round 6: a FINAL word carries the byte itself (literals are read where the words are written), so the gather is one pass over
+// the words without a look into the compressed input; a round makes up to three hops per open word (20 launches instead of 31).
 // Round 3: (1) a match that overlaps itself (offset < length: LZ4's way of writing a periodic run, lz4.c:1840-1870) points every
 // byte at the FIRST period, src = op - off + (k mod off), instead of at the byte `off` before it: the run is resolved in one
 // round whatever its length (the two upper byte planes of a grid's indices are ONE run of 300 MB each: 28 rounds before).
@@ -41,8 +43,9 @@ constexpr uint32_t PD_LONG = 1024;            // runs from this length go to the
 constexpr uint32_t PD_PIECE = 65536;          // ... in pieces of at most this many bytes
 constexpr uint32_t PD_END = 0xffffffffu;      // "walk ended with the last sequence of the block"
 constexpr uint32_t PD_NONE = 0xfffffffeu;     // "no token seen / walk failed"
-constexpr uint32_t PD_FINAL = 0x80000000u;    // src word: low 31 bits index the compressed input (else: an output index)
-constexpr int PD_ROUNDS = 31;                 // chains are shorter than 2^31
+constexpr uint32_t PD_FINAL = 0x80000000u;    // src word: final, its low byte is the output byte (else: an earlier output index)
+constexpr int PD_HOPS = 3;                    // pointer hops of an open word per round
+constexpr int PD_ROUNDS = 20;                 // chains are shorter than 2^31 < 3^20
 
 struct Tile { uint32_t first, exit, nseq, pad; unsigned long long obytes; };
 struct Job { uint32_t op, len, a, b; };       // b == PD_NONE: literals from input position a; else match: offset a, its first period starts at output b
@@ -434,7 +437,7 @@ __global__ void __launch_bounds__(64) k_pd_fill(PdPlanes P, uint32_t n, uint32_t
       }
     else
       for (uint32_t k = (uint32_t)lane; k < s.lit_len; k += 64u)
-        src[op + k] = PD_FINAL | (s.lit_pos + k);
+        src[op + k] = PD_FINAL | b.at(s.lit_pos + k);                             // a final word carries the byte itself (round 6)
     op += s.lit_len;
     if (s.kind == 1)
       break;
@@ -487,7 +490,7 @@ __global__ void __launch_bounds__(256) k_pd_jobs(PdPlanes P, uint32_t job_cap, u
     const Job q = pl.jobs[j];
     if (q.b == PD_NONE)
       for (uint32_t k = threadIdx.x; k < q.len; k += 256u)
-        src[q.op + k] = PD_FINAL | (q.a + k);
+        src[q.op + k] = PD_FINAL | (uint32_t)pl.in[q.a + k];                      // (fill checked that the run lies inside the block)
     else
       {
       // piece of a match that starts at output b + a: byte i of the match comes from b + (i mod a), the first period
@@ -533,9 +536,16 @@ __global__ void __launch_bounds__(256) k_pd_jump(PdPlanes P, uint32_t n)
     for (int k = 0; k < 4; ++k)
       if (!(w[k] & PD_FINAL))
         {
-        w[k] = __hip_atomic_load(&src[w[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // up to PD_HOPS hops per round: a round is a pass over the whole workspace whatever is still open, so fewer, longer
+        // rounds (chains shrink to a third per round instead of a half)
+        uint32_t x = __hip_atomic_load(&src[w[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int hop = 1; hop < PD_HOPS; ++hop)
+          if (!(x & PD_FINAL))
+            x = __hip_atomic_load(&src[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w[k] = x;
         mine = true;
-        open = open || !(w[k] & PD_FINAL);
+        open = open || !(x & PD_FINAL);
         }
     if (mine)
       *((u32x4*)src + i) = w;
@@ -546,7 +556,9 @@ __global__ void __launch_bounds__(256) k_pd_jump(PdPlanes P, uint32_t n)
     if (!(s & PD_FINAL))
       {
       // s < i: an earlier output byte; whatever it holds right now is final or a still earlier byte
-      const uint32_t t = __hip_atomic_load(&src[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t t = __hip_atomic_load(&src[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int hop = 1; hop < PD_HOPS && !(t & PD_FINAL); ++hop)
+        t = __hip_atomic_load(&src[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&src[i], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       open = open || !(t & PD_FINAL);
       }
@@ -577,34 +589,40 @@ __global__ void __launch_bounds__(256) k_pd_jump(PdPlanes P, uint32_t n)
 
 __global__ void __launch_bounds__(256) k_pd_gather(PdPlanes P, uint32_t n, uint32_t* __restrict__ status)
   {
+  // a final word carries its byte: the plane is the low bytes of the words, sixteen words per thread and store
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   const PdPlane& pl = P.p[blockIdx.y];
-  const uint8_t* in = pl.in;
-  const uint32_t clen = pl.clen;
   const uint32_t* src = pl.src;
   uint8_t* out = pl.out;
-  if (clen == 0u || pl.ctl->error)
+  if (pl.clen == 0u || pl.ctl->error)
     return;
-  bool bad = false;
-  for (uint32_t i0 = 4u * (blockIdx.x * 256u + threadIdx.x); i0 < n; i0 += 4u * gridDim.x * 256u)
+  uint32_t open = 0;
+  const uint32_t n16 = n >> 4;
+  const bool aligned = ((uintptr_t)out & 15u) == 0u;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u)
     {
-    uint32_t w = 0;
-    const uint32_t m = n - i0 < 4u ? n - i0 : 4u;
-    for (uint32_t k = 0; k < m; ++k)
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
       {
-      const uint32_t s = src[i0 + k];
-      const uint32_t q = s & ~PD_FINAL;
-      if (!(s & PD_FINAL) || q >= clen)
-        bad = true;
-      else
-        w |= (uint32_t)in[q] << (8u * k);
+      const u32x4 w = __builtin_nontemporal_load((const u32x4*)src + 4u * i + (uint32_t)q);
+      open |= ~(w[0] & w[1] & w[2] & w[3]);
+      o[q] = (w[0] & 255u) | ((w[1] & 255u) << 8) | ((w[2] & 255u) << 16) | (w[3] << 24);
       }
-    if (m == 4u && (((uintptr_t)(out + i0)) & 3u) == 0u)
-      *(uint32_t*)(out + i0) = w;
+    if (aligned)
+      __builtin_nontemporal_store(o, (u32x4*)out + i);
     else
-      for (uint32_t k = 0; k < m; ++k)
-        out[i0 + k] = (uint8_t)(w >> (8u * k));
+      for (int q = 0; q < 4; ++q)
+        for (int k = 0; k < 4; ++k)
+          out[16u * i + 4u * (uint32_t)q + (uint32_t)k] = (uint8_t)(o[q] >> (8 * k));
     }
-  if (__ballot(bad) && (threadIdx.x & 63) == 0)
+  for (uint32_t i = 16u * n16 + blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
+    {
+    const uint32_t w = src[i];
+    open |= ~w;
+    out[i] = (uint8_t)w;
+    }
+  if (__ballot((open & PD_FINAL) != 0u) && (threadIdx.x & 63) == 0)
     atomicOr(status, 8u);                           // a chain that never reached a literal: cannot happen after PD_ROUNDS rounds
   }
 
