@@ -165,6 +165,77 @@ __device__ __forceinline__ void parse_seq(const Bytes& b, uint32_t p, Seq& s, in
   s.kind = 0;
   }
 
+// ---- 64 candidate tokens at once --------------------------------------------------------------------------------------------------
+// parse_seq follows the chain one sequence at a time: four dependent LDS round trips and ~300 instructions per sequence by a wave
+// that has nothing else to do - a tile of a mesh's second index plane holds ~2,500 sequences, and one wave per tile walked them for
+// 10 ms (k_pd_tiles) and again for 11 ms (k_pd_fill).  Here lane l decodes the sequence that WOULD start at byte p + l (token, up to
+// one length-extension byte each for the literals and the match, offset), all 64 at once, and the true chain from p is then followed
+// through the lanes with v_readlane: ~15 instructions per sequence.  A candidate with more than three extension bytes (runs of 784
+// bytes and more) is `slow`: the chain stops there and parse_seq takes that one sequence.  Only used where the window and everything a
+// candidate can reach lie inside the staged image and far from the end of the block (win_ok): the last sequence, truncated blocks
+// and everything else that needs care stay with parse_seq.
+struct Win { uint32_t next, lit, lit_pos, off, mlen, slow; };
+constexpr uint32_t WIN_EXT = 3;                                            // length-extension bytes a candidate may have (runs below 784 bytes: never a job, PD_LONG)
+constexpr uint32_t WIN_REACH = 64u + 1u + WIN_EXT + (15u + 255u * WIN_EXT) + 2u + WIN_EXT + 16u;   // bytes from p on that a window may look at (with slack)
+static_assert(15u + 255u * WIN_EXT + 4u < PD_LONG && WIN_REACH + PD_LEAD < PD_STAGE, "a window's sequences are short runs inside the staged image");
+
+// k mod f for k < 2^16 and 0 < f < 2^16 without an integer division (the self-overlapping matches of a periodic plane: every word of
+// them points at the first period): quotient from the float reciprocal, one correction either way
+__device__ __forceinline__ uint32_t mod_small(uint32_t k, uint32_t f, float rf)
+  {
+  const uint32_t q = (uint32_t)((float)k * rf);
+  int r = (int)(k - q * f);
+  r = r < 0 ? r + (int)f : r;
+  return (uint32_t)r >= f ? (uint32_t)r - f : (uint32_t)r;
+  }
+
+__device__ __forceinline__ bool win_ok(const Bytes& b, uint32_t p)
+  {
+  return p >= b.base && p - b.base + WIN_REACH <= b.staged && p + WIN_REACH <= b.clen;
+  }
+
+__device__ __forceinline__ Win scan_window(const Bytes& b, uint32_t p, int lane)
+  {
+  Win w;
+  const uint32_t P = p + (uint32_t)lane;
+  const uint32_t tok = b.at(P);
+  uint32_t lit = tok >> 4, ml = tok & 15u, q = P + 1u;
+  uint32_t slow = 0u;
+  if (lit == 15u)
+    {
+    uint32_t e = 255u;
+    for (uint32_t x = 0; x < WIN_EXT && e == 255u; ++x)
+      {
+      e = b.at(q);
+      lit += e;
+      ++q;
+      }
+    slow = e == 255u ? 1u : 0u;
+    }
+  w.lit_pos = q;
+  w.lit = lit;
+  q += lit;
+  w.off = b.at(q) | (b.at(q + 1u) << 8);
+  q += 2u;
+  if (ml == 15u)
+    {
+    uint32_t e = 255u;
+    for (uint32_t x = 0; x < WIN_EXT && e == 255u; ++x)
+      {
+      e = b.at(q);
+      ml += e;
+      ++q;
+      }
+    slow |= e == 255u ? 1u : 0u;
+    }
+  w.mlen = ml + 4u;
+  w.next = q;
+  w.slow = slow;
+  return w;
+  }
+
+__device__ __forceinline__ uint32_t lane_of(uint32_t x, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)l); }
+
 __device__ __forceinline__ void stage_tile(uint32_t* lds, const uint8_t* __restrict__ in, uint32_t clen, uint32_t from, int lane, Bytes& b)
   {
   // dword-aligned image of in[from .. from + PD_STAGE)
@@ -204,6 +275,28 @@ __device__ __forceinline__ void walk_tile(const Bytes& b, uint32_t start, uint32
       t.exit = p;
       if (t.first == PD_NONE) t.first = p;       // nothing starts inside the tile: the chain passes through
       return;
+      }
+    if (win_ok(b, p))
+      {
+      const Win w = scan_window(b, p, lane);
+      const uint32_t outl = w.lit + w.mlen;
+      uint32_t cur = 0;
+      bool slow = false;
+      while (cur < 64u && p + cur < hi)
+        {
+        if (lane_of(w.slow, cur)) { slow = true; break; }
+        if (p + cur >= lo && t.first == PD_NONE)
+          t.first = p + cur;
+        if (t.first != PD_NONE)
+          {
+          ++t.nseq;
+          t.obytes += lane_of(outl, cur);
+          }
+        cur = uni(lane_of(w.next, cur) - p);
+        }
+      p += cur;
+      if (!slow)
+        continue;                                  // (the window is used up, or the walk has reached hi: the loop's head sees to that)
       }
     Seq s;
     parse_seq(b, p, s, lane);
@@ -418,6 +511,91 @@ __global__ void __launch_bounds__(64) k_pd_fill(PdPlanes P, uint32_t n, uint32_t
   bool bad = false;
   while (p < hi)
     {
+    if (win_ok(b, p))
+      {
+      // the sequences of the chain that start in the next 64 bytes, all at once (scan_window): which lanes they are, where their
+      // output begins (a scan over their lengths), then every lane writes the words of its own sequence - a sequence of such a
+      // plane is a handful of bytes - and only matches of more than 32 bytes are written by the whole wave, one after the other
+      const Win w = scan_window(b, p, lane);
+      uint64_t chain = 0;
+      uint32_t cur = 0;
+      bool slow = false;
+      while (cur < 64u && p + cur < hi)
+        {
+        if (lane_of(w.slow, cur)) { slow = true; break; }
+        chain |= 1ull << cur;
+        cur = uni(lane_of(w.next, cur) - p);
+        }
+      const bool mine = (chain >> lane) & 1ull;
+      const uint32_t outl = mine ? w.lit + w.mlen : 0u;
+      uint32_t incl = outl, mxl = (mine && w.lit <= 32u) ? w.lit : 0u, mxm = (mine && w.mlen <= 32u) ? w.mlen : 0u;
+      for (int d = 1; d < 64; d <<= 1)
+        {
+        const uint32_t o2 = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= d)
+          incl += o2;
+        }
+      for (int d = 32; d > 0; d >>= 1)
+        {
+        mxl = max(mxl, (uint32_t)__shfl_xor((int)mxl, d, 64));
+        mxm = max(mxm, (uint32_t)__shfl_xor((int)mxm, d, 64));
+        }
+      const uint32_t total = lane_of(incl, 63u);
+      if (total > n - op) { bad = true; break; }
+      const uint32_t lop = op + incl - outl, mop = lop + w.lit;            // where my literals / my match begin
+      // (lz4.c:1800-1830: the offset must stay inside what has been written)
+      if (__ballot(mine && (w.off == 0u || w.off > mop)) != 0ull) { bad = true; break; }
+      {
+      const bool shortl = mine && w.lit <= 32u;
+      for (uint32_t k = 0; k < mxl; ++k)
+        if (shortl && k < w.lit)
+          src[lop + k] = PD_FINAL | b.at(w.lit_pos + k);
+      uint64_t longl = __ballot(mine && w.lit > 32u);
+      while (longl)
+        {
+        const uint32_t l = (uint32_t)__builtin_ctzll(longl);
+        longl &= longl - 1ull;
+        const uint32_t o = lane_of(lop, l), f = lane_of(w.lit_pos, l), m = lane_of(w.lit, l);
+        for (uint32_t k = (uint32_t)lane; k < m; k += 64u)
+          src[o + k] = PD_FINAL | b.at(f + k);
+        }
+      }
+      {
+      // short matches, lane by lane; one that overlaps itself points at its first period (k mod off, kept as a running remainder)
+      const bool shortm = mine && w.mlen <= 32u;
+      const uint32_t first = mop - w.off;
+      uint32_t r = 0;
+      for (uint32_t k = 0; k < mxm; ++k)
+        {
+        if (shortm && k < w.mlen)
+          src[mop + k] = first + r;
+        ++r;
+        r = r == w.off ? 0u : r;
+        }
+      }
+      uint64_t longm = __ballot(mine && w.mlen > 32u);
+      while (longm)
+        {
+        const uint32_t l = (uint32_t)__builtin_ctzll(longm);
+        longm &= longm - 1ull;
+        const uint32_t o = lane_of(mop, l), f = lane_of(w.off, l), m = lane_of(w.mlen, l);
+        if (m <= f)
+          for (uint32_t k = (uint32_t)lane; k < m; k += 64u)
+            src[o + k] = o + k - f;
+        else
+          {
+          const float rf = 1.0f / (float)f;
+          for (uint32_t k = (uint32_t)lane; k < m; k += 64u)
+            src[o + k] = o - f + mod_small(k, f, rf);
+          }
+        }
+      op += total;
+      p += cur;
+      if (!slow)
+        continue;
+      if (p >= hi)
+        break;
+      }
     Seq s;
     parse_seq(b, p, s, lane);
     if (s.kind == 2) { bad = true; break; }
@@ -459,8 +637,11 @@ __global__ void __launch_bounds__(64) k_pd_fill(PdPlanes P, uint32_t n, uint32_t
         src[op + k] = op + k - s.off;
     else
       // the match overlaps itself: a periodic run.  Every byte points at the first period (which lies before the match).
+      {
+      const float rf = 1.0f / (float)s.off;                                       // (mlen < PD_LONG here: mod_small's range)
       for (uint32_t k = (uint32_t)lane; k < s.mlen; k += 64u)
-        src[op + k] = op - s.off + k % s.off;
+        src[op + k] = op - s.off + mod_small(k, s.off, rf);
+      }
     op += s.mlen;
     p = s.next;
     }
