@@ -98,6 +98,30 @@ struct Seq { uint32_t lit_pos, lit_len, off, mlen, next; int kind; };   // kind 
 // call this together with the same arguments: 64 bytes per round (a 30 KiB match has 118 extension bytes).  false: malformed.
 __device__ __forceinline__ bool ext_length(const Bytes& b, uint32_t& q, uint32_t& len, int lane)
   {
+  // A run of megabytes is a megabyte / 255 of extension bytes (the upper byte planes of a regular mesh's indices are ONE match of
+  // 300 MB: 1.18 MB of 0xFF), and 64 bytes per round trip made that 2 ms for the one wave that meets it - in the chain walk, in
+  // the tile walk and in the fill, each the tail of its kernel.  Far from the block's end the run is first skipped 8 KiB at a time:
+  // eight 16-byte loads per lane, all issued before the first is looked at; the first block that is not all 0xFF goes to the
+  // byte-wise rounds below.
+  for (;;)
+    {
+    if (q + 8192u + 16u > b.clen || len > 0x7fffffffu - 255u * 8192u)
+      break;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    struct __attribute__((packed, aligned(1))) U { u32x4 v; };
+    uint32_t all = 0xffffffffu;
+    u32x4 x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      x[k] = ((const U*)(b.in + q + 1024u * (uint32_t)k + 16u * (uint32_t)lane))->v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      all &= x[k][0] & x[k][1] & x[k][2] & x[k][3];
+    if (__ballot(all != 0xffffffffu) != 0ull)
+      break;
+    len += 255u * 8192u;
+    q += 8192u;
+    }
   for (;;)
     {
     const uint32_t pos = q + (uint32_t)lane;
