@@ -49,7 +49,7 @@ constexpr int PD_ROUNDS = 20;                 // chains are shorter than 2^31 < 
 
 struct Tile { uint32_t first, exit, nseq, pad; unsigned long long obytes; };
 struct Job { uint32_t op, len, a, b; };       // b == PD_NONE: literals from input position a; else match: offset a, its first period starts at output b
-struct Ctl { uint32_t error, njobs, changed, done, total_seq, arrived, pad[2]; };
+struct Ctl { uint32_t error, njobs, changed, done, total_seq, arrived, run_end, pad; };   // run_end: the block's first literal run ends here (tile 0's walk)
 
 // One plane of a stream and its workspace
 struct PdPlane
@@ -355,6 +355,18 @@ __global__ void __launch_bounds__(64) k_pd_tiles(PdPlanes P, int second)
   const uint32_t lo = t * PD_TILE, hi = lo + PD_TILE;
   uint32_t start = lo > PD_LEAD ? lo - PD_LEAD : 0u;
   Tile* dst = second ? pl.tiles : pl.tiles0;
+  if (second && hi <= pl.ctl->run_end)
+    {
+    // An incompressible plane is ONE literal run of its whole size: every byte of it read as a token is garbage, every tile's
+    // speculative walk ends in the next tile, and the second round walked all 37,000 tiles of a 300 MB plane again (4 ms).  The
+    // chain enters none of them: tile 0's walk, which begins at a true token, has said where the block's first literal run ends.
+    if (lane == 0)
+      {
+      dst[t] = pl.tiles0[t];
+      pl.onpath[t] = 0u;
+      }
+    return;
+    }
   if (second)
     {
     // second round: where the predecessor's walk of the first round left its tile.  Even if that walk started at a wrong
@@ -402,6 +414,13 @@ __global__ void __launch_bounds__(64) k_pd_tiles(PdPlanes P, int second)
       if (q + 1u < clen && q + 1u < hi)
         start = q + 1u;                               // behind the remainder byte
       }
+    }
+  if (!second && t == 0u)
+    {
+    Seq s0;
+    parse_seq(b, 0u, s0, lane);
+    if (lane == 0)
+      pl.ctl->run_end = (s0.kind != 2 && s0.lit_len >= 2u * PD_TILE) ? s0.lit_pos + s0.lit_len : 0u;
     }
   Tile r;
   walk_tile(b, start, lo, hi, r, lane);           // every lane walks the same chain (uniform control flow, LDS broadcast reads)
@@ -507,6 +526,38 @@ __global__ void __launch_bounds__(64) k_pd_chain(PdPlanes P, uint32_t n, uint32_
     ctl->total_seq = seqs;
   }
 
+// Places in the job list, reserved PD_JCHUNK at a time: a tile of a periodic plane holds ~300 runs of a KiB and more, and an atomic
+// round trip per run was most of the fill's time.  What a wave has reserved and not used is filled with empty jobs (length 0).
+constexpr uint32_t PD_JCHUNK = 16;
+struct JobSlots
+  {
+  uint32_t base = 0, left = 0;
+  __device__ __forceinline__ uint32_t take(uint32_t np, Ctl* ctl, Job* jobs, uint32_t job_cap, int lane)
+    {
+    if (np > left)
+      {
+      release(jobs, job_cap, lane);
+      const uint32_t want = np > PD_JCHUNK ? np : PD_JCHUNK;
+      uint32_t j0 = 0;
+      if (lane == 0)
+        j0 = atomicAdd(&ctl->njobs, want);
+      base = uni(j0);
+      left = want;
+      }
+    const uint32_t at = base;
+    base += np;
+    left -= np;
+    return at;
+    }
+  __device__ __forceinline__ void release(Job* jobs, uint32_t job_cap, int lane)
+    {
+    for (uint32_t k = (uint32_t)lane; k < left; k += 64u)
+      if (base + k < job_cap)
+        jobs[base + k] = Job{ 0u, 0u, 0u, PD_NONE };
+    left = 0;
+    }
+  };
+
 // one wave per tile on the chain: source words of its output bytes
 __global__ void __launch_bounds__(64) k_pd_fill(PdPlanes P, uint32_t n, uint32_t job_cap, uint32_t* __restrict__ status)
   {
@@ -533,6 +584,7 @@ __global__ void __launch_bounds__(64) k_pd_fill(PdPlanes P, uint32_t n, uint32_t
   uint32_t p = r.first;
   uint32_t op = out_base[t];
   bool bad = false;
+  JobSlots slots;
   while (p < hi)
     {
     if (win_ok(b, p))
@@ -629,10 +681,7 @@ __global__ void __launch_bounds__(64) k_pd_fill(PdPlanes P, uint32_t n, uint32_t
       {
       // pieces of at most PD_PIECE bytes, one workgroup each
       const uint32_t np = (s.lit_len + PD_PIECE - 1u) / PD_PIECE;
-      uint32_t j0 = 0;
-      if (lane == 0)
-        j0 = atomicAdd(&ctl->njobs, np);
-      j0 = uni(j0);
+      const uint32_t j0 = slots.take(np, ctl, jobs, job_cap, lane);
       for (uint32_t k = (uint32_t)lane; k < np; k += 64u)
         if (j0 + k < job_cap)
           jobs[j0 + k] = Job{ op + k * PD_PIECE, (k + 1u == np) ? s.lit_len - k * PD_PIECE : PD_PIECE, s.lit_pos + k * PD_PIECE, PD_NONE };
@@ -648,10 +697,7 @@ __global__ void __launch_bounds__(64) k_pd_fill(PdPlanes P, uint32_t n, uint32_t
     if (s.mlen >= PD_LONG)
       {
       const uint32_t np = (s.mlen + PD_PIECE - 1u) / PD_PIECE;
-      uint32_t j0 = 0;
-      if (lane == 0)
-        j0 = atomicAdd(&ctl->njobs, np);
-      j0 = uni(j0);
+      const uint32_t j0 = slots.take(np, ctl, jobs, job_cap, lane);
       for (uint32_t k = (uint32_t)lane; k < np; k += 64u)
         if (j0 + k < job_cap)
           jobs[j0 + k] = Job{ op + k * PD_PIECE, (k + 1u == np) ? s.mlen - k * PD_PIECE : PD_PIECE, s.off, op - s.off };
@@ -669,6 +715,7 @@ __global__ void __launch_bounds__(64) k_pd_fill(PdPlanes P, uint32_t n, uint32_t
     op += s.mlen;
     p = s.next;
     }
+  slots.release(jobs, job_cap, lane);
   if (bad && lane == 0)
     {
     atomicOr(status, 8u);
@@ -837,7 +884,9 @@ PdPlan pd_plan(uint32_t plane_bytes, uint32_t max_clen)
   {
   PdPlan p;
   p.max_tiles = (max_clen + PD_TILE - 1) / PD_TILE + 1;
-  p.job_cap = plane_bytes / PD_LONG + 2 * p.max_tiles + 16;    // every job covers >= PD_LONG output bytes or ends a run
+  // every job covers >= PD_LONG output bytes or ends a run; a tile leaves fewer than PD_JCHUNK reserved places unused at its end, and so
+  // does every run of more than PD_JCHUNK pieces
+  p.job_cap = plane_bytes / PD_LONG + 2 * p.max_tiles + 16 + PD_JCHUNK * (p.max_tiles + plane_bytes / (PD_JCHUNK * PD_PIECE) + 1);
   size_t o = 0;
   auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes + 16, 256); return at; };
   p.tiles = take(sizeof(Tile) * (size_t)p.max_tiles);
