@@ -342,6 +342,22 @@ __device__ __forceinline__ void walk_tile(const Bytes& b, uint32_t start, uint32
     }
   }
 
+// the block's first sequence, before anything else: where its literal run ends (Ctl::run_end; 0: nothing worth knowing)
+__global__ void __launch_bounds__(64) k_pd_head(PdPlanes P)
+  {
+  __shared__ uint32_t lds[PD_STAGE / 4 + 2];
+  const int lane = threadIdx.x;
+  const PdPlane& pl = P.p[blockIdx.x];
+  if (pl.clen == 0u)
+    return;
+  Bytes b;
+  stage_tile(lds, pl.in, pl.clen, 0u, lane, b);
+  Seq s0;
+  parse_seq(b, 0u, s0, lane);
+  if (lane == 0)
+    pl.ctl->run_end = (s0.kind != 2 && s0.lit_len >= 2u * PD_TILE) ? s0.lit_pos + s0.lit_len : 0u;
+  }
+
 __global__ void __launch_bounds__(64) k_pd_tiles(PdPlanes P, int second)
   {
   __shared__ uint32_t lds[PD_STAGE / 4 + 2];
@@ -355,14 +371,16 @@ __global__ void __launch_bounds__(64) k_pd_tiles(PdPlanes P, int second)
   const uint32_t lo = t * PD_TILE, hi = lo + PD_TILE;
   uint32_t start = lo > PD_LEAD ? lo - PD_LEAD : 0u;
   Tile* dst = second ? pl.tiles : pl.tiles0;
-  if (second && hi <= pl.ctl->run_end)
+  if (t != 0u && hi <= pl.ctl->run_end)
     {
     // An incompressible plane is ONE literal run of its whole size: every byte of it read as a token is garbage, every tile's
-    // speculative walk ends in the next tile, and the second round walked all 37,000 tiles of a 300 MB plane again (4 ms).  The
-    // chain enters none of them: tile 0's walk, which begins at a true token, has said where the block's first literal run ends.
+    // speculative walk ends in the next tile, and both rounds walked all 37,000 tiles of a 300 MB plane (7 + 1 ms).  The chain
+    // enters none of them: k_pd_head has said where the block's first literal run ends.
     if (lane == 0)
       {
-      dst[t] = pl.tiles0[t];
+      Tile none;
+      none.first = PD_NONE; none.exit = PD_NONE; none.nseq = 0; none.pad = 0; none.obytes = 0;
+      dst[t] = none;                                  // (k_pd_chain walks the tile the chain really enters on the spot)
       pl.onpath[t] = 0u;
       }
     return;
@@ -414,13 +432,6 @@ __global__ void __launch_bounds__(64) k_pd_tiles(PdPlanes P, int second)
       if (q + 1u < clen && q + 1u < hi)
         start = q + 1u;                               // behind the remainder byte
       }
-    }
-  if (!second && t == 0u)
-    {
-    Seq s0;
-    parse_seq(b, 0u, s0, lane);
-    if (lane == 0)
-      pl.ctl->run_end = (s0.kind != 2 && s0.lit_len >= 2u * PD_TILE) ? s0.lit_pos + s0.lit_len : 0u;
     }
   Tile r;
   walk_tile(b, start, lo, hi, r, lane);           // every lane walks the same chain (uniform control flow, LDS broadcast reads)
@@ -960,6 +971,7 @@ int launch_lz4_decode_parallel(const uint8_t* const d_payloads[8], const uint32_
   const unsigned np = (unsigned)nplanes;
   // (a plane with no block at all - an empty plane is the one-byte block 0x00, lz4.c:1146-1172 with n = 0 - is reported by
   // the chain kernel; the other phases skip it)
+  hipLaunchKernelGGL(k_pd_head, dim3(np), dim3(64), 0, st, P);
   hipLaunchKernelGGL(k_pd_tiles, dim3(max_nt, np), dim3(64), 0, st, P, 0);
   hipLaunchKernelGGL(k_pd_tiles, dim3(max_nt, np), dim3(64), 0, st, P, 1);
   hipLaunchKernelGGL(k_pd_chain, dim3(np), dim3(64), 0, st, P, plane_bytes, d_status);
