@@ -1405,7 +1405,7 @@ static bool lz4_use_xchg()
 
 struct Plan { Geom g; size_t off_desc, off_meta, off_snap, off_end, off_cbytes, off_coff, off_altdesc, off_altmeta, off_altend, total; };
 
-// mode 0: long matches (1 MiB chunks, 384 KiB warm-up), mode 1: short sequences (192 KiB / 70,000 B); TRICO_LZ4_CHUNK / TRICO_LZ4_WARM
+// mode 0: long matches (512 KiB chunks, 384 KiB warm-up), mode 1: short sequences (64-192 KiB / 70,000 B); TRICO_LZ4_CHUNK / TRICO_LZ4_WARM
 // fix one geometry for both (tuning knobs)
 static bool geometry_forced() { return getenv("TRICO_LZ4_CHUNK") || getenv("TRICO_LZ4_WARM"); }
 
@@ -1417,7 +1417,7 @@ Plan make_plan(uint32_t n, int nplanes, size_t plane_stride, int mode)
     Env v;
     v.forced = geometry_forced();
     const char* e = getenv("TRICO_LZ4_CHUNK");
-    v.chunk = e ? (uint32_t)atoi(e) : (1u << 20);
+    v.chunk = e ? (uint32_t)atoi(e) : (512u << 10);        // (round 6: 1 MiB until then - with alternative parses and open matches the parse pass is what is left, and it is one chunk's time)
     if (v.chunk < (1u << 17)) v.chunk = 1u << 17;
     const char* w = getenv("TRICO_LZ4_WARM");
     v.warm = w ? (uint32_t)atoi(w) : (384u << 10);
