@@ -1051,6 +1051,34 @@ __global__ void __launch_bounds__(64 * STITCH_W) k_lz4_stitch(const uint8_t* __r
     {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
     __syncthreads();
+    if (ver == 0u)
+      {
+      // Runs of chunks whose speculation holds, 64 at a time (round 6: one chunk per step was 1,563 steps of three dependent memory
+      // round trips per plane of short sequences: 4.6 ms).  Lane l looks at chunk cur + 1 + l: it is the chain's next chunk with its
+      // parse accepted as it stands iff its predecessor is (lane l - 1; lane 0: cur, which is), the predecessor's parse ended with a
+      // match end inside this chunk, this chunk's snapshot was taken exactly there, and k_lz4_alt found its table equal to the
+      // predecessor's speculative end state (bit 0 of agree) - the very tests of the single step below for ver = 0.
+      const uint32_t lane64 = threadIdx.x & 63u;
+      const uint32_t jl = cur + 1u + lane64;
+      bool good = false;
+      if (jl < g.K)
+        {
+        const Meta prev = pm[jl - 1u], me = pm[jl];
+        good = prev.end_kind == END_MATCH && prev.end_ip / g.chunk == jl && me.snap_valid != 0u && me.snap_ip == prev.end_ip &&
+               me.end_kind != END_NONE && (agree[(size_t)p * g.K + jl] & 1u) != 0u;
+        }
+      const uint64_t gm = __ballot(good);
+      const uint32_t run = gm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~gm);
+      if (run != 0u)
+        {
+        if (threadIdx.x < run)
+          pm[jl].accepted = 1u;
+        if (threadIdx.x == 0)
+          atomicAdd(status + 1, run);
+        cur += run;
+        continue;
+        }
+      }
     const uint32_t kind = uni(pm[cur].end_kind), ip = uni(pm[cur].end_ip);
     if (kind == END_FINAL)
       return;
