@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _lib(native_libs):
+    native_libs.lib()                      # (imports torch first where it is installed: one HIP runtime per process)
     L = ctypes.CDLL(native_libs.LIB_PATH)
     vp, ci = ctypes.c_void_p, ctypes.c_int
     L.LZ4_compress_default.argtypes = [vp, vp, ci, ci]
@@ -84,3 +85,23 @@ def test_block_api_against_the_compiled_reference(native_libs):
     assert na == nb and a[:na].tobytes() == b[:nb].tobytes()
     for cap in (na - 1, na, na + 1):                   # the output-limited path of the reference (lz4.c:975-980, 1057-1062, 1153-1160)
         assert (R.LZ4_compress_default(data.ctypes.data, a.ctypes.data, data.size, cap) > 0) == (L.LZ4_compress_default(data.ctypes.data, b.ctypes.data, data.size, cap) > 0)
+
+
+def test_block_api_takes_device_pointers(native_libs):
+    """src / dst in HBM (the boundary's MI355X extension: any data pointer may be a HIP device pointer)"""
+    import torch
+    L = _lib(native_libs)
+    rng = np.random.default_rng(3)
+    data = np.concatenate([rng.integers(0, 4, 400000, dtype=np.uint8), np.zeros(700000, np.uint8), rng.integers(0, 256, 5000, dtype=np.uint8)])
+    want = O.lz4_compress(data)
+    d_src = torch.from_numpy(data).cuda()
+    bound = L.LZ4_compressBound(data.size)
+    d_dst = torch.zeros(bound, dtype=torch.uint8, device="cuda")
+    n = L.LZ4_compress_default(d_src.data_ptr(), d_dst.data_ptr(), data.size, bound)
+    assert n == len(want), native_libs.last_error()
+    assert d_dst[:n].cpu().numpy().tobytes() == want
+    d_out = torch.full((data.size + 32,), 0xEE, dtype=torch.uint8, device="cuda")
+    assert L.LZ4_decompress_safe(d_dst.data_ptr(), d_out.data_ptr(), n, data.size) == data.size, native_libs.last_error()
+    back = d_out.cpu().numpy()
+    assert back[:data.size].tobytes() == data.tobytes() and (back[data.size:] == 0xEE).all()
+    assert L.LZ4_decompress_safe(d_dst.data_ptr(), d_out.data_ptr(), n, data.size + 32) == data.size, native_libs.last_error()
