@@ -83,4 +83,10 @@ for case in range(cases):
     r.close()
     if case % 25 == 24:
         print("case", case + 1, "ok, %.0f s" % (time.time() - t0), flush=True)
-print("soak passed:", cases, "cases, seed", seed)
+import ctypes
+vs = (ctypes.c_uint64 * 3)()
+api.lib().trico_hip_encode_verify_stats(vs)
+st = (ctypes.c_uint32 * 4)()
+api.lib().trico_hip_last_stats(st)
+print("soak passed:", cases, "cases, seed", seed, "| encode verification: %d streams, %d values, %d differed | decode repeats %d, other-writer streams %d"
+      % (vs[0], vs[1], vs[2], st[2], st[3]))
