@@ -38,6 +38,7 @@
 //   preds   (k64_pred):   sorted neighbour with the same hash -> its payload, scattered back to the value's index
 #include <atomic>
 #include "common.hpp"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace trico {
@@ -711,6 +712,9 @@ int both_tables(const u64* src, uint32_t n, int arity, const EncPlan& p, uint8_t
       return 0;
     walk0 = h[0] <= walk_limit(n, arity);
     walk1 = h[4] <= walk_limit(n, arity);
+    if (getenv("TRICO_HIP_DEBUG"))
+      fprintf(stderr, "trico_hip: double encoder, %u x %d values: FCM table %u operations, longest of %u lists %u (an even share: %u); DFCM table %u, longest %u (%u)\n",
+              n, arity, h[1], (unsigned)arity * OWNERS, h[0], h[1] / ((unsigned)arity * OWNERS), h[5], h[4], h[5] / ((unsigned)arity * OWNERS));
     }
   static thread_local Side side;
   const Marks none = { nullptr, nullptr, nullptr, nullptr };
