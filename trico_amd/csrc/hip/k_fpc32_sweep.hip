@@ -1434,7 +1434,7 @@ __global__ void __launch_bounds__(256) k_fpc32_fixup(int arity, uint32_t S, cons
 // ---- gather: segment slots -> contiguous payload ----------------------------------------------------------------------------
 // grid (S, components); each workgroup moves one segment.  Without records: the destination is written as aligned 16-byte vectors,
 // the source (a 256-byte aligned slot) is read as 4 + 1 dwords per vector and re-aligned with v_alignbyte.
-// With records the slot is cut into sub-chunks of 1 KiB of SOURCE bytes (more for slots beyond 512 KiB).  A pass over the records
+// With records the slot is cut into sub-chunks of 2 KiB of SOURCE bytes (more for slots beyond 1 MiB).  A pass over the records
 // counts the unused bytes of every sub-chunk - a prefix sum says where its output begins - and marks the ones a record touches.
 // Then every WAVE takes sub-chunks by itself, no barrier: an untouched one is the copy with a shift again; a touched one passes
 // through the wave's own LDS, 64 x 16 bytes at a time: the records put their residual bytes and code bits into a patch area (ORed
@@ -1442,6 +1442,12 @@ __global__ void __launch_bounds__(256) k_fpc32_fixup(int arity, uint32_t S, cons
 // of every lane says where they go, and they land in a small output ring whose positions are congruent to the destination's
 // modulo 16 and leave it as aligned 16-byte vectors.  Every output byte is written once, by the wave that owns it; the partial
 // vectors at the ends of a sub-chunk's output go byte by byte.  Nothing is searched: a record knows its slot position.
+// sub-chunks of 2 KiB of a slot (round 6; 1 KiB until then.  Same box, alternating: gather 166 -> 158 us on the benchmark mesh, 155 -> 153 us
+// on the walk mesh; 4 KiB is slower again by as much - fewer sub-chunks mean fewer set-ups, larger ones more bytes through the record path
+// for one record.  The boxes themselves differ by +-10 us on this kernel.)
+#ifndef TRICO_GSUBSHIFT
+#define TRICO_GSUBSHIFT 11
+#endif
 constexpr uint32_t GSUB = 1024;                    // source bytes per piece (64 lanes x 16)
 constexpr uint32_t MAXSUB = 512;                   // sub-chunks per slot (LDS: 8 workgroups per compute unit)
 constexpr uint32_t WRING = 1024 + 64;              // a wave's output buffer: at most 15 + 1024 bytes are in it at a time (+ the slack of a 16-byte store)
@@ -1536,7 +1542,7 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
   __shared__ __attribute__((aligned(16))) uint32_t wlds[4][(GSUB + GSUB / 8 + WRING + 32) / 4];       // per wave: patches, unused marks, output ring
   const uint32_t slen = rawbytes[(size_t)cc * S + g];
   const uint32_t* list = recs + rowi * RCAP * RECW;
-  uint32_t subshift = 10;
+  uint32_t subshift = TRICO_GSUBSHIFT;
   while (((slen - 1u) >> subshift) >= MAXSUB)
     ++subshift;
   const uint32_t subsize = 1u << subshift, nsub = ((slen - 1u) >> subshift) + 1u;
