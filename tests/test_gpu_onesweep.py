@@ -1,4 +1,4 @@
-"""The one-sweep float encoder (k_fpc32_sweep.hip: k_fpc32_sweep / k_fpc32_pscan_* / k_fpc32_fixup / k_fpc32_gather; the library's
+"""The one-sweep float encoder (k_fpc32_sweep.hip: k_fpc32_sweep / k_fpc32_scanfix / k_fpc32_gather; the library's
 choice on a device that passes the lane-order test) against the oracle: the archives have to be the reference's bytes on streams built
 to stress the deferred values - a stream whose every DFCM class is new (a record per value at the start of every segment), exact hits
 that are deferred (residual length 0: four unused bytes in a row), the coder's "never written" mark as a value and as a stride (the

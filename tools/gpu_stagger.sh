@@ -8,6 +8,6 @@ for b in "$@"; do
   export TRICO_FPC32_STAGGER=$b
   for m in grid walk; do
     timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/enc -- python $R/tools/perf_fpc32.py $m > $O/b${b}_$m.log 2>&1
-    echo "## beta $b $m"; grep "kernel span" $O/b${b}_$m.log; python $R/tools/prof_summary.py $O/enc | grep "sweep<\|gather\|fixup"; rm -rf $O/enc
+    echo "## beta $b $m"; grep "kernel span" $O/b${b}_$m.log; python $R/tools/prof_summary.py $O/enc | grep "sweep<\|gather\|scanfix\|offsets"; rm -rf $O/enc
   done
 done 2>&1 | tee $O/summary.txt

@@ -9,7 +9,7 @@ for v in "$@"; do
     case $v in
       *diag) timeout -k 10 120 python $R/tools/perf_fpc32.py $m > $O/${v}_$m.log 2>&1; echo "## $v $m"; grep "kernel span" $O/${v}_$m.log; grep "sweep diag" $O/${v}_$m.log | tail -3 ;;
       *) timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/enc -- python $R/tools/perf_fpc32.py $m > $O/${v}_$m.log 2>&1
-         echo "## $v $m"; grep "kernel span" $O/${v}_$m.log; python $R/tools/prof_summary.py $O/enc | grep "sweep \|gather\|fixup"; rm -rf $O/enc ;;
+         echo "## $v $m"; grep "kernel span" $O/${v}_$m.log; python $R/tools/prof_summary.py $O/enc | grep "sweep<\|gather\|scanfix\|offsets"; rm -rf $O/enc ;;
     esac
   done
 done

@@ -96,6 +96,7 @@ struct ProfSpan
   bool active, counted;
   hipEvent_t e0, e1;
   explicit ProfSpan(int kernel_id, bool count_launch = true);
+  void stop();                    // the span ends here (before the host waits for the stream), not at the end of the scope
   ~ProfSpan();
   };
 
@@ -131,9 +132,11 @@ size_t fpc32_encode_workspace(uint32_t n, int arity);
 // FPC32_CODER_BALLOT: always the two-sweep coder with ballots (what the decoders' self-check uses).
 constexpr int FPC32_CODER_AUTO = 0, FPC32_CODER_BALLOT = 1;
 constexpr uint32_t FPC32_FLAG_ORDER = 1u;      // a sampled step found the LDS exchange out of lane order (-> fpc32_distrust_lane_order())
+constexpr uint32_t FPC32_FLAG_SCAN = 4u;       // a bounded wait between the workgroups of the one-sweep coder's scan kernel ran out (k_fpc32_scanfix)
 constexpr uint32_t FPC32_FLAG_SENTINEL = 2u;   // a payload equal to the one-sweep coder's "never written" mark was written to a table
 int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
-                        uint8_t* d_ws, size_t ws_bytes, int coder = FPC32_CODER_AUTO);
+                        uint8_t* d_ws, size_t ws_bytes, int coder = FPC32_CODER_AUTO, uint32_t* h_sizes = nullptr);
+// (h_sizes: six words of pinned host memory that get the same words as d_sizes, valid when the stream is done - saves the copy launch)
 void fpc32_distrust_lane_order();    // this device's exchange is not used again in this process
 bool lds_lane_order_ok();            // the device applies the lanes of one LDS exchange in lane order (tested once per device)
 int fpc32_code_sweep_mode();          // what FPC32_CODER_AUTO runs: 0 two sweeps + ballots, 2 two sweeps + exchange, 3 one sweep + exchange

@@ -23,7 +23,7 @@ constexpr uint32_t SENT = 0x7fc0dead;
 
 // what a wave of the one-sweep coder can raise; the flags travel in the upper half of its record count (Plan::off_nrec) and reach
 // the host with the sizes (k_fpc32_offsets)
-constexpr uint32_t FLAG_ORDER = FPC32_FLAG_ORDER, FLAG_SENTINEL = FPC32_FLAG_SENTINEL;
+constexpr uint32_t FLAG_ORDER = FPC32_FLAG_ORDER, FLAG_SENTINEL = FPC32_FLAG_SENTINEL, FLAG_SCAN = FPC32_FLAG_SCAN;
 
 // Record of a deferred value (k_fpc32_sweep -> k_fpc32_fixup -> k_fpc32_gather), RECW words:
 //   w0 slot offset of the value's four reserved bytes | gi << 24 | ft1 << 28 | ft2 << 29
@@ -54,7 +54,7 @@ struct Plan
   uint32_t L, S, segcap, nch;
   Stagger sg;
   size_t rows, slot_stride;
-  size_t off_summ, off_inc, off_chmax, off_nrec, off_recs, off_segbytes, off_rawbytes, off_segoff, off_gslots, off_grecs, off_gmeta, off_diag, off_slots, total;
+  size_t off_summ, off_inc, off_chmax, off_agg, agg_words, off_nrec, off_recs, off_segbytes, off_rawbytes, off_segoff, off_gslots, off_grecs, off_gmeta, off_diag, off_slots, total;
   };
 
 // Workgroups of k_fpc32_sweep (one wave per component) the current device holds at once (k_fpc32_sweep.hip).  The sweep wants its whole
@@ -138,6 +138,9 @@ inline Plan make_plan(uint32_t n, int arity)
   p.off_summ = o;      o += align_up(p.rows * ROW * 4, 256);
   p.off_inc = o;       o += align_up(p.rows * ROW * 4, 256);
   p.off_chmax = o;     o += align_up((size_t)p.nch * arity * TAB * 4, 256);
+  // the one-sweep coder's scan (k_fpc32_scanfix): per (chunk, component, class) one 64-bit word "ready | latest entry"; the sweep zeroes them
+  p.agg_words = (size_t)p.nch * arity * TAB;
+  p.off_agg = o;       o += align_up(p.agg_words * 8, 256);
   p.off_nrec = o;      o += align_up(p.rows * 4, 256);
   p.off_recs = o;      o += align_up(p.rows * RCAP * RECW * 4, 256);
   p.off_segbytes = o;  o += align_up(p.rows * 4, 256);

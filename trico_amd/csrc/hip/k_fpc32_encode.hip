@@ -791,7 +791,8 @@ __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(8, 8))
 // record counts, so that nothing has to be zeroed before a sweep), read back with the sizes.
 // rectot[c] = the records (deferred values) of component c: the gather takes the components in the order of these.
 __global__ void __launch_bounds__(1024) k_fpc32_offsets(const uint32_t* __restrict__ segbytes, uint32_t S, int arity, uint32_t* __restrict__ segoff,
-                                                        uint32_t* __restrict__ sizes, const uint32_t* __restrict__ nrec, uint32_t* __restrict__ rectot)
+                                                        uint32_t* __restrict__ sizes, const uint32_t* __restrict__ nrec, uint32_t* __restrict__ rectot,
+                                                        uint32_t* __restrict__ mirror)
   {
   __shared__ uint32_t wsum[16], wfl[16], wrec[16];
   const uint32_t c = blockIdx.x;
@@ -839,6 +840,12 @@ __global__ void __launch_bounds__(1024) k_fpc32_offsets(const uint32_t* __restri
     sizes[c] = total;
     sizes[3u + c] = fl;
     rectot[c] = recs;
+    if (mirror)
+      {
+      // (pinned host memory: the caller reads the sizes there when the stream is done - no copy launch behind this kernel)
+      mirror[c] = total;
+      mirror[3u + c] = fl;
+      }
     }
   }
 
@@ -880,13 +887,18 @@ __global__ void __launch_bounds__(256) k_fpc32_compare(const uint8_t* __restrict
   }
 
 // n == 0: undefined in the reference; defined as header + one full pad group
-__global__ void k_fpc32_empty(uint8_t* out, size_t out_stride, uint32_t* sizes)
+__global__ void k_fpc32_empty(uint8_t* out, size_t out_stride, uint32_t* sizes, uint32_t* mirror)
   {
   uint8_t* o = out + (size_t)blockIdx.x * out_stride;
   const uint8_t bts[16] = { 0x25, 0, 0, 0, 0, 0x24, 0x92, 0x49, 0, 0, 0, 0, 0, 0, 0, 0 };
   for (int i = 0; i < 16; ++i) o[i] = bts[i];
   sizes[blockIdx.x] = 16;
   sizes[3u + blockIdx.x] = 0;
+  if (mirror)
+    {
+    mirror[blockIdx.x] = 16;
+    mirror[3u + blockIdx.x] = 0;
+    }
   }
 
 
@@ -998,12 +1010,12 @@ int fpc32_code_sweep_mode()
   }
 
 int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
-                        uint8_t* d_ws, size_t ws_bytes, int coder)
+                        uint8_t* d_ws, size_t ws_bytes, int coder, uint32_t* h_sizes)
   {
   hipStream_t st = current_stream();
   if (n == 0)
     {
-    hipLaunchKernelGGL(k_fpc32_empty, dim3(arity), dim3(1), 0, st, d_out, out_stride, d_sizes);
+    hipLaunchKernelGGL(k_fpc32_empty, dim3(arity), dim3(1), 0, st, d_out, out_stride, d_sizes, h_sizes);
     return hip_ok(hipGetLastError(), "k_fpc32_empty") ? 1 : 0;
     }
   const Plan p = make_plan(n, arity);
@@ -1026,7 +1038,7 @@ int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
     {
     if (!launch_fpc32_sweep(src, n, arity, p, d_ws))
       return 0;
-    hipLaunchKernelGGL(k_fpc32_offsets, dim3(arity), dim3(1024), 0, st, segbytes, p.S, arity, segoff, d_sizes, nrec, (uint32_t*)(d_ws + p.off_diag + 256));
+    hipLaunchKernelGGL(k_fpc32_offsets, dim3(arity), dim3(1024), 0, st, segbytes, p.S, arity, segoff, d_sizes, nrec, (uint32_t*)(d_ws + p.off_diag + 256), h_sizes);
     return hip_ok(hipGetLastError(), "k_fpc32_offsets") ? 1 : 0;
     }
   const uint32_t prio_mode = 8u | (1u << 8);      // priority by progress, at most one block of lag between the component waves (measured in round 3)
@@ -1046,7 +1058,7 @@ int launch_fpc32_encode(const void* d_src, uint32_t n, int arity, uint8_t* d_out
   else
     hipLaunchKernelGGL(k_fpc32_code<M_BALLOT>, dim3(p.S), dim3(threads), (size_t)arity * LDSW_C * 4 + 16, st,
                        src, n, arity, p.L, p.S, inc, slots, p.slot_stride, p.segcap, segbytes, prio_mode);
-  hipLaunchKernelGGL(k_fpc32_offsets, dim3(arity), dim3(1024), 0, st, segbytes, p.S, arity, segoff, d_sizes, nrec, (uint32_t*)(d_ws + p.off_diag + 256));
+  hipLaunchKernelGGL(k_fpc32_offsets, dim3(arity), dim3(1024), 0, st, segbytes, p.S, arity, segoff, d_sizes, nrec, (uint32_t*)(d_ws + p.off_diag + 256), h_sizes);
   return hip_ok(hipGetLastError(), "fpc32 encode kernels") ? 1 : 0;
   }
 

@@ -20,8 +20,8 @@
 //                   value's residual).  Steps whose 64 values all continue their runs with an exact prediction - the x / y of a
 //                   grid, the flat parts of a scan - leave a constant 24- or 88-byte pattern with one LDS store and skip the
 //                   byte layout altogether.  At its end the wave publishes its tables (= what the segment leaves behind).
-//   k_fpc32_pscan_* incoming payload of every (segment, class) = the entry of the nearest earlier segment that wrote the class.
-//   k_fpc32_fixup   per record: residual, length and code from the incoming entry; the segment's final size.
+//   k_fpc32_scanfix incoming payload of every (segment, class) = the entry of the nearest earlier segment that wrote the class; then
+//                   per record: residual, length and code from the incoming entry; the segment's final size.
 //   k_fpc32_offsets (k_fpc32_encode.hip) exclusive scan of the segment sizes.
 //   k_fpc32_gather  slot -> final position: a plain copy for segments without records, else a pass through LDS that drops the
 //                   unused bytes of the reserved fields and ORs residuals and codes in.
@@ -1062,7 +1062,7 @@ __device__ __forceinline__ uint32_t sweep_end(Sweep& sw, uint8_t* __restrict__ s
 // The write-side guard (workgroups S .. S + G - 1 of the sweep): workgroup j codes the first GUARD_STEPS steps of a sampled segment
 // again - compiled step, run starts resolved with BALLOTS, nothing that depends on the order in which the LDS unit applies an
 // exchange - into a slot and a record list of its own.  The fix-up kernel compares them with what the sweep made of that segment
-// (k_fpc32_fixup, workgroups beyond S): same bytes, same records, or FLAG_ORDER.
+// (k_fpc32_scanfix, guard_compare): same bytes, same records, or FLAG_ORDER.
 struct GuardMeta { uint32_t seg, bytes, nrec, pad; };
 
 template <bool HOOK>
@@ -1111,9 +1111,12 @@ k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t 
               uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap, uint32_t* __restrict__ segbytes, uint32_t* __restrict__ rawbytes,
               uint32_t* __restrict__ nrec, uint32_t* __restrict__ recs, uint32_t sabotage, uint32_t seed,
               uint8_t* __restrict__ gslots, uint32_t* __restrict__ grecs, GuardMeta* __restrict__ gmeta, uint64_t* __restrict__ diag,
-              uint32_t rblocks)
+              uint32_t rblocks, uint64_t* __restrict__ agg, uint32_t agg_words)
   {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  // the ready words and counters of the scan that follows (k_fpc32_scanfix): a word per thread
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < agg_words; q += gridDim.x * blockDim.x)
+    agg[q] = 0ull;
   const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;      // (c in a scalar register)
   const uint32_t g = blockIdx.x;
 #ifdef TRICO_SWEEP_DIAG
@@ -1243,119 +1246,138 @@ k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t 
 #endif
   }
 
-// ---- cross-segment scan: incoming payload of (segment, class) = the published entry of the nearest earlier segment that wrote
-// the class, else 0 (the reference's zeroed tables, fpsc.c:104-105) -------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_fpc32_pscan_a(const uint32_t* __restrict__ outT, uint32_t S, int arity, uint32_t* __restrict__ chlast)
-  {
-  const uint32_t col = blockIdx.x * 256u + threadIdx.x;      // (component, class)
-  const uint32_t ncol = (uint32_t)arity * TAB;
-  if (col >= ncol)
-    return;
-  const uint32_t c = col / TAB, k = col % TAB;
-  const uint32_t g0 = blockIdx.y * CH, g1 = (g0 + CH < S) ? g0 + CH : S;
-  uint32_t last = SENT;
-#pragma unroll 8
-  for (uint32_t g = g0; g < g1; ++g)
-    {
-    const uint32_t t = outT[((size_t)g * arity + c) * ROW + k];
-    last = t != SENT ? t : last;
-    }
-  chlast[(size_t)blockIdx.y * ncol + col] = last;
-  }
+// ---- cross-segment scan + the deferred values, ONE launch -------------------------------------------------------------------------
+// Incoming payload of (segment, class) = the published entry of the nearest earlier segment that wrote the class, else 0 (the
+// reference's zeroed tables, fpsc.c:104-105); then, per record of a deferred value: residual, length and code from the incoming entry
+// (fpsc.c:133-189 for one value; the record keeps them for the gather: w6 = residual, w7 = length | code << 4) and the segment's size
+// without the unused bytes of its reserved fields (rawbytes keeps what the slot holds).
+// Until round 6 these were three launches - k_fpc32_pscan_a (latest entry per chunk of CH segments), k_fpc32_pscan_b (the same rows
+// read again, the incoming rows written: 28 MB), k_fpc32_fixup (a wave per row, looking its classes up in those rows) - of 6 + 12 +
+// 20 us with ~4.6 us of nothing between two launches.  Now ONE workgroup of 1024 threads owns (chunk y, component c): thread k reads
+// column k of the chunk's CH rows, leaves for every row "the latest entry written earlier IN THIS CHUNK, else SENT" in LDS (CH x 1040
+// words: 133 KB), publishes the chunk's latest as one 64-bit word "ready | entry" (an agent-scope store: a word that carries its own
+// flag needs no fence), takes the words of the chunks before it as they appear (what comes into the chunk: a 1040-word row of LDS),
+// and then the workgroup's waves take the chunk's rows, a wave per row: a look-up is an LDS read, and SENT there means "what came
+// into the chunk".  The incoming rows never exist in memory.  The sweep zeroes the ready words.  Workgroups are dispatched in the
+// order of their index and a workgroup waits only for lower indices: no wait needs a workgroup the device has not started.  The
+// waits are bounded all the same (SPIN_MAX polls): FLAG_SCAN sends the stream to the two-sweep coder.
+// The write-side guard's comparison rides along: what guard workgroup j of the sweep coded with ballots (guard_segment) against what
+// the sweep left for that segment - the bytes, the number of records up to there and the records themselves (the words the sweep
+// wrote).  A difference raises FLAG_ORDER for the component (it travels with the segment's record count to k_fpc32_offsets and the
+// host).  The LAST workgroups do it, between publishing and looking back: they have the longest wait in front of them.
+constexpr uint64_t AGG_READY = 1ull << 32;
+constexpr uint32_t SPIN_MAX = 1u << 21;             // x (a round of loads + s_sleep 2): seconds
+constexpr int LOOKB_NEAR = 8, LOOKB_FAR = 24;       // words of earlier chunks in flight per thread: first round, later rounds
+constexpr uint32_t SF_THREADS = 1024;
+constexpr uint32_t SF_LDS_WORDS = (uint32_t)CH * TAB + TAB + CH;
+static_assert(TAB - 1024 == 16 && SF_LDS_WORDS * 4u <= 160u * 1024u, "thread k: DFCM... column k, the first 16 threads one more; LDS of a compute unit");
 
-__global__ void __launch_bounds__(256) k_fpc32_pscan_b(const uint32_t* __restrict__ outT, uint32_t S, int arity,
-                                                       const uint32_t* __restrict__ chlast, uint32_t* __restrict__ inc)
-  {
-  const uint32_t col = blockIdx.x * 256u + threadIdx.x;
-  const uint32_t ncol = (uint32_t)arity * TAB;
-  if (col >= ncol)
-    return;
-  const uint32_t c = col / TAB, k = col % TAB;
-  uint32_t carry = 0;
-#pragma unroll 8
-  for (uint32_t j = 0; j < blockIdx.y; ++j)
-    {
-    const uint32_t t = chlast[(size_t)j * ncol + col];
-    carry = t != SENT ? t : carry;
-    }
-  const uint32_t g0 = blockIdx.y * CH, g1 = (g0 + CH < S) ? g0 + CH : S;
-#pragma unroll 8
-  for (uint32_t g = g0; g < g1; ++g)
-    {
-    const size_t r = ((size_t)g * arity + c) * ROW + k;
-    const uint32_t t = outT[r];
-    inc[r] = carry;
-    carry = t != SENT ? t : carry;
-    }
-  }
+__device__ __forceinline__ uint64_t agg_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// ---- the deferred values: residual, length and code from the incoming entries (fpsc.c:133-189 for one value) -----------------
-// One workgroup per (segment, component) with records (what a thread does is a chain of three memory round trips: the more threads, the better).  The record keeps the result for the gather (w6 = residual, w7 = length |
-// code << 4); the segment's size loses the unused bytes of its reserved fields (rawbytes keeps what the slot holds).
-// Workgroups S .. S + G - 1 are the second half of the write-side guard: what guard workgroup j coded with ballots (guard_segment)
-// against what the sweep left for that segment - the bytes, the number of records up to there and the records themselves.  A
-// difference raises FLAG_ORDER for the component (it travels with the segment's record count to k_fpc32_offsets and the host).
-// what one workgroup of k_fpc32_fixup does for its (segment or guard row, component)
-__device__ __forceinline__ void fixup_rows(int arity, uint32_t S, const uint32_t* __restrict__ inc, uint32_t* __restrict__ segbytes,
-                                           uint32_t* __restrict__ rawbytes, uint32_t* __restrict__ nrec, uint32_t* __restrict__ recs,
-                                           const uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap,
-                                           const uint8_t* __restrict__ gslots, const uint32_t* __restrict__ grecs,
-                                           const GuardMeta* __restrict__ gmeta, uint32_t g, uint32_t c, uint32_t lane,
-                                           uint32_t* __restrict__ part)
+// What comes into chunk y for column k of component c: the latest entry of the chunks before it, else 0.  Backwards: the LOOKB_NEAR
+// chunks next to mine first - the common classes are written in every chunk, and a wave all of whose lanes have met a writer is done
+// (benchmark mesh: most waves) - then the rest LOOKB_FAR at a time.  (A round trip of such a load is ~2 us, no cache may serve it, and
+// all words of all columns would be 65 MB of them.)
+template <int B>
+__device__ __forceinline__ void look_back_round(const uint64_t* __restrict__ agg, uint32_t j1, uint32_t arity, uint32_t c, uint32_t k,
+                                                uint32_t& carry, bool& found, bool& late)
   {
-  if (g >= S)
+  uint64_t w[B];
+  uint32_t polls = 0;
+  for (;;)
     {
-    const size_t row = (size_t)(g - S) * arity + c;
-    const GuardMeta m = gmeta[row];
-    const size_t rowi = (size_t)m.seg * arity + c;
-    const uint32_t* mine = (const uint32_t*)(slots + (size_t)c * slot_stride + (size_t)m.seg * segcap);
-    const uint32_t* theirs = (const uint32_t*)(gslots + row * GUARD_CAP);
-    const uint32_t H = nrec[rowi] & 0xffffu;
-    bool diff = H < m.nrec || rawbytes[(size_t)c * S + m.seg] < m.bytes;      // (rawbytes: the segment's own workgroup may be changing segbytes right now)
-    // (differences are ORed together, not tested one by one: the loads of all rounds are then independent of each other - with
-    // `diff = diff || ...` the up to 18 rounds of a workgroup were 18 dependent pairs of round trips, the tail of the whole kernel)
-    uint32_t acc = 0;
-    const uint32_t nw = (m.bytes + 3u) >> 2;
-#pragma unroll 4
-    for (uint32_t t = lane; t < nw; t += 256u)
+    bool ok = true;
+#pragma unroll
+    for (uint32_t q = 0; q < (uint32_t)B; ++q)
       {
-      const uint32_t keep = 4u * t + 4u <= m.bytes ? 0xffffffffu : (1u << (8u * (m.bytes & 3u))) - 1u;
-      acc |= (mine[t] ^ theirs[t]) & keep;
+      w[q] = q < j1 ? agg_load(&agg[((size_t)(j1 - 1u - q) * arity + c) * TAB + k]) : (AGG_READY | SENT);      // chunk j1 - 1 first
+      ok = ok && (w[q] >> 32) != 0ull;
       }
-    const uint32_t* ra = recs + rowi * RCAP * RECW, * rb = grecs + row * RCAP * RECW;
-    const uint32_t ncmp = H < m.nrec ? 0u : REC_CMPW * m.nrec;
-#pragma unroll 4
-    for (uint32_t t = lane; t < ncmp; t += 256u)
-      acc |= ra[RECW * (t / REC_CMPW) + t % REC_CMPW] ^ rb[RECW * (t / REC_CMPW) + t % REC_CMPW];
-    diff = diff || acc != 0u;
-    if (lane == 0 && H > m.nrec)
-      diff = diff || (ra[RECW * m.nrec] & REC_POS) < m.bytes;      // a record of the sweep inside the compared bytes that the guard does not have
-    if (diff)
-      atomicOr(&nrec[rowi], FLAG_ORDER << 16);
-    return;
+    if (ok)
+      break;
+    if (++polls > SPIN_MAX)
+      {
+      late = true;
+      break;
+      }
+    __builtin_amdgcn_s_sleep(2);
     }
-  (void)part;
+#pragma unroll
+  for (uint32_t q = 0; q < (uint32_t)B; ++q)
+    {
+    const uint32_t v = (uint32_t)w[q];
+    if (!found && v != SENT)
+      {
+      carry = v;
+      found = true;
+      }
+    }
   }
 
-// The deferred values of ONE (segment, component) row, by one wave.  What a record needs is three dependent memory round trips -
-// its words, the incoming entry of its class, the store of the result - and nothing else, so a lane takes up to FIX_B records at
-// once: their loads are issued together, then their look-ups, then their stores.  (Round 5 gave every row a workgroup of 256
-// threads: 6,800 workgroups in four rounds of ~5 us on the device, 26 us, for what is three round trips.)
-constexpr uint32_t FIX_B = 8;
-__device__ __forceinline__ void fixup_row_wave(const uint32_t* __restrict__ inc, uint32_t* __restrict__ segbytes, const uint32_t* __restrict__ rawbytes,
-                                               const uint32_t* __restrict__ nrec, uint32_t* __restrict__ recs, uint32_t S, uint32_t arity,
-                                               uint32_t rowi, uint32_t lane)
+__device__ __forceinline__ uint32_t look_back(const uint64_t* __restrict__ agg, uint32_t y, uint32_t arity, uint32_t c, uint32_t k, bool& late)
   {
+  uint32_t carry = 0;
+  bool found = false;
+  if (y == 0u)
+    return 0u;
+  look_back_round<LOOKB_NEAR>(agg, y, arity, c, k, carry, found, late);
+  for (uint32_t j1 = y > (uint32_t)LOOKB_NEAR ? y - (uint32_t)LOOKB_NEAR : 0u; j1 > 0u && __ballot(!found) != 0ull;
+       j1 = j1 > (uint32_t)LOOKB_FAR ? j1 - (uint32_t)LOOKB_FAR : 0u)
+    look_back_round<LOOKB_FAR>(agg, j1, arity, c, k, carry, found, late);
+  return carry;
+  }
+
+// one (guard row, component) by the first 256 threads of a workgroup
+__device__ __forceinline__ void guard_compare(int arity, uint32_t S, const uint32_t* __restrict__ rawbytes, uint32_t* __restrict__ nrec,
+                                              const uint32_t* __restrict__ recs, const uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap,
+                                              const uint8_t* __restrict__ gslots, const uint32_t* __restrict__ grecs,
+                                              const GuardMeta* __restrict__ gmeta, uint32_t j, uint32_t c, uint32_t lane)
+  {
+  const size_t row = (size_t)j * arity + c;
+  const GuardMeta m = gmeta[row];
+  const size_t rowi = (size_t)m.seg * arity + c;
+  const uint32_t* mine = (const uint32_t*)(slots + (size_t)c * slot_stride + (size_t)m.seg * segcap);
+  const uint32_t* theirs = (const uint32_t*)(gslots + row * GUARD_CAP);
   const uint32_t H = nrec[rowi] & 0xffffu;
+  bool diff = H < m.nrec || rawbytes[(size_t)c * S + m.seg] < m.bytes;
+  // (differences are ORed together, not tested one by one: the loads of all rounds are then independent of each other - with
+  // `diff = diff || ...` the up to 18 rounds of a workgroup were 18 dependent pairs of round trips)
+  uint32_t acc = 0;
+  const uint32_t nw = (m.bytes + 3u) >> 2;
+#pragma unroll 4
+  for (uint32_t t = lane; t < nw; t += 256u)
+    {
+    const uint32_t keep = 4u * t + 4u <= m.bytes ? 0xffffffffu : (1u << (8u * (m.bytes & 3u))) - 1u;
+    acc |= (mine[t] ^ theirs[t]) & keep;
+    }
+  const uint32_t* ra = recs + rowi * RCAP * RECW, * rb = grecs + row * RCAP * RECW;
+  const uint32_t ncmp = H < m.nrec ? 0u : REC_CMPW * m.nrec;
+#pragma unroll 4
+  for (uint32_t t = lane; t < ncmp; t += 256u)
+    acc |= ra[RECW * (t / REC_CMPW) + t % REC_CMPW] ^ rb[RECW * (t / REC_CMPW) + t % REC_CMPW];
+  diff = diff || acc != 0u;
+  if (lane == 0 && H > m.nrec)
+    diff = diff || (ra[RECW * m.nrec] & REC_POS) < m.bytes;      // a record of the sweep inside the compared bytes that the guard does not have
+  if (diff)
+    atomicOr(&nrec[rowi], FLAG_ORDER << 16);
+  }
+
+// The deferred values of ONE (segment, component) row, by one wave.  What a record needs is its words, the incoming entry of its
+// class (LDS: `local` = the row of entries written earlier in the chunk, `cin` = what came into the chunk), the store of the result,
+// and nothing else, so a lane takes up to FIX_B records at once: their loads are issued together, then their stores.
+constexpr uint32_t FIX_B = 8;
+__device__ __forceinline__ void fixup_row_wave(const uint32_t* __restrict__ local, const uint32_t* __restrict__ cin, uint32_t H,
+                                               uint32_t* __restrict__ segbytes, const uint32_t* __restrict__ rawbytes,
+                                               uint32_t* __restrict__ recs, uint32_t S, uint32_t arity, uint32_t rowi, uint32_t lane)
+  {
   if (H == 0u)
     return;
   uint32_t* list = recs + (size_t)rowi * RCAP * RECW;
-  const uint32_t* row = inc + (size_t)rowi * ROW;            // the segment's incoming tables
   uint32_t unused = 0;
   for (uint32_t base = 0; base < H; base += 64u * FIX_B)
     {
     u32x4 w[FIX_B];
-    uint32_t known[FIX_B], k2w[FIX_B], p1[FIX_B], p2[FIX_B];
+    uint32_t known[FIX_B], k2w[FIX_B];
 #pragma unroll
     for (uint32_t i = 0; i < FIX_B; ++i)
       {
@@ -1374,24 +1396,25 @@ __device__ __forceinline__ void fixup_row_wave(const uint32_t* __restrict__ inc,
     for (uint32_t i = 0; i < FIX_B; ++i)
       {
       const uint32_t j = base + 64u * i + lane;
-      const bool ft1 = (w[i][0] & REC_FT1) != 0u, ft2 = (w[i][0] & REC_FT2) != 0u;
-      p1[i] = known[i];
-      p2[i] = known[i];
       if (j < H)
         {
+        const bool ft1 = (w[i][0] & REC_FT1) != 0u, ft2 = (w[i][0] & REC_FT2) != 0u;
+        uint32_t p1 = known[i], p2 = known[i];
         // (fpsc.c:96-97: the FCM class is the predecessor's top four bits)
-        if (ft1) p1[i] = row[w[i][3] >> 28];
-        if (ft2) p2[i] = row[16u + (k2w[i] >> 2)];
-        }
-      }
-#pragma unroll
-    for (uint32_t i = 0; i < FIX_B; ++i)
-      {
-      const uint32_t j = base + 64u * i + lane;
-      if (j < H)
-        {
+        if (ft1)
+          {
+          const uint32_t k = w[i][3] >> 28;
+          p1 = local[k];
+          p1 = p1 == SENT ? cin[k] : p1;
+          }
+        if (ft2)
+          {
+          const uint32_t k = 16u + (k2w[i] >> 2);
+          p2 = local[k];
+          p2 = p2 == SENT ? cin[k] : p2;
+          }
         const uint32_t v = w[i][2], a = w[i][3];
-        const uint32_t x1 = v ^ p1[i], x2 = v ^ (a + p2[i]);
+        const uint32_t x1 = v ^ p1, x2 = v ^ (a + p2);
         const uint32_t n1 = (39u - (uint32_t)__clz((int)x1)) >> 3;
         const uint32_t n2 = (39u - (uint32_t)__clz((int)(x2 | 1u))) >> 3;
         const bool use2 = n2 < n1;
@@ -1409,26 +1432,90 @@ __device__ __forceinline__ void fixup_row_wave(const uint32_t* __restrict__ inc,
     }
   }
 
-__global__ void __launch_bounds__(256) k_fpc32_fixup(int arity, uint32_t S, const uint32_t* __restrict__ inc, uint32_t* __restrict__ segbytes,
-                                                     uint32_t* __restrict__ rawbytes, uint32_t* __restrict__ nrec, uint32_t* __restrict__ recs,
-                                                     const uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap,
-                                                     const uint8_t* __restrict__ gslots, const uint32_t* __restrict__ grecs,
-                                                     const GuardMeta* __restrict__ gmeta, uint32_t row_blocks)
+__global__ void __launch_bounds__(1024) k_fpc32_scanfix(const uint32_t* __restrict__ outT, uint32_t S, int arity, uint32_t nch,
+                                                        uint64_t* __restrict__ agg, uint32_t* __restrict__ segbytes,
+                                                        const uint32_t* __restrict__ rawbytes, uint32_t* __restrict__ nrec,
+                                                        uint32_t* __restrict__ recs, const uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap,
+                                                        const uint8_t* __restrict__ gslots, const uint32_t* __restrict__ grecs,
+                                                        const GuardMeta* __restrict__ gmeta, uint32_t guard_rows)
   {
-  // (The scan of the segment sizes stays a launch of its own, k_fpc32_offsets: done by "the workgroup that finishes last", the 7,700
-  // atomic increments of the counter that finds it took 0.4 ms - they are served one after the other.)
-  // Workgroups [0, row_blocks): four rows each, a wave per row.  Behind them one workgroup per (guard row, component).
-  __shared__ uint32_t part[4];
-  if (blockIdx.x < row_blocks)
+  extern __shared__ __attribute__((aligned(16))) uint32_t sf_lds[];
+  uint32_t* M = sf_lds;                              // [CH][TAB]: entries written earlier in the chunk
+  uint32_t* cin = sf_lds + (uint32_t)CH * TAB;       // [TAB]: what comes into the chunk
+  uint32_t* Hs = cin + TAB;                          // [CH]: records of the chunk's rows
+  const uint32_t y = blockIdx.x / (uint32_t)arity, c = blockIdx.x - y * (uint32_t)arity;
+  const uint32_t tid = threadIdx.x;
+  const bool two = tid < (uint32_t)TAB - SF_THREADS;                 // the first sixteen threads: a second column
+  const uint32_t k0 = tid, k1 = two ? SF_THREADS + tid : k0;
+  const uint32_t g0 = y * CH, cnt = (S - g0 < (uint32_t)CH) ? S - g0 : (uint32_t)CH;
+  if (tid < (uint32_t)CH)
+    Hs[tid] = tid < cnt ? nrec[(size_t)(g0 + tid) * arity + c] & 0xffffu : 0u;
+  uint32_t run0 = SENT, run1 = SENT;
+  {
+  uint32_t t0[CH], t1[CH];
+#pragma unroll
+  for (uint32_t i = 0; i < (uint32_t)CH; ++i)
     {
-    const uint32_t rowi = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (rowi < S * (uint32_t)arity)
-      fixup_row_wave(inc, segbytes, rawbytes, nrec, recs, S, (uint32_t)arity, rowi, threadIdx.x & 63u);
-    return;
+    const uint32_t* row = outT + ((size_t)(g0 + i) * arity + c) * ROW;
+    t0[i] = i < cnt ? row[k0] : SENT;
+    t1[i] = (two && i < cnt) ? row[k1] : SENT;
     }
-  const uint32_t q = blockIdx.x - row_blocks;
-  const uint32_t g = S + q / (uint32_t)arity, c = q % (uint32_t)arity, lane = threadIdx.x;
-  fixup_rows(arity, S, inc, segbytes, rawbytes, nrec, recs, slots, slot_stride, segcap, gslots, grecs, gmeta, g, c, lane, part);
+#pragma unroll
+  for (uint32_t i = 0; i < (uint32_t)CH; ++i)
+    {
+    M[i * (uint32_t)TAB + k0] = run0;
+    if (two)
+      M[i * (uint32_t)TAB + k1] = run1;
+    run0 = t0[i] != SENT ? t0[i] : run0;
+    run1 = t1[i] != SENT ? t1[i] : run1;
+    }
+  }
+  uint64_t* mine = agg + ((size_t)y * arity + c) * TAB;
+  __hip_atomic_store(&mine[k0], AGG_READY | run0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (two)
+    __hip_atomic_store(&mine[k1], AGG_READY | run1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // the guard's rows: the last workgroups of the grid
+#ifndef SF_NO_GUARD
+  if (tid < 256u)
+    for (uint32_t q = gridDim.x - 1u - blockIdx.x; q < guard_rows; q += gridDim.x)
+      guard_compare(arity, S, rawbytes, nrec, recs, slots, slot_stride, segcap, gslots, grecs, gmeta, q / (uint32_t)arity, q % (uint32_t)arity, tid);
+#endif
+  // the chunks before mine (the second column: the first wave only)
+  bool late = false;
+#ifdef SF_NO_LOOK
+  const uint32_t carry0 = 0;
+#else
+  const uint32_t carry0 = look_back(agg, y, (uint32_t)arity, c, k0, late);
+#endif
+  uint32_t carry1 = 0;
+  if (two)
+    carry1 = look_back(agg, y, (uint32_t)arity, c, k1, late);
+  if (late)
+    atomicOr(&nrec[c], FLAG_SCAN << 16);                   // (row 0 of the component: k_fpc32_offsets collects the flags per component)
+  cin[k0] = carry0;
+  if (two)
+    cin[k1] = carry1;
+  __syncthreads();
+#ifndef SF_NO_FIX
+  for (uint32_t r = tid >> 6; r < cnt; r += SF_THREADS / 64u)
+    fixup_row_wave(M + r * (uint32_t)TAB, cin, Hs[r], segbytes, rawbytes, recs, S, (uint32_t)arity, (g0 + r) * (uint32_t)arity + c, tid & 63u);
+#endif
+  }
+
+// the scan kernel's LDS is beyond the 64 KiB a kernel gets without asking: claimed once per device of the process
+static bool scanfix_lds_claimed()
+  {
+  static std::atomic<int> state[16];             // 0 not asked, 1 claimed, 2 refused
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16)
+    return hipFuncSetAttribute((const void*)k_fpc32_scanfix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SF_LDS_WORDS * 4u)) == hipSuccess;
+  int st = state[dev].load();
+  if (st == 0)
+    {
+    st = hipFuncSetAttribute((const void*)k_fpc32_scanfix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SF_LDS_WORDS * 4u)) == hipSuccess ? 1 : 2;
+    state[dev].store(st);
+    }
+  return st == 1;
   }
 
 // ---- gather: segment slots -> contiguous payload ----------------------------------------------------------------------------
@@ -1919,8 +2006,7 @@ int launch_fpc32_sweep(const uint32_t* d_src, uint32_t n, int arity, const Plan&
   {
   hipStream_t st = current_stream();
   uint32_t* outT = (uint32_t*)(d_ws + p.off_summ);
-  uint32_t* inc = (uint32_t*)(d_ws + p.off_inc);
-  uint32_t* chlast = (uint32_t*)(d_ws + p.off_chmax);
+  uint64_t* agg = (uint64_t*)(d_ws + p.off_agg);
   uint32_t* segbytes = (uint32_t*)(d_ws + p.off_segbytes);
   uint32_t* rawbytes = (uint32_t*)(d_ws + p.off_rawbytes);
   uint32_t* nrec = (uint32_t*)(d_ws + p.off_nrec);
@@ -1951,10 +2037,10 @@ int launch_fpc32_sweep(const uint32_t* d_src, uint32_t n, int arity, const Plan&
   constexpr bool HOOK = SWEEP_HOOK;
   if (use_asm)
     hipLaunchKernelGGL((k_fpc32_sweep<HOOK, true>), dim3(p.S + G), dim3(threads), lds, st, d_src, n, arity, p.L, p.sg, p.S, outT,
-                       slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, sabotage, seed, gslots, grecs, gmeta, diag, rblocks);
+                       slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, sabotage, seed, gslots, grecs, gmeta, diag, rblocks, agg, (uint32_t)p.agg_words);
   else
     hipLaunchKernelGGL((k_fpc32_sweep<HOOK, false>), dim3(p.S + G), dim3(threads), lds, st, d_src, n, arity, p.L, p.sg, p.S, outT,
-                       slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, sabotage, seed, gslots, grecs, gmeta, diag, rblocks);
+                       slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, sabotage, seed, gslots, grecs, gmeta, diag, rblocks, agg, (uint32_t)p.agg_words);
 #ifdef TRICO_SWEEP_DIAG
   {
   // diagnostic build: clocks of the wave of segment S / 2 of every component, printed per launch; every wave's timeline to a file
@@ -1977,12 +2063,13 @@ int launch_fpc32_sweep(const uint32_t* d_src, uint32_t n, int arity, const Plan&
     }
   }
 #endif
-  const unsigned colblocks = ((unsigned)arity * TAB + 255u) / 256u;
-  hipLaunchKernelGGL(k_fpc32_pscan_a, dim3(colblocks, p.nch), dim3(256), 0, st, outT, p.S, arity, chlast);
-  hipLaunchKernelGGL(k_fpc32_pscan_b, dim3(colblocks, p.nch), dim3(256), 0, st, outT, p.S, arity, chlast, inc);
-  const unsigned row_blocks = (p.S * (unsigned)arity + 3u) / 4u;
-  hipLaunchKernelGGL(k_fpc32_fixup, dim3(row_blocks + G * (unsigned)arity), dim3(256), 0, st, arity, p.S, inc, segbytes, rawbytes, nrec, recs,
-                     slots, p.slot_stride, p.segcap, gslots, grecs, gmeta, row_blocks);
+  if (!scanfix_lds_claimed())
+    {
+    set_error("float encoder: cannot claim 135 KiB of LDS for the scan");
+    return 0;
+    }
+  hipLaunchKernelGGL(k_fpc32_scanfix, dim3(p.nch * (unsigned)arity), dim3(SF_THREADS), SF_LDS_WORDS * 4u, st, outT, p.S, arity, p.nch, agg,
+                     segbytes, rawbytes, nrec, recs, slots, p.slot_stride, p.segcap, gslots, grecs, gmeta, G * (unsigned)arity);
   return hip_ok(hipGetLastError(), "fpc32 encode kernels (sweep)") ? 1 : 0;
   }
 

@@ -146,10 +146,13 @@ ProfSpan::ProfSpan(int kernel_id, bool count_launch) : k(kernel_id), active(fals
   (void)hipEventRecord(e0, current_stream());
   }
 
-ProfSpan::~ProfSpan()
+ProfSpan::~ProfSpan() { stop(); }
+
+void ProfSpan::stop()
   {
   if (!active)
     return;
+  active = false;
   (void)hipEventRecord(e1, current_stream());
   if (g_prof_n == g_prof_cap)
     {
@@ -221,6 +224,15 @@ const void* stage_in(DevBuf& buf, const void* src, size_t bytes, size_t offset)
   if (!upload_bytes(buf.p + offset, src, bytes, current_stream()))
     return nullptr;
   return buf.p + offset;
+  }
+
+// the six words k_fpc32_offsets mirrored into the pinned buffer (launch_fpc32_encode's h_sizes)
+constexpr int MIRROR_AT = 32;
+static int read_mirrored_sizes(trico_hip_ctx* ctx, uint32_t six[6])
+  {
+  TRICO_HIP_TRY(hipStreamSynchronize(current_stream()));
+  memcpy(six, ctx->h_pinned + MIRROR_AT, 6 * sizeof(uint32_t));
+  return 1;
   }
 
 static int read_back_words(trico_hip_ctx* ctx, const uint32_t* d_words, int count, uint32_t* host)
@@ -518,8 +530,9 @@ int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int
     const size_t ws = fpc32_encode_workspace(n, arity);
     if (!ctx->tmp.reserve(ws))
       return 0;
-    if (!launch_fpc32_encode(d_src, n, arity, ctx->out.p, stride, d_sizes, ctx->tmp.p, ctx->tmp.cap))
+    if (!launch_fpc32_encode(d_src, n, arity, ctx->out.p, stride, d_sizes, ctx->tmp.p, ctx->tmp.cap, FPC32_CODER_AUTO, ctx->h_pinned + MIRROR_AT))
       return 0;
+    span.stop();                    // (the kernels, not the host's wait for them)
     ctx->out_in_slots = n != 0;
     ctx->slots_n = n;
     ctx->slots_arity = arity;
@@ -549,7 +562,7 @@ int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int
     // order, or a payload equal to the coder's "never written" mark.  Raised, the payloads are not to be trusted: the stream is
     // coded again by the two-sweep coder with ballots, which depends on neither; a device that showed the first is not asked again.
     uint32_t six[6] = { 0, 0, 0, 0, 0, 0 };
-    if (!read_back_words(ctx, d_sizes, 6, six))
+    if (!read_mirrored_sizes(ctx, six))
       return 0;
     uint32_t raised = 0;
     for (int c = 0; c < arity; ++c)
@@ -573,8 +586,8 @@ int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int
       if (raised & FPC32_FLAG_SENTINEL)
         g_recoded_sentinel += 1;
       if (getenv("TRICO_HIP_DEBUG"))
-        fprintf(stderr, "trico_hip: float encoder flags 0x%x (1: LDS exchange out of lane order, 2: payload equals the table mark); "
-                        "coding the stream again with the ballot coder\n", raised);
+        fprintf(stderr, "trico_hip: float encoder flags 0x%x (1: LDS exchange out of lane order, 2: payload equals the table mark, "
+                        "4: a wait in the scan kernel ran out); coding the stream again with the ballot coder\n", raised);
       raised = 0;
       if (!launch_fpc32_encode(d_src, n, arity, ctx->out.p, stride, d_sizes, ctx->tmp.p, ctx->tmp.cap, FPC32_CODER_BALLOT) ||
           !read_back_words(ctx, d_sizes, 6, six))
