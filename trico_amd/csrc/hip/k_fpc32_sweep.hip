@@ -514,7 +514,7 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   "v_lshrrev_b32 %[t3], 26, v61\n" \
   "v_and_or_b32 %[a1p], %[t3], 60, %[t1s]\n"                         /* FCM entry: table + 4 * (top four bits of v[i-1]) */ \
   "v_mov_b32_dpp %[s1p], %[sp] wave_shr:1" SW_DPPF                   /* stride of v[i-1] */ \
-  "s_waitcnt lgkmcnt(0)\n"                                           /* the staging words read at the end of the step before (also a wait state of the next move) */ \
+  "s_nop 0\n" \
   "v_mov_b32_dpp %[t1], %[a1p] wave_shr:1" SW_DPPF \
   "v_lshrrev_b32 %[t4], 22, %[s1p]\n" \
   "v_mov_b32_dpp %[t0], %[s1p] wave_shr:1" SW_DPPF                   /* stride of v[i-2] */ \
@@ -523,13 +523,10 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   "v_bitop3_b32 %[t3], %[t3], %[t4], %[k3e0] bitop3:0x6c\n"          /* ((s2 >> 17) & 0x3e0) ^ (s1 >> 22): the DFCM class */ \
   "v_lshl_add_u32 %[a2p], %[t3], 2, %[t2s]\n" \
   "s_lshr_b64 vcc, %[st1], 1\n"                                      /* a run ends where the next lane starts one ... */ \
-  "s_cmp_lg_u32 %[pend], 0\n" \
+  "s_bitset1_b32 vcc_hi, 31\n"                                       /* (... lane 63 always; also the second wait state of the move below) */ \
   "v_mov_b32_dpp %[t2v], %[a2p] wave_shr:1" SW_DPPF \
   "v_cmp_ne_u32_e64 %[st2], %[a2p], %[t2v]\n" \
-  "s_cselect_b64 exec, -1, 0\n" \
-  SW_FLUSH_STORES \
-  /* run starts: exchange by the lanes where a run starts or ends (... lane 63 always) */ \
-  "s_bitset1_b32 vcc_hi, 31\n" \
+  /* run starts: exchange by the lanes where a run starts or ends */ \
   "s_or_b64 exec, vcc, %[st1]\n" \
   "ds_wrxchg_rtn_b32 %[t1], %[a1p], " V "\n" \
   "v_cmp_eq_u32_e32 vcc, %[ksent], " V "\n" \
@@ -539,9 +536,12 @@ __device__ __forceinline__ uint64_t uni(uint64_t x) { return ((uint64_t)uni((uin
   "s_or_b64 exec, vcc, %[st2]\n" \
   "ds_wrxchg_rtn_b32 %[t2v], %[a2p], %[sp]\n" \
   "v_cmp_eq_u32_e32 vcc, %[ksent], %[sp]\n" \
-  "s_mov_b64 exec, -1\n" \
   "s_or_b64 %[sent], %[sent], vcc\n" \
-  "s_waitcnt lgkmcnt(0)\n" \
+  "s_cmp_lg_u32 %[pend], 0\n" \
+  "s_cselect_b64 exec, -1, 0\n" \
+  "s_waitcnt lgkmcnt(0)\n"                                           /* ONE wait per step: the exchanges, and the staging words read at the end of the step before */ \
+  SW_FLUSH_STORES \
+  "s_mov_b64 exec, -1\n" \
   "v_cndmask_b32_e64 %[t1], v61, %[t1], %[st1]\n"                   /* FCM prediction: inside a run the previous value */ \
   "v_cndmask_b32_e64 %[t2v], %[s1p], %[t2v], %[st2]\n"               /* DFCM prediction: inside a run the previous stride */ \
   "v_cmp_eq_u32_e32 vcc, %[ksent], %[t1]\n" \
