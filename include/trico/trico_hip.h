@@ -232,6 +232,9 @@ TRICO_API int trico_hip_fpc32_code_sweep(void);
  * sampled step of the one-sweep coder found the LDS exchange out of lane order (the device is not asked again afterwards),
  * out[1] = because a value or stride equal to the coder's "never written" table mark was stored (2^-32 per value on random bits). */
 TRICO_API void trico_hip_encode_stats(uint32_t out[2]);
+/* ... and because a bounded wait between the workgroups of the encoder's scan kernel ran out (k_fpc32_scanfix; never seen outside the
+ * test that provokes it) */
+TRICO_API uint32_t trico_hip_encode_scan_recodes(void);
 /* Opt-in FULL verification of the float encoder (process-wide; -1 returns to what TRICO_HIP_ENCODE_VERIFY=1 says, default off).
  * Every float stream of the API's table sizes is coded a second time by the two-sweep coder with ballots and the payloads are
  * compared byte for byte on the device before the call returns (about +1 ms per 50 M vertices of device time, and the payload is

@@ -124,7 +124,8 @@ for kind, W, H in (("walk", 300, 77), ("grid", 256, 128), ("walk", 1000, 1000)):
     assert a.tobytes() == o.tobytes(), (kind, W, H)
     a.close(); o.close()
 after = stats()
-print("GUARD", after[0] - before[0], after[1] - before[1], L.trico_hip_fpc32_code_sweep())
+L.trico_hip_encode_scan_recodes.restype = ctypes.c_uint32
+print("GUARD", after[0] - before[0], after[1] - before[1], L.trico_hip_fpc32_code_sweep(), L.trico_hip_encode_scan_recodes())
 """
 
 
@@ -134,7 +135,9 @@ def _guard_child(env_add):
     env.update(env_add)
     out = subprocess.run([sys.executable, "-c", GUARD_CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "GUARD" in out.stdout, out.stdout + out.stderr
-    return [int(x) for x in out.stdout.split("GUARD")[1].split()[:3]]
+    vals = [int(x) for x in out.stdout.split("GUARD")[1].split()[:4]]
+    _guard_child.scan = vals[3]
+    return vals[:3]
 
 
 def test_write_side_guard_catches_an_exchange_out_of_lane_order():
@@ -148,7 +151,15 @@ def test_write_side_guard_catches_an_exchange_out_of_lane_order():
 
 def test_write_side_guard_is_quiet_without_sabotage():
     order, sentinel, mode = _guard_child({})
-    assert order == 0 and sentinel == 0 and mode == 3, (order, sentinel, mode)
+    assert order == 0 and sentinel == 0 and mode == 3 and _guard_child.scan == 0, (order, sentinel, mode, _guard_child.scan)
+
+
+def test_a_scan_workgroup_that_never_publishes_is_waited_for_with_a_bound():
+    """TRICO_HIP_ENCODE_SABOTAGE=2 (test-hooks library only): the first workgroup of k_fpc32_scanfix keeps the word the chunks behind it
+    wait for.  Their waits run out (512 polls under the hook, 2^21 in the product), FLAG_SCAN reaches the host, the streams with more
+    than one chunk are coded again by the two-sweep coder, the device stays trusted - and every archive is still the reference's."""
+    order, sentinel, mode = _guard_child({"TRICO_HIP_ENCODE_SABOTAGE": "2"})
+    assert order == 0 and sentinel == 0 and mode == 3 and _guard_child.scan >= 1, (order, sentinel, mode, _guard_child.scan)
 
 
 def test_product_library_has_no_encode_sabotage_switch():

@@ -35,6 +35,13 @@ namespace fpc32 {
 
 namespace {
 
+// (sabotage switches for the tests exist in libtrico_testhooks.so only)
+#ifdef TRICO_HIP_TEST_HOOKS
+constexpr bool SWEEP_HOOK = true;
+#else
+constexpr bool SWEEP_HOOK = false;
+#endif
+
 constexpr int FLB = 512;                          // the staging area leaves in blocks of this many bytes (8 per lane)
 constexpr int STAGE_LIVE = FLB + 280;             // < 512 unflushed + <= 280 of the step
 constexpr int STAGE = STAGE_LIVE + 256;           // + 4 dump bytes per lane (compiled step only)
@@ -1280,7 +1287,7 @@ __device__ __forceinline__ uint64_t agg_load(const uint64_t* p) { return __hip_a
 // all words of all columns would be 65 MB of them.)
 template <int B>
 __device__ __forceinline__ void look_back_round(const uint64_t* __restrict__ agg, uint32_t j1, uint32_t arity, uint32_t c, uint32_t k,
-                                                uint32_t& carry, bool& found, bool& late)
+                                                uint32_t& carry, bool& found, bool& late, uint32_t spin_max)
   {
   uint64_t w[B];
   uint32_t polls = 0;
@@ -1295,7 +1302,7 @@ __device__ __forceinline__ void look_back_round(const uint64_t* __restrict__ agg
       }
     if (ok)
       break;
-    if (++polls > SPIN_MAX)
+    if (++polls > spin_max)
       {
       late = true;
       break;
@@ -1314,16 +1321,16 @@ __device__ __forceinline__ void look_back_round(const uint64_t* __restrict__ agg
     }
   }
 
-__device__ __forceinline__ uint32_t look_back(const uint64_t* __restrict__ agg, uint32_t y, uint32_t arity, uint32_t c, uint32_t k, bool& late)
+__device__ __forceinline__ uint32_t look_back(const uint64_t* __restrict__ agg, uint32_t y, uint32_t arity, uint32_t c, uint32_t k, bool& late, uint32_t spin_max)
   {
   uint32_t carry = 0;
   bool found = false;
   if (y == 0u)
     return 0u;
-  look_back_round<LOOKB_NEAR>(agg, y, arity, c, k, carry, found, late);
+  look_back_round<LOOKB_NEAR>(agg, y, arity, c, k, carry, found, late, spin_max);
   for (uint32_t j1 = y > (uint32_t)LOOKB_NEAR ? y - (uint32_t)LOOKB_NEAR : 0u; j1 > 0u && __ballot(!found) != 0ull;
        j1 = j1 > (uint32_t)LOOKB_FAR ? j1 - (uint32_t)LOOKB_FAR : 0u)
-    look_back_round<LOOKB_FAR>(agg, j1, arity, c, k, carry, found, late);
+    look_back_round<LOOKB_FAR>(agg, j1, arity, c, k, carry, found, late, spin_max);
   return carry;
   }
 
@@ -1432,12 +1439,13 @@ __device__ __forceinline__ void fixup_row_wave(const uint32_t* __restrict__ loca
     }
   }
 
+template <bool HOOK>
 __global__ void __launch_bounds__(1024) k_fpc32_scanfix(const uint32_t* __restrict__ outT, uint32_t S, int arity, uint32_t nch,
                                                         uint64_t* __restrict__ agg, uint32_t* __restrict__ segbytes,
                                                         const uint32_t* __restrict__ rawbytes, uint32_t* __restrict__ nrec,
                                                         uint32_t* __restrict__ recs, const uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap,
                                                         const uint8_t* __restrict__ gslots, const uint32_t* __restrict__ grecs,
-                                                        const GuardMeta* __restrict__ gmeta, uint32_t guard_rows)
+                                                        const GuardMeta* __restrict__ gmeta, uint32_t guard_rows, uint32_t sabotage)
   {
   extern __shared__ __attribute__((aligned(16))) uint32_t sf_lds[];
   uint32_t* M = sf_lds;                              // [CH][TAB]: entries written earlier in the chunk
@@ -1450,7 +1458,6 @@ __global__ void __launch_bounds__(1024) k_fpc32_scanfix(const uint32_t* __restri
   const uint32_t g0 = y * CH, cnt = (S - g0 < (uint32_t)CH) ? S - g0 : (uint32_t)CH;
   if (tid < (uint32_t)CH)
     Hs[tid] = tid < cnt ? nrec[(size_t)(g0 + tid) * arity + c] & 0xffffu : 0u;
-  uint32_t run0 = SENT, run1 = SENT;
   {
   uint32_t t0[CH], t1[CH];
 #pragma unroll
@@ -1460,6 +1467,24 @@ __global__ void __launch_bounds__(1024) k_fpc32_scanfix(const uint32_t* __restri
     t0[i] = i < cnt ? row[k0] : SENT;
     t1[i] = (two && i < cnt) ? row[k1] : SENT;
     }
+  // first what the others wait for: the chunk's latest entries
+  uint32_t last0 = SENT, last1 = SENT;
+#pragma unroll
+  for (uint32_t i = 0; i < (uint32_t)CH; ++i)
+    {
+    last0 = t0[i] != SENT ? t0[i] : last0;
+    last1 = t1[i] != SENT ? t1[i] : last1;
+    }
+  uint64_t* mine = agg + ((size_t)y * arity + c) * TAB;
+  // (test hook, libtrico_testhooks.so only: the first workgroup never publishes - everybody behind it in its component has to give up)
+  const bool mute = HOOK && (sabotage & 2u) != 0u && blockIdx.x == 0u;
+  if (!mute)
+    {
+    __hip_atomic_store(&mine[k0], AGG_READY | last0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (two)
+      __hip_atomic_store(&mine[k1], AGG_READY | last1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  uint32_t run0 = SENT, run1 = SENT;
 #pragma unroll
   for (uint32_t i = 0; i < (uint32_t)CH; ++i)
     {
@@ -1470,36 +1495,25 @@ __global__ void __launch_bounds__(1024) k_fpc32_scanfix(const uint32_t* __restri
     run1 = t1[i] != SENT ? t1[i] : run1;
     }
   }
-  uint64_t* mine = agg + ((size_t)y * arity + c) * TAB;
-  __hip_atomic_store(&mine[k0], AGG_READY | run0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (two)
-    __hip_atomic_store(&mine[k1], AGG_READY | run1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // the guard's rows: the last workgroups of the grid
-#ifndef SF_NO_GUARD
   if (tid < 256u)
     for (uint32_t q = gridDim.x - 1u - blockIdx.x; q < guard_rows; q += gridDim.x)
       guard_compare(arity, S, rawbytes, nrec, recs, slots, slot_stride, segcap, gslots, grecs, gmeta, q / (uint32_t)arity, q % (uint32_t)arity, tid);
-#endif
   // the chunks before mine (the second column: the first wave only)
   bool late = false;
-#ifdef SF_NO_LOOK
-  const uint32_t carry0 = 0;
-#else
-  const uint32_t carry0 = look_back(agg, y, (uint32_t)arity, c, k0, late);
-#endif
+  const uint32_t spin_max = (HOOK && (sabotage & 2u) != 0u) ? 512u : SPIN_MAX;
+  const uint32_t carry0 = look_back(agg, y, (uint32_t)arity, c, k0, late, spin_max);
   uint32_t carry1 = 0;
   if (two)
-    carry1 = look_back(agg, y, (uint32_t)arity, c, k1, late);
+    carry1 = look_back(agg, y, (uint32_t)arity, c, k1, late, spin_max);
   if (late)
     atomicOr(&nrec[c], FLAG_SCAN << 16);                   // (row 0 of the component: k_fpc32_offsets collects the flags per component)
   cin[k0] = carry0;
   if (two)
     cin[k1] = carry1;
   __syncthreads();
-#ifndef SF_NO_FIX
   for (uint32_t r = tid >> 6; r < cnt; r += SF_THREADS / 64u)
     fixup_row_wave(M + r * (uint32_t)TAB, cin, Hs[r], segbytes, rawbytes, recs, S, (uint32_t)arity, (g0 + r) * (uint32_t)arity + c, tid & 63u);
-#endif
   }
 
 // the scan kernel's LDS is beyond the 64 KiB a kernel gets without asking: claimed once per device of the process
@@ -1508,11 +1522,11 @@ static bool scanfix_lds_claimed()
   static std::atomic<int> state[16];             // 0 not asked, 1 claimed, 2 refused
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16)
-    return hipFuncSetAttribute((const void*)k_fpc32_scanfix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SF_LDS_WORDS * 4u)) == hipSuccess;
+    return hipFuncSetAttribute((const void*)k_fpc32_scanfix<SWEEP_HOOK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SF_LDS_WORDS * 4u)) == hipSuccess;
   int st = state[dev].load();
   if (st == 0)
     {
-    st = hipFuncSetAttribute((const void*)k_fpc32_scanfix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SF_LDS_WORDS * 4u)) == hipSuccess ? 1 : 2;
+    st = hipFuncSetAttribute((const void*)k_fpc32_scanfix<SWEEP_HOOK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SF_LDS_WORDS * 4u)) == hipSuccess ? 1 : 2;
     state[dev].store(st);
     }
   return st == 1;
@@ -1929,11 +1943,6 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
 
 unsigned guard_workgroups(const Plan& p) { return p.S < GUARD_WGS ? p.S : GUARD_WGS; }
 
-#ifdef TRICO_HIP_TEST_HOOKS
-constexpr bool SWEEP_HOOK = true;
-#else
-constexpr bool SWEEP_HOOK = false;
-#endif
 
 } // namespace
 
@@ -2037,10 +2046,10 @@ int launch_fpc32_sweep(const uint32_t* d_src, uint32_t n, int arity, const Plan&
   constexpr bool HOOK = SWEEP_HOOK;
   if (use_asm)
     hipLaunchKernelGGL((k_fpc32_sweep<HOOK, true>), dim3(p.S + G), dim3(threads), lds, st, d_src, n, arity, p.L, p.sg, p.S, outT,
-                       slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, sabotage, seed, gslots, grecs, gmeta, diag, rblocks, agg, (uint32_t)p.agg_words);
+                       slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, sabotage & 1u, seed, gslots, grecs, gmeta, diag, rblocks, agg, (uint32_t)p.agg_words);
   else
     hipLaunchKernelGGL((k_fpc32_sweep<HOOK, false>), dim3(p.S + G), dim3(threads), lds, st, d_src, n, arity, p.L, p.sg, p.S, outT,
-                       slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, sabotage, seed, gslots, grecs, gmeta, diag, rblocks, agg, (uint32_t)p.agg_words);
+                       slots, p.slot_stride, p.segcap, segbytes, rawbytes, nrec, recs, sabotage & 1u, seed, gslots, grecs, gmeta, diag, rblocks, agg, (uint32_t)p.agg_words);
 #ifdef TRICO_SWEEP_DIAG
   {
   // diagnostic build: clocks of the wave of segment S / 2 of every component, printed per launch; every wave's timeline to a file
@@ -2068,8 +2077,8 @@ int launch_fpc32_sweep(const uint32_t* d_src, uint32_t n, int arity, const Plan&
     set_error("float encoder: cannot claim 135 KiB of LDS for the scan");
     return 0;
     }
-  hipLaunchKernelGGL(k_fpc32_scanfix, dim3(p.nch * (unsigned)arity), dim3(SF_THREADS), SF_LDS_WORDS * 4u, st, outT, p.S, arity, p.nch, agg,
-                     segbytes, rawbytes, nrec, recs, slots, p.slot_stride, p.segcap, gslots, grecs, gmeta, G * (unsigned)arity);
+  hipLaunchKernelGGL(k_fpc32_scanfix<HOOK>, dim3(p.nch * (unsigned)arity), dim3(SF_THREADS), SF_LDS_WORDS * 4u, st, outT, p.S, arity, p.nch, agg,
+                     segbytes, rawbytes, nrec, recs, slots, p.slot_stride, p.segcap, gslots, grecs, gmeta, G * (unsigned)arity, sabotage);
   return hip_ok(hipGetLastError(), "fpc32 encode kernels (sweep)") ? 1 : 0;
   }
 

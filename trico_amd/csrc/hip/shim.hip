@@ -169,7 +169,7 @@ void ProfSpan::stop()
 static int g_device_state = 0;   // 0 unknown, 1 ok, -1 none
 static thread_local uint32_t g_stats[4] = { 0, 0, 0, 0 };      // words 0, 1: the last trico_hip_int_encode of this thread
 static std::atomic<uint32_t> g_repeats{ 0 }, g_other_writer{ 0 };   // words 2, 3: process-wide (a batch may be led by another thread)
-static std::atomic<uint32_t> g_recoded_order{ 0 }, g_recoded_sentinel{ 0 };   // trico_hip_encode_stats
+static std::atomic<uint32_t> g_recoded_order{ 0 }, g_recoded_sentinel{ 0 }, g_recoded_scan{ 0 };   // trico_hip_encode_stats, trico_hip_encode_scan_recodes
 static std::atomic<int> g_strict{ -1 };                     // trico_hip_set_strict: -1 = what TRICO_HIP_STRICT says
 static std::atomic<int> g_verify{ -1 };                     // trico_hip_set_encode_verify: -1 = what TRICO_HIP_ENCODE_VERIFY says
 static std::atomic<uint64_t> g_verified_streams{ 0 }, g_verified_values{ 0 }, g_verify_mismatch{ 0 };
@@ -585,6 +585,8 @@ int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int
         }
       if (raised & FPC32_FLAG_SENTINEL)
         g_recoded_sentinel += 1;
+      if (raised & FPC32_FLAG_SCAN)
+        g_recoded_scan += 1;
       if (getenv("TRICO_HIP_DEBUG"))
         fprintf(stderr, "trico_hip: float encoder flags 0x%x (1: LDS exchange out of lane order, 2: payload equals the table mark, "
                         "4: a wait in the scan kernel ran out); coding the stream again with the ballot coder\n", raised);
@@ -1393,6 +1395,8 @@ void trico_hip_encode_stats(uint32_t out[2])
   out[0] = g_recoded_order.load();
   out[1] = g_recoded_sentinel.load();
   }
+
+uint32_t trico_hip_encode_scan_recodes(void) { return g_recoded_scan.load(); }
 
 void trico_hip_set_strict(int on) { g_strict.store(on < 0 ? -1 : on != 0); }
 uint32_t trico_hip_ctx_other_writer_streams(const trico_hip_ctx* ctx) { return ctx ? ctx->other_writer_streams : 0u; }
