@@ -499,7 +499,7 @@ def extras(args, api, meshgen, dev, d_v, d_t, nv, nt, raw_bytes):
 
     def one_step(dv, dt):
         t0 = time.perf_counter()
-        a = api.Archive.open_for_writing(raw_bytes // 4, device=True)
+        a = api.Archive.open_for_writing(raw_bytes // 2, device=True)
         assert a.write("vertices", dv, nv) == 1 and a.write("triangles", dt, nt) == 1, api.last_error()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -577,7 +577,7 @@ def extras(args, api, meshgen, dev, d_v, d_t, nv, nt, raw_bytes):
         # together into one batch
         import threading
         kt = 8
-        a = api.Archive.open_for_writing(raw_bytes // 4, device=True)
+        a = api.Archive.open_for_writing(raw_bytes // 2, device=True)
         assert a.write("vertices", d_v, nv) == 1 and a.write("triangles", d_t, nt) == 1, api.last_error()
         touts = [(torch.empty_like(d_v), torch.empty_like(d_t)) for _ in range(kt)]
         terr = []
@@ -621,7 +621,7 @@ def decode_model(api, d_v, d_t, nv, nt, raw_bytes):
     trico_hip_decode_jobs, hipEvent span around kernel + self-check), nanoseconds and cycles per value."""
     import struct
     L = api.lib()
-    a = api.Archive.open_for_writing(raw_bytes // 4, device=True)
+    a = api.Archive.open_for_writing(raw_bytes // 2, device=True)
     assert a.write("vertices", d_v, nv) == 1, api.last_error()
     head = bytearray(8 + 5 + 3 * 4 + 64)
     base = a.get_buffer_pointer()
@@ -1070,7 +1070,7 @@ def main():
         if sharded:
             return step_sharded(check)
         te0 = time.perf_counter()
-        a = api.Archive.open_for_writing(raw_bytes // 4, device=True)      # caller-chosen initial size: no regrowth
+        a = api.Archive.open_for_writing(raw_bytes // 2, device=True)      # caller-chosen initial size: no regrowth, and room for the vertex stream's worst case (the writer then frames it in place)
         assert a.write("vertices", d_v, nv) == 1, api.last_error()
         assert a.write("triangles", d_t, nt) == 1, api.last_error()
         sync()

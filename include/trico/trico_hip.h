@@ -158,6 +158,13 @@ TRICO_API int trico_hip_weld_vertices(trico_hip_ctx* ctx, const float* corners, 
 /* all `count` payloads of the last encode, payload c to dsts[c]; float payloads going to device memory take one
  * fused gather launch (what the archive writers use) */
 TRICO_API int trico_hip_fetch_payloads(trico_hip_ctx* ctx, int count, void* const* dsts);
+/* A float stream (width 4: trico_compress with the API's table sizes) coded AND framed in one queue of launches: from d_first on, in
+ * device memory, `u32 bytes, payload` for each of the `arity` components (the body of a stream behind its type and count,
+ * trico.c:215-262), placed by the sizes the device computed - the host waits once, at the end, and gets them in sizes[].  d_first needs
+ * room for arity * (4 + 5 + 4 n + 3 (n / 8 + 2) + 8) bytes.  1: done; 0: error; -1: not this way (width, n == 0, destination not in
+ * device memory, full verification switched on, or the encoder raised a flag) - nothing to rely on was written, call
+ * trico_hip_fpc_encode + trico_hip_fetch_payloads, which cover every case.  What the archive writers do for device-resident archives. */
+TRICO_API int trico_hip_fpc_encode_place(trico_hip_ctx* ctx, const void* src, uint32_t n, int arity, int width, void* d_first, uint32_t sizes[3]);
 /* device address of payload `c` of the last encode (valid until the next encode on ctx) */
 TRICO_API const uint8_t* trico_hip_payload_device_pointer(trico_hip_ctx* ctx, int c);
 

@@ -22,6 +22,7 @@ int trico_hip_int_encode(trico_hip_ctx* c, const void* s, uint32_t n, int w, uin
 int trico_hip_int_decode(trico_hip_ctx* c, const uint8_t* const p[8], const uint32_t z[8], int w, uint32_t n, void* d) { (void)c; (void)p; (void)z; (void)w; (void)n; (void)d; return 0; }
 int trico_hip_fetch_payload(trico_hip_ctx* c, int i, void* d) { (void)c; (void)i; (void)d; return 0; }
 int trico_hip_fetch_payloads(trico_hip_ctx* c, int n, void* const* d) { (void)c; (void)n; (void)d; return 0; }
+int trico_hip_fpc_encode_place(trico_hip_ctx* c, const void* s, uint32_t n, int a, int w, void* d, uint32_t* z) { (void)c; (void)s; (void)n; (void)a; (void)w; (void)d; (void)z; return 0; }
 int trico_hip_decode_jobs(trico_hip_decode_job* j, int n) { for (int i = 0; i < n; ++i) j[i].ok = j[i].dst == NULL; return 0; }
 uint32_t trico_hip_ctx_other_writer_streams(const trico_hip_ctx* c) { (void)c; return 0; }
 int trico_hip_walk_frames(const uint8_t* d, uint64_t z, uint64_t p, const uint8_t t[21], trico_hip_frame_bytes* o, int c, uint8_t h[8]) { (void)d; (void)z; (void)p; (void)t; (void)o; (void)c; (void)h; return -1; }

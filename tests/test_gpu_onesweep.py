@@ -227,3 +227,4 @@ def test_full_encode_verification_catches_what_the_sampling_guard_is_told_to_ign
     streams, values, differed = [int(x) for x in out.stdout.split("VERIFY")[1].split()[:3]]
     assert streams >= 1 and differed >= 1, (streams, values, differed)
     assert "ENCODE VERIFICATION FAILED" in out.stderr
+

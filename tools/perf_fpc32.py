@@ -18,24 +18,28 @@ d = torch.from_numpy(v).cuda()
 ctx = L.trico_hip_ctx_create()
 sizes = (ctypes.c_uint32 * 3)()
 L.trico_hip_profile_enable(1)
+place = os.environ.get("PERF_PLACE", "1") == "1"      # coded and framed in one queue of launches, as the archive writer does for a device archive
+bound = 5 + 4 * n + 3 * ((n + 7) // 8 + 1) + 8
+dst = torch.empty(3 * (4 + bound) + 1024, dtype=torch.uint8, device="cuda")
 for it in range(6):
     if it == 1:
         L.trico_hip_profile_reset()
     t0 = time.perf_counter()
-    assert L.trico_hip_fpc_encode(ctx, d.data_ptr(), n, 3, 4, sizes) == 1, api.last_error()
-    if it == 0:
-        dst = torch.empty(sum(sizes) + 1024, dtype=torch.uint8, device="cuda")
-    off = 0
-    if os.environ.get("PERF_GATHER_ALL", "1") == "1":   # all payloads with ONE gather launch, as the archive writer does
-        ptrs = (ctypes.c_void_p * 3)()
-        for c in range(3):
-            ptrs[c] = dst.data_ptr() + off
-            off += sizes[c]
-        assert L.trico_hip_fetch_payloads(ctx, 3, ptrs) == 1, api.last_error()
+    if place:
+        assert L.trico_hip_fpc_encode_place(ctx, d.data_ptr(), n, 3, 4, dst.data_ptr(), sizes) == 1, api.last_error()
     else:
-        for c in range(3):      # one launch per component
-            assert L.trico_hip_fetch_payload(ctx, c, dst.data_ptr() + off) == 1, api.last_error()
-            off += sizes[c]
+        assert L.trico_hip_fpc_encode(ctx, d.data_ptr(), n, 3, 4, sizes) == 1, api.last_error()
+        off = 0
+        if os.environ.get("PERF_GATHER_ALL", "1") == "1":   # all payloads with ONE gather launch
+            ptrs = (ctypes.c_void_p * 3)()
+            for c in range(3):
+                ptrs[c] = dst.data_ptr() + off
+                off += sizes[c]
+            assert L.trico_hip_fetch_payloads(ctx, 3, ptrs) == 1, api.last_error()
+        else:
+            for c in range(3):      # one launch per component
+                assert L.trico_hip_fetch_payload(ctx, c, dst.data_ptr() + off) == 1, api.last_error()
+                off += sizes[c]
     L.trico_hip_synchronize()
     t1 = time.perf_counter()
     print("iter", it, "wall ms %.3f" % ((t1 - t0) * 1e3), list(sizes), flush=True)

@@ -55,7 +55,7 @@ HIP_SYMBOLS = [
     "trico_hip_available", "trico_hip_last_error", "trico_hip_ctx_create", "trico_hip_ctx_destroy",
     "trico_hip_set_stream", "trico_hip_synchronize", "trico_hip_pointer_is_device", "trico_hip_device_alloc",
     "trico_hip_device_free", "trico_hip_copy", "trico_hip_fpc_encode", "trico_hip_fpc_decode",
-    "trico_hip_int_encode", "trico_hip_int_decode", "trico_hip_fetch_payload", "trico_hip_fetch_payloads", "trico_hip_payload_device_pointer",
+    "trico_hip_int_encode", "trico_hip_int_decode", "trico_hip_fetch_payload", "trico_hip_fetch_payloads", "trico_hip_fpc_encode_place", "trico_hip_payload_device_pointer",
     "trico_hip_open_archive_for_writing_device", "trico_hip_profile_enable", "trico_hip_profile_reset",
     "trico_hip_profile_ms", "trico_hip_last_stats", "trico_hip_encode_stats", "trico_hip_fpc32_code_sweep",
     "trico_hip_decode_jobs", "trico_hip_decode_jobs_reserve", "trico_hip_list_streams", "trico_hip_read_archives",
@@ -158,6 +158,8 @@ def lib():
     L.trico_hip_fetch_payload.argtypes = [vp, ci, vp]
     L.trico_hip_fetch_payloads.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
     L.trico_hip_fetch_payloads.restype = ctypes.c_int
+    L.trico_hip_fpc_encode_place.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+    L.trico_hip_fpc_encode_place.restype = ctypes.c_int
     L.trico_hip_fetch_payload.restype = ci
     L.trico_hip_payload_device_pointer.argtypes = [vp, ci]
     L.trico_hip_payload_device_pointer.restype = vp

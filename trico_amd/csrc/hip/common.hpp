@@ -142,6 +142,7 @@ bool lds_lane_order_ok();            // the device applies the lanes of one LDS 
 int fpc32_code_sweep_mode();          // what FPC32_CODER_AUTO runs: 0 two sweeps + ballots, 2 two sweeps + exchange, 3 one sweep + exchange
 int launch_fpc32_gather(uint32_t n, int arity, int c, const uint8_t* d_ws, uint8_t* d_dst);
 int launch_fpc32_gather_all(uint32_t n, int arity, const uint8_t* d_ws, uint8_t* const d_dst[3]);
+int launch_fpc32_gather_framed(uint32_t n, int arity, const uint8_t* d_ws, uint8_t* d_first, const uint32_t* d_sizes);
 int launch_fpc32_compare(uint32_t n, int arity, const uint8_t* d_ws, const uint32_t* d_sizes, const uint8_t* const d_pay[3],
                          const uint32_t sizes[3], uint32_t* d_status, uint32_t flag);
 // generic: sets bit `flag` of *d_status if *d_size != n_expected or the first n_expected bytes of a and b differ

@@ -215,7 +215,9 @@ __device__ __forceinline__ uint32_t popc_below(uint64_t mask)
 // k_fpc32_sweep.hip: the one-sweep coder.  launch_fpc32_sweep queues sweep, cross-segment scan and fix-up (sizes of the segments are
 // final afterwards: Plan::off_segbytes); launch_fpc32_gather_rec moves the slots of components [c0, c0 + count) to dst[0..count).
 int launch_fpc32_sweep(const uint32_t* d_src, uint32_t n, int arity, const Plan& p, uint8_t* d_ws);
-int launch_fpc32_gather_rec(const Plan& p, int arity, int c0, int count, const uint8_t* d_ws, uint8_t* const d_dst[3]);
+int launch_fpc32_gather_rec(const Plan& p, int arity, int c0, int count, const uint8_t* d_ws, uint8_t* const d_dst[3], const uint32_t* d_sizes = nullptr);
+// (d_sizes given, c0 = 0, count = arity: d_dst[0] is where the stream's first size field goes, the components follow each other as
+// `u32 bytes, payload`, placed by the sizes in device memory)
 
 } // namespace fpc32
 } // namespace trico

@@ -1093,6 +1093,16 @@ int launch_fpc32_compare(uint32_t n, int arity, const uint8_t* d_ws, const uint3
   return hip_ok(hipGetLastError(), "k_fpc32_compare") ? 1 : 0;
   }
 
+// All components in one launch, framed for the container (`u32 bytes, payload` per component) from d_first on, placed on the device by
+// the sizes launch_fpc32_encode left in d_sizes: nothing here needs the host to have read them.
+int launch_fpc32_gather_framed(uint32_t n, int arity, const uint8_t* d_ws, uint8_t* d_first, const uint32_t* d_sizes)
+  {
+  if (n == 0)
+    return 0;
+  uint8_t* const dst[3] = { d_first, nullptr, nullptr };
+  return launch_fpc32_gather_rec(make_plan(n, arity), arity, 0, arity, d_ws, dst, d_sizes);
+  }
+
 // All components in one launch, each to its own destination (the archive writer knows all of them up front).
 int launch_fpc32_gather_all(uint32_t n, int arity, const uint8_t* d_ws, uint8_t* const d_dst[3])
   {

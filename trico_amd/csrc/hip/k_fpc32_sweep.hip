@@ -1607,7 +1607,8 @@ __device__ __forceinline__ void copy_shifted(uint8_t* __restrict__ dd, const uin
 __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict__ slots, size_t slot_stride, uint32_t segcap, uint32_t S,
                                                       const uint32_t* __restrict__ segbytes, const uint32_t* __restrict__ rawbytes,
                                                       const uint32_t* __restrict__ segoff, GatherDst dst, const uint32_t* __restrict__ nrec,
-                                                      const uint32_t* __restrict__ recs, int arity, int c0, const uint32_t* __restrict__ rectot)
+                                                      const uint32_t* __restrict__ recs, int arity, int c0, const uint32_t* __restrict__ rectot,
+                                                      const uint32_t* __restrict__ sizes)
   {
   const uint32_t g = blockIdx.x, tid = threadIdx.x;
   // The components in the order of their records (k_fpc32_offsets counts them), most first: a component full of them (a grid's z:
@@ -1628,7 +1629,19 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
   const uint32_t cc = (uint32_t)c0 + c;                                           // component in the workspace's numbering
   const uint32_t len = segbytes[(size_t)cc * S + g];
   const uint8_t* s = slots + (size_t)cc * slot_stride + (size_t)g * segcap;       // 256-byte aligned, segcap has 280 bytes of slack
-  uint8_t* d = dst.p[c] + segoff[(size_t)cc * S + g];
+  uint8_t* d = dst.p[c];
+  if (sizes)
+    {
+    // Chained destinations (the archive writer, device buffer): dst.p[0] is where the stream's FIRST size field goes; every component
+    // is `u32 bytes, payload` right behind the component before it (trico.c:215-262), and where that is the sizes in device memory say
+    // (k_fpc32_offsets) - the host need not have read them when this launch is queued.  Segment 0 writes the size field.
+    d = dst.p[0] + 4u;
+    for (uint32_t k = 0; k < cc; ++k)
+      d += sizes[k] + 4u;
+    if (g == 0u && tid < 4u)
+      d[(int)tid - 4] = (uint8_t)(sizes[cc] >> (8u * tid));
+    }
+  d += segoff[(size_t)cc * S + g];
   const size_t rowi = (size_t)g * arity + cc;
   const uint32_t H = nrec[rowi] & 0xffffu;
   if (H == 0u)
@@ -2082,12 +2095,12 @@ int launch_fpc32_sweep(const uint32_t* d_src, uint32_t n, int arity, const Plan&
   return hip_ok(hipGetLastError(), "fpc32 encode kernels (sweep)") ? 1 : 0;
   }
 
-int launch_fpc32_gather_rec(const Plan& p, int arity, int c0, int count, const uint8_t* d_ws, uint8_t* const d_dst[3])
+int launch_fpc32_gather_rec(const Plan& p, int arity, int c0, int count, const uint8_t* d_ws, uint8_t* const d_dst[3], const uint32_t* d_sizes)
   {
   GatherDst dst = { { d_dst[0], count > 1 ? d_dst[1] : nullptr, count > 2 ? d_dst[2] : nullptr } };
   hipLaunchKernelGGL(k_fpc32_gather, dim3(p.S, count), dim3(256), 0, current_stream(), d_ws + p.off_slots, p.slot_stride, p.segcap, p.S,
                      (const uint32_t*)(d_ws + p.off_segbytes), (const uint32_t*)(d_ws + p.off_rawbytes), (const uint32_t*)(d_ws + p.off_segoff),
-                     dst, (const uint32_t*)(d_ws + p.off_nrec), (const uint32_t*)(d_ws + p.off_recs), arity, c0, (const uint32_t*)(d_ws + p.off_diag + 256));
+                     dst, (const uint32_t*)(d_ws + p.off_nrec), (const uint32_t*)(d_ws + p.off_recs), arity, c0, (const uint32_t*)(d_ws + p.off_diag + 256), d_sizes);
   return hip_ok(hipGetLastError(), "k_fpc32_gather") ? 1 : 0;
   }
 

@@ -483,6 +483,47 @@ int trico_hip_fpc_encode(trico_hip_ctx* ctx, const void* src, uint32_t n, int ar
   return trico_hip_fpc_encode_ex(ctx, src, n, arity, width, width == 4 ? 4u : 20u, width == 4 ? 10u : 20u, sizes);
   }
 
+// One queue of launches from the values to the framed stream body in a device buffer: encode, then the gather placed by the sizes in
+// device memory (`u32 bytes, payload` per component from d_first on); the host waits once, at the end, for the sizes.  1 = done,
+// 0 = error, -1 = not this way (not a float stream of the API's table sizes, empty, destination not in device memory, full
+// verification asked for, or a flag of the one-sweep coder was raised): the caller takes trico_hip_fpc_encode + fetch_payloads, which
+// deals with every case; nothing the caller may rely on has been written.
+int trico_hip_fpc_encode_place(trico_hip_ctx* ctx, const void* src, uint32_t n, int arity, int width, void* d_first, uint32_t sizes[3])
+  {
+  if (!ctx || !device_ready())
+    return 0;
+  if (width != 4 || n == 0 || arity < 1 || arity > 3 || !src || !d_first || force_serial_stage(1) || encode_verify_on() ||
+      !trico_hip_pointer_is_device(d_first))
+    return -1;
+  const size_t in_bytes = (size_t)n * arity * 4u;
+  if (!ctx->in.reserve(in_bytes + 16))
+    return 0;
+  ctx->out_count = 0;
+  ctx->out_in_slots = false;
+  const void* d_src = stage_in(ctx->in, src, in_bytes);
+  if (!d_src)
+    return 0;
+  uint32_t* d_sizes = (uint32_t*)ctx->aux.p;
+  const size_t ws = fpc32_encode_workspace(n, arity);
+  if (!ctx->tmp.reserve(ws))
+    return 0;
+  {
+  ProfSpan span(TRICO_HIP_K_FPC32_ENCODE);
+  if (!launch_fpc32_encode(d_src, n, arity, nullptr, 0, d_sizes, ctx->tmp.p, ctx->tmp.cap, FPC32_CODER_AUTO, ctx->h_pinned + MIRROR_AT) ||
+      !launch_fpc32_gather_framed(n, arity, ctx->tmp.p, (uint8_t*)d_first, d_sizes))
+    return 0;
+  }
+  uint32_t six[6] = { 0, 0, 0, 0, 0, 0 };
+  if (!read_mirrored_sizes(ctx, six))
+    return 0;
+  for (int c = 0; c < arity; ++c)
+    if (six[3 + c] != 0)
+      return -1;                    // (what was placed is not the stream; the caller's other way codes it again and counts the flag)
+  for (int c = 0; c < arity; ++c)
+    sizes[c] = six[c];
+  return 1;
+  }
+
 int trico_hip_fpc_encode_ex(trico_hip_ctx* ctx, const void* src, uint32_t n, int arity, int width, uint32_t e1, uint32_t e2,
                             uint32_t sizes[3])
   {

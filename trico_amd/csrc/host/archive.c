@@ -454,6 +454,35 @@ static int write_fp_stream(void* archive, enum trico_stream_type st, uint32_t co
   if (!a || !a->writable || !arch_ctx(a))
     return 0;
   uint32_t sizes[3] = { 0, 0, 0 };
+  if (width == 4 && n != 0 && a->buffer_on_device)
+    {
+    /* A device-resident archive with room for the stream's worst case: the encoder frames the stream body in place (one queue of
+     * launches, one wait).  Otherwise - and whenever the encoder says "not this way" - sizes first, then the payloads. */
+    const uint64_t bound = 5 + 4ull * n + 3ull * (((uint64_t)n + 7) / 8 + 1) + 8;
+    const uint64_t worst = 5 + (uint64_t)arity * (4 + bound);
+    if (a->buffer_size - a->used >= worst)
+      {
+      const uint64_t rollback = a->used;
+      uint8_t head[5];
+      head[0] = (uint8_t)st;
+      store_le32(head + 1, count_field);
+      if (!put_host(a, head, 5))
+        {
+        a->used = rollback;
+        return 0;
+        }
+      const int r = trico_hip_fpc_encode_place(a->ctx, data, n, arity, width, a->buffer + a->used, sizes);
+      if (r == 1)
+        {
+        for (int c = 0; c < arity; ++c)
+          a->used += 4 + (uint64_t)sizes[c];
+        return 1;
+        }
+      a->used = rollback;
+      if (r == 0)
+        return 0;
+      }
+    }
   if (!trico_hip_fpc_encode(a->ctx, data, n, arity, width, sizes))
     return 0;
   return append_stream(a, st, count_field, arity, sizes);
