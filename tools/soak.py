@@ -63,7 +63,11 @@ for case in range(cases):
             else:
                 data = rng.integers(0, min(hi, int(np.iinfo(dt).max) + 1), n * arity).astype(dt)
         streams.append((name, np.ascontiguousarray(data), n))
-    a = api.Archive.open_for_writing(1 << 12)
+    # where the archive lives: host memory; device memory without room (sizes first, payloads second, the buffer grows); device memory with
+    # room for every stream's worst case (float streams are framed in place: trico_hip_fpc_encode_place)
+    where = int(rng.integers(3)) if os.environ.get("SOAK_DEVICE") else 0
+    room = 4096 + 2 * sum(len(d.tobytes()) + 64 for _, d, _ in streams)
+    a = api.Archive.open_for_writing(1 << 12) if where == 0 else api.Archive.open_for_writing(1 << 12 if where == 1 else room, device=True)
     o = O.OracleArchive()
     for name, data, n in streams:
         assert a.write(name, data, n) == 1, (case, name, api.last_error())
