@@ -72,3 +72,18 @@ for g in range(S):
 print("  by arrival on the unit, loop time median: " + " ".join("%d:%.0f" % (kk, np.median((l1 - l0)[z][k == kk])) for kk in range(k.max() + 1)))
 print("  by arrival on the unit, end median:       " + " ".join("%d:%.0f" % (kk, np.median(end[z][k == kk])) for kk in range(k.max() + 1)))
 print("  by arrival on the unit, end max:          " + " ".join("%d:%.0f" % (kk, np.max(end[z][k == kk])) for kk in range(k.max() + 1)))
+# what the late compute units have in common: workgroups on the unit, the most waves of the slow component on one of its SIMDs, the XCC
+zmax = {}
+for kk, v in zc.items():
+    zmax[kk // 4] = max(zmax.get(kk // 4, 0), len(v))
+grp = {}
+for u, ends in per_cu.items():
+    grp.setdefault((len(ends), zmax.get(u, 0)), []).append(max(ends))
+for kk in sorted(grp):
+    print("  units with %d workgroups, at most %d waves of component %d on a SIMD: %d units, last end median %.1f max %.1f" % (kk[0], kk[1], slow, len(grp[kk]), np.median(grp[kk]), np.max(grp[kk])))
+gx = {}
+for u, ends in per_cu.items():
+    gx.setdefault(u // 1000, []).append(max(ends))
+print("  last end per unit by XCC (median / max): " + " ".join("%d:%.0f/%.0f" % (x, np.median(v), np.max(v)) for x, v in sorted(gx.items())))
+late = sorted(per_cu.items(), key=lambda kv: -max(kv[1]))[:8]
+print("  the latest units: " + "; ".join("xcc %d se %d cu %d: %d wgs, end %.0f" % (u // 1000, (u % 1000) // 100, u % 50, len(e), max(e)) for u, e in late))

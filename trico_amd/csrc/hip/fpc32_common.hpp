@@ -63,6 +63,7 @@ struct Plan
 int fpc32_sweep_resident_workgroups(int arity);
 int fpc32_sweep_class_size();                 // segments per class of the staggered geometry: the compute units of the current device
 int fpc32_sweep_stagger_permille();           // how much longer than the mean the first class's segments are (the last: shorter), in 1/1000
+int fpc32_sweep_class_weights(uint32_t K, int arity, double* w);     // 1: w[0..K) are the relative lengths of the classes (measured tables); 0: the linear rule
 
 inline Plan make_plan(uint32_t n, int arity)
   {
@@ -97,10 +98,12 @@ inline Plan make_plan(uint32_t n, int arity)
     double wsum = 0;
     double w[STAGGER_MAX];
     uint32_t cnt[STAGGER_MAX];
+    const int table = fpc32_sweep_class_weights(K, arity, w);
     for (uint32_t k = 0; k < K; ++k)
       {
       cnt[k] = k + 1 < K ? C : p.S - k * C;
-      w[k] = 1.0 + (double)beta / 1000.0 * (1.0 - (2.0 * k + 1.0) / (double)K);
+      if (!table)
+        w[k] = 1.0 + (double)beta / 1000.0 * (1.0 - (2.0 * k + 1.0) / (double)K);
       wsum += w[k] * cnt[k];
       }
     uint64_t given = 0, at = 0;

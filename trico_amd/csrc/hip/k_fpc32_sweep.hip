@@ -2024,6 +2024,27 @@ int fpc32_sweep_stagger_permille()
   return beta;
   }
 
+int fpc32_sweep_class_weights(uint32_t K, int arity, double* w)
+  {
+  // measurements (test-hooks library): TRICO_FPC32_STAGGER_W = K comma-separated relative lengths
+  static const char* env = tune_env("TRICO_FPC32_STAGGER_W");
+  (void)arity;
+  if (!env)
+    return 0;
+  uint32_t got = 0;
+  const char* q = env;
+  while (*q && got < (uint32_t)STAGGER_MAX)
+    {
+    char* end = nullptr;
+    const double v = strtod(q, &end);
+    if (end == q)
+      break;
+    w[got++] = v > 0.05 ? v : 0.05;
+    q = *end == ',' ? end + 1 : end;
+    }
+  return got == K ? 1 : 0;
+  }
+
 int launch_fpc32_sweep(const uint32_t* d_src, uint32_t n, int arity, const Plan& p, uint8_t* d_ws)
   {
   hipStream_t st = current_stream();
