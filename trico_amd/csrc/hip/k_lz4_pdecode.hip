@@ -44,8 +44,13 @@ constexpr uint32_t PD_PIECE = 65536;          // ... in pieces of at most this m
 constexpr uint32_t PD_END = 0xffffffffu;      // "walk ended with the last sequence of the block"
 constexpr uint32_t PD_NONE = 0xfffffffeu;     // "no token seen / walk failed"
 constexpr uint32_t PD_FINAL = 0x80000000u;    // src word: final, its low byte is the output byte (else: an earlier output index)
-constexpr int PD_HOPS = 3;                    // pointer hops of an open word per round
-constexpr int PD_ROUNDS = 20;                 // chains are shorter than 2^31 < 3^20
+#ifndef TRICO_PD_HOPS
+#define TRICO_PD_HOPS 4
+#define TRICO_PD_ROUNDS 16
+#endif
+constexpr int PD_HOPS = TRICO_PD_HOPS;        // pointer hops of an open word per round
+constexpr int PD_ROUNDS = TRICO_PD_ROUNDS;    // chains are shorter than 2^31 < 4^16 (3 hops x 20 rounds until round 6: 12.4 ms for the benchmark
+                                              // mesh's planes; 4 x 16: 11.5; 5 x 14: 11.55; 6 x 12: 11.7 - a round is a pass over 4.8 GB of words)
 
 struct Tile { uint32_t first, exit, nseq, pad; unsigned long long obytes; };
 struct Job { uint32_t op, len, a, b; };       // b == PD_NONE: literals from input position a; else match: offset a, its first period starts at output b
@@ -800,7 +805,7 @@ __global__ void __launch_bounds__(256) k_pd_jump(PdPlanes P, uint32_t n)
       if (!(w[k] & PD_FINAL))
         {
         // up to PD_HOPS hops per round: a round is a pass over the whole workspace whatever is still open, so fewer, longer
-        // rounds (chains shrink to a third per round instead of a half)
+        // rounds (chains shrink to a quarter per round)
         uint32_t x = __hip_atomic_load(&src[w[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int hop = 1; hop < PD_HOPS; ++hop)
