@@ -1538,7 +1538,9 @@ static bool scanfix_lds_claimed()
 // With records the slot is cut into sub-chunks of 2 KiB of SOURCE bytes (more for slots beyond 1 MiB).  A pass over the records
 // counts the unused bytes of every sub-chunk - a prefix sum says where its output begins - and marks the ones a record touches.
 // Then every WAVE takes sub-chunks by itself, no barrier: an untouched one is the copy with a shift again; a touched one passes
-// through the wave's own LDS, 64 x 16 bytes at a time: the records put their residual bytes and code bits into a patch area (ORed
+// through the wave's own LDS, a piece of 64 x 32 bytes at a time (64 x 16 until round 6: what a piece costs whatever it holds - the loads a
+// piece ahead, the pass over the records, the scan, the flush of the ring - is ~210 of ~390 instructions; same box, alternating,
+// benchmark mesh 150.5-153.1 -> 140.3-141.1 us): the records put their residual bytes and code bits into a patch area (ORed
 // into the lanes' bytes: the sweep left zeros there) and mark the unused bytes of their fields, a wave scan over the valid bytes
 // of every lane says where they go, and they land in a small output ring whose positions are congruent to the destination's
 // modulo 16 and leave it as aligned 16-byte vectors.  Every output byte is written once, by the wave that owns it; the partial
@@ -1549,9 +1551,15 @@ static bool scanfix_lds_claimed()
 #ifndef TRICO_GSUBSHIFT
 #define TRICO_GSUBSHIFT 11
 #endif
-constexpr uint32_t GSUB = 1024;                    // source bytes per piece (64 lanes x 16)
+#ifndef TRICO_GLANEB
+#define TRICO_GLANEB 32
+#endif
+constexpr uint32_t GLB = TRICO_GLANEB;             // source bytes of a piece a lane takes: 16 or 32 (64 would leave LDS for 18 waves per compute unit)
+static_assert(GLB == 16u || GLB == 32u, "a lane's unused bytes are one 32-bit mask");
+constexpr uint32_t GVN = GLB / 16u;
+constexpr uint32_t GSUB = 64u * GLB;               // source bytes per piece
 constexpr uint32_t MAXSUB = 512;                   // sub-chunks per slot (LDS: 8 workgroups per compute unit)
-constexpr uint32_t WRING = 1024 + 64;              // a wave's output buffer: at most 15 + 1024 bytes are in it at a time (+ the slack of a 16-byte store)
+constexpr uint32_t WRING = GSUB + 64;               // a wave's output buffer: at most 15 + GSUB bytes are in it at a time (+ the slack of a 16-byte store)
 struct GatherDst { uint8_t* p[3]; };
 
 // 16 bytes in a row to LDS byte address ad.  An LDS dword store at an address that is not a multiple of four costs about eight
@@ -1791,22 +1799,28 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
           }
         return r;
         };
-      auto load_vec = [&](uint32_t pb) -> u32x4
+      struct Vec { u32x4 v[GVN]; };
+      auto load_vec = [&](uint32_t pb) -> Vec
         {
-        const uint32_t sb = sb0 + pb + 16u * lane;
-        u32x4 v = { 0u, 0u, 0u, 0u };
-        if (sb < sb0 + sl)
-          v = *(const u32x4*)(s + sb);
-        return v;
+        Vec r;
+#pragma unroll
+        for (uint32_t h = 0; h < GVN; ++h)
+          {
+          const uint32_t sb = sb0 + pb + GLB * lane + 16u * h;
+          r.v[h] = u32x4{ 0u, 0u, 0u, 0u };
+          if (sb < sb0 + sl)
+            r.v[h] = *(const u32x4*)(s + sb);
+          }
+        return r;
         };
-      u32x4 vnext = load_vec(0u);
+      Vec vnext = load_vec(0u);
       Rec rnext = load_rec(rj + lane);
       const uint32_t pbase = (uint32_t)(uintptr_t)(lds_u8*)PB;
       for (uint32_t pb = 0; pb < sl; pb += GSUB)
         {
-        const uint32_t cb = sb0 + pb, sb = cb + 16u * lane;
+        const uint32_t cb = sb0 + pb, sb = cb + GLB * lane;
         const uint32_t pend = sl - pb < GSUB ? sb0 + sl : cb + GSUB;             // end of the piece in the slot
-        u32x4 vec = vnext;
+        Vec vec = vnext;
         const Rec r0 = rnext;
         const uint32_t rj0 = rj;
         // the records that are done with after this piece: their field ends inside it (they come first: slot order)
@@ -1819,7 +1833,9 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
           vnext = load_vec(pb + GSUB);
           rnext = load_rec(rj + lane);
           }
-        *(u32x4*)(PB + 16u * lane) = u32x4{ 0u, 0u, 0u, 0u };
+#pragma unroll
+        for (uint32_t h = 0; h < GVN; ++h)
+          *(u32x4*)(PB + GLB * lane + 16u * h) = u32x4{ 0u, 0u, 0u, 0u };
         if (lane < GSUB / 32u)
           U[lane] = 0u;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1889,37 +1905,45 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
         if (again && pb + GSUB < sl)
           rnext = load_rec(rj + lane);                            // (not by looking at rnext: that would wait for the load just issued)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        {
-        const u32x4 pt = *(const u32x4*)(PB + 16u * lane);
-        vec[0] |= pt[0]; vec[1] |= pt[1]; vec[2] |= pt[2]; vec[3] |= pt[3];
-        }
-        uint32_t m16 = (U[lane >> 1] >> (16u * (lane & 1u))) & 0xffffu;
-        if (sb + 16u > pend)
-          m16 |= sb >= pend ? 0xffffu : (0xffffu << (pend - sb)) & 0xffffu;       // beyond the sub-chunk's content
-        const uint32_t cnt = 16u - (uint32_t)__popc(m16);
+#pragma unroll
+        for (uint32_t h = 0; h < GVN; ++h)
+          {
+          const u32x4 pt = *(const u32x4*)(PB + GLB * lane + 16u * h);
+          vec.v[h][0] |= pt[0]; vec.v[h][1] |= pt[1]; vec.v[h][2] |= pt[2]; vec.v[h][3] |= pt[3];
+          }
+        // the unused bytes among the lane's GLB, one bit each
+        constexpr uint32_t LMASK = GLB == 32u ? 0xffffffffu : 0xffffu;
+        uint32_t mu = GLB == 32u ? U[lane] : (U[lane >> 1] >> (16u * (lane & 1u))) & 0xffffu;
+        if (sb + GLB > pend)
+          mu |= sb >= pend ? LMASK : (LMASK << (pend - sb)) & LMASK;             // beyond the sub-chunk's content
+        const uint32_t cnt = GLB - (uint32_t)__popc(mu);
         const uint32_t incl = wave_scan_incl(cnt);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         const uint32_t p = wpos + (incl - cnt);
-        if (m16 == 0u)
-          lds_store16(obase + p, vec);
+        if (mu == 0u)
+          {
+#pragma unroll
+          for (uint32_t h = 0; h < GVN; ++h)
+            lds_store16(obase + p + 16u * h, vec.v[h]);
+          }
         else
           {
-          // a lane with unused bytes among its sixteen: byte by byte, an unused one to the lane's dump byte instead of a branch
+          // a lane with unused bytes among its own: byte by byte, an unused one to the lane's dump byte instead of a branch
           // around the store (sixteen branches were 150 instructions per piece, this is 80: gather 163 -> 153 us on the benchmark mesh,
           // 150 -> 144 us on the walk mesh, same box, alternating; every lane this way, without lds_store16: 159 us)
           uint32_t q = obase + p;
           const uint32_t dump = obase + WRING + 32u + lane;
 #pragma unroll
-          for (int bb = 0; bb < 16; ++bb)
+          for (uint32_t bb = 0; bb < GLB; ++bb)
             {
-            const uint32_t keep = ((m16 >> bb) & 1u) ^ 1u;
-            *(lds_vu8*)(uintptr_t)(keep ? q : dump) = (uint8_t)(vec[bb >> 2] >> (8 * (bb & 3)));
+            const uint32_t keep = ((mu >> bb) & 1u) ^ 1u;
+            *(lds_vu8*)(uintptr_t)(keep ? q : dump) = (uint8_t)(vec.v[bb >> 4][(bb >> 2) & 3u] >> (8u * (bb & 3u)));
             q += keep;
             }
           }
         wpos += total;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // whole vectors leave (at most 65 are there), what is behind them moves to the front
+        // whole vectors leave (at most GSUB / 16 + 1 are there), what is behind them moves to the front
         const uint32_t nvec = wpos >> 4;
         for (uint32_t t = lane; t < nvec; t += 64u)
           {
