@@ -1554,8 +1554,9 @@ static bool scanfix_lds_claimed()
 #ifndef TRICO_GLANEB
 #define TRICO_GLANEB 32
 #endif
-constexpr uint32_t GLB = TRICO_GLANEB;             // source bytes of a piece a lane takes: 16 or 32 (64 would leave LDS for 18 waves per compute unit)
-static_assert(GLB == 16u || GLB == 32u, "a lane's unused bytes are one 32-bit mask");
+
+constexpr uint32_t GLB = TRICO_GLANEB;             // source bytes of a piece a lane takes: 16, 32 or 64 (64 with sub-chunks of 4 KiB: 172 us against 133-139)
+static_assert(GLB == 16u || GLB == 32u || GLB == 64u, "a lane's unused bytes are one 64-bit mask");
 constexpr uint32_t GVN = GLB / 16u;
 constexpr uint32_t GSUB = 64u * GLB;               // source bytes per piece
 constexpr uint32_t MAXSUB = 512;                   // sub-chunks per slot (LDS: 8 workgroups per compute unit)
@@ -1663,6 +1664,7 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
   __shared__ uint32_t touched[MAXSUB / 32];                      // a record has a byte in sub-chunk k
   __shared__ uint32_t wsum[4], next_sub;
   __shared__ __attribute__((aligned(16))) uint32_t wlds[4][(GSUB + GSUB / 8 + WRING + 32 + 64) / 4];  // per wave: patches, unused marks, output ring, a dump byte per lane
+  // (the patches inside the ring, which is idle while they are read: 147 against 133-139 us; fewer workgroups per unit through more LDS: no difference down to five)
   const uint32_t slen = rawbytes[(size_t)cc * S + g];
   const uint32_t* list = recs + rowi * RCAP * RECW;
   uint32_t subshift = TRICO_GSUBSHIFT;
@@ -1836,8 +1838,10 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
 #pragma unroll
         for (uint32_t h = 0; h < GVN; ++h)
           *(u32x4*)(PB + GLB * lane + 16u * h) = u32x4{ 0u, 0u, 0u, 0u };
-        if (lane < GSUB / 32u)
-          U[lane] = 0u;
+#pragma unroll
+        for (uint32_t w = 0; w < (GSUB / 32u + 63u) / 64u; ++w)
+          if (lane + 64u * w < GSUB / 32u)
+            U[lane + 64u * w] = 0u;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // the records with a byte in the piece: from the first whose field ends in it to the last whose header begins in it
         bool again = false;                                        // more than 64 of them: rnext was loaded before rj was final
@@ -1912,15 +1916,15 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
           vec.v[h][0] |= pt[0]; vec.v[h][1] |= pt[1]; vec.v[h][2] |= pt[2]; vec.v[h][3] |= pt[3];
           }
         // the unused bytes among the lane's GLB, one bit each
-        constexpr uint32_t LMASK = GLB == 32u ? 0xffffffffu : 0xffffu;
-        uint32_t mu = GLB == 32u ? U[lane] : (U[lane >> 1] >> (16u * (lane & 1u))) & 0xffffu;
+        constexpr uint64_t LMASK = GLB == 64u ? ~0ull : (1ull << (GLB & 63u)) - 1ull;
+        uint64_t mu = GLB == 64u ? ((uint64_t)U[2u * lane + 1u] << 32) | U[2u * lane] : GLB == 32u ? (uint64_t)U[lane] : (uint64_t)((U[lane >> 1] >> (16u * (lane & 1u))) & 0xffffu);
         if (sb + GLB > pend)
           mu |= sb >= pend ? LMASK : (LMASK << (pend - sb)) & LMASK;             // beyond the sub-chunk's content
-        const uint32_t cnt = GLB - (uint32_t)__popc(mu);
+        const uint32_t cnt = GLB - (uint32_t)__popcll(mu);
         const uint32_t incl = wave_scan_incl(cnt);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         const uint32_t p = wpos + (incl - cnt);
-        if (mu == 0u)
+        if (mu == 0ull)
           {
 #pragma unroll
           for (uint32_t h = 0; h < GVN; ++h)
@@ -1936,7 +1940,7 @@ __global__ void __launch_bounds__(256) k_fpc32_gather(const uint8_t* __restrict_
 #pragma unroll
           for (uint32_t bb = 0; bb < GLB; ++bb)
             {
-            const uint32_t keep = ((mu >> bb) & 1u) ^ 1u;
+            const uint32_t keep = ((uint32_t)(mu >> bb) & 1u) ^ 1u;
             *(lds_vu8*)(uintptr_t)(keep ? q : dump) = (uint8_t)(vec.v[bb >> 4][(bb >> 2) & 3u] >> (8u * (bb & 3u)));
             q += keep;
             }
