@@ -61,3 +61,34 @@ def test_device_archive_with_and_without_room_for_the_worst_case(native_libs, ro
             o.write(name, data, count)
         assert a.tobytes() == o.tobytes(), (kind, W, H, room)
         a.close(); o.close()
+
+
+def test_in_place_framing_behind_the_two_sweep_coder():
+    """The same framing when the slots come from the two-sweep coder (what a device whose LDS exchange is not trusted runs; here chosen
+    with TRICO_FPC32_SWEEPS=2 in the test-hooks library): the gather is the same kernel, the slots have no records."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = r"""
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+from trico_amd import api
+from oracle import oracle as O
+from streams import mesh_streams
+assert api.lib().trico_hip_fpc32_code_sweep() == 2
+for kind, W, H in (("walk", 300, 77), ("grid", 1000, 1000)):
+    s = mesh_streams(kind, W, H)
+    raw = sum(len(memoryview(d).cast("B")) for _, d, _ in s)
+    a = api.Archive.open_for_writing(2 * raw + 4096, device=True)
+    o = O.OracleArchive()
+    for name, data, count in s:
+        assert a.write(name, data, count) == 1, api.last_error()
+        o.write(name, data, count)
+    assert a.tobytes() == o.tobytes(), (kind, W, H)
+    a.close(); o.close()
+print("PLACED")
+"""
+    env = dict(os.environ, TRICO_AMD_LIB=os.path.join(root, "tests", "_build", "libtrico_testhooks.so"), TRICO_FPC32_SWEEPS="2")
+    out = subprocess.run([sys.executable, "-c", child % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "PLACED" in out.stdout, out.stdout + out.stderr
