@@ -142,7 +142,7 @@ inline Plan make_plan(uint32_t n, int arity)
   p.off_inc = o;       o += align_up(p.rows * ROW * 4, 256);
   p.off_chmax = o;     o += align_up((size_t)p.nch * arity * TAB * 4, 256);
   // the one-sweep coder's scan (k_fpc32_scanfix): per (chunk, component, class) one 64-bit word "ready | latest entry"; the sweep zeroes them
-  p.agg_words = (size_t)p.nch * arity * TAB;
+  p.agg_words = (size_t)(p.nch + (p.nch + 7) / 8) * arity * TAB;        // (the chunks' words, then one per group of eight chunks)
   p.off_agg = o;       o += align_up(p.agg_words * 8, 256);
   p.off_nrec = o;      o += align_up(p.rows * 4, 256);
   p.off_recs = o;      o += align_up(p.rows * RCAP * RECW * 4, 256);

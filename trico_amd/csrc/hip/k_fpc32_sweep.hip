@@ -1274,17 +1274,15 @@ k_fpc32_sweep(const uint32_t* __restrict__ src, uint32_t n, int arity, uint32_t 
 // host).  The LAST workgroups do it, between publishing and looking back: they have the longest wait in front of them.
 constexpr uint64_t AGG_READY = 1ull << 32;
 constexpr uint32_t SPIN_MAX = 1u << 21;             // x (a round of loads + s_sleep 2): seconds
-constexpr int LOOKB_NEAR = 8, LOOKB_FAR = 24;       // words of earlier chunks in flight per thread: first round, later rounds
 constexpr uint32_t SF_THREADS = 1024;
 constexpr uint32_t SF_LDS_WORDS = (uint32_t)CH * TAB + TAB + CH;
 static_assert(TAB - 1024 == 16 && SF_LDS_WORDS * 4u <= 160u * 1024u, "thread k: DFCM... column k, the first 16 threads one more; LDS of a compute unit");
 
 __device__ __forceinline__ uint64_t agg_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// What comes into chunk y for column k of component c: the latest entry of the chunks before it, else 0.  Backwards: the LOOKB_NEAR
-// chunks next to mine first - the common classes are written in every chunk, and a wave all of whose lanes have met a writer is done
-// (benchmark mesh: most waves) - then the rest LOOKB_FAR at a time.  (A round trip of such a load is ~2 us, no cache may serve it, and
-// all words of all columns would be 65 MB of them.)
+// What comes into chunk y for column k of component c: the latest entry of the chunks before it, else 0.  One round of look_back_round
+// asks for B words at once, nearest chunk first (a round trip of such a load is ~2 us: no cache may serve it), and a wave all of whose
+// lanes have met a writer stops looking.
 template <int B>
 __device__ __forceinline__ void look_back_round(const uint64_t* __restrict__ agg, uint32_t j1, uint32_t arity, uint32_t c, uint32_t k,
                                                 uint32_t& carry, bool& found, bool& late, uint32_t spin_max)
@@ -1321,16 +1319,24 @@ __device__ __forceinline__ void look_back_round(const uint64_t* __restrict__ agg
     }
   }
 
-__device__ __forceinline__ uint32_t look_back(const uint64_t* __restrict__ agg, uint32_t y, uint32_t arity, uint32_t c, uint32_t k, bool& late, uint32_t spin_max)
+// Two levels: the chunks of my group of GROUPC first (one round); the last chunk of every group publishes the group's latest entry
+// when it has done that, and whoever is still looking takes the groups before its own (one more round for up to eight groups) - at most
+// 7 + 8 words per column and two or three round trips.  (One level - the eight nearest chunks, then 24 at a time, up to 71 words and four
+// round trips: 34.2 us on the benchmark mesh, 26.2 us on the walk mesh, against 31.7 and 17.3.)
+constexpr uint32_t GROUPC = 8;
+__device__ __forceinline__ uint32_t look_back(uint64_t* __restrict__ agg, uint32_t nch, uint32_t y, uint32_t arity, uint32_t c, uint32_t k,
+                                              uint32_t own, bool& late, uint32_t spin_max)
   {
   uint32_t carry = 0;
   bool found = false;
-  if (y == 0u)
-    return 0u;
-  look_back_round<LOOKB_NEAR>(agg, y, arity, c, k, carry, found, late, spin_max);
-  for (uint32_t j1 = y > (uint32_t)LOOKB_NEAR ? y - (uint32_t)LOOKB_NEAR : 0u; j1 > 0u && __ballot(!found) != 0ull;
-       j1 = j1 > (uint32_t)LOOKB_FAR ? j1 - (uint32_t)LOOKB_FAR : 0u)
-    look_back_round<LOOKB_FAR>(agg, j1, arity, c, k, carry, found, late, spin_max);
+  const uint32_t gp = y / GROUPC, j = y % GROUPC;
+  if (j > 0u)
+    look_back_round<(int)GROUPC>(agg + (size_t)gp * GROUPC * arity * TAB, j, arity, c, k, carry, found, late, spin_max);
+  uint64_t* ga = agg + (size_t)nch * arity * TAB;
+  if (j == GROUPC - 1u)
+    __hip_atomic_store(&ga[((size_t)gp * arity + c) * TAB + k], AGG_READY | (own != SENT ? own : found ? carry : SENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (uint32_t g1 = gp; g1 > 0u && __ballot(!found) != 0ull; g1 = g1 > GROUPC ? g1 - GROUPC : 0u)
+    look_back_round<(int)GROUPC>(ga, g1, arity, c, k, carry, found, late, spin_max);
   return carry;
   }
 
@@ -1458,6 +1464,7 @@ __global__ void __launch_bounds__(1024) k_fpc32_scanfix(const uint32_t* __restri
   const uint32_t g0 = y * CH, cnt = (S - g0 < (uint32_t)CH) ? S - g0 : (uint32_t)CH;
   if (tid < (uint32_t)CH)
     Hs[tid] = tid < cnt ? nrec[(size_t)(g0 + tid) * arity + c] & 0xffffu : 0u;
+  uint32_t last0_kept = SENT, last1_kept = SENT;         // the chunk's own latest entries
   {
   uint32_t t0[CH], t1[CH];
 #pragma unroll
@@ -1475,6 +1482,8 @@ __global__ void __launch_bounds__(1024) k_fpc32_scanfix(const uint32_t* __restri
     last0 = t0[i] != SENT ? t0[i] : last0;
     last1 = t1[i] != SENT ? t1[i] : last1;
     }
+  last0_kept = last0;
+  last1_kept = last1;
   uint64_t* mine = agg + ((size_t)y * arity + c) * TAB;
   // (test hook, libtrico_testhooks.so only: the first workgroup never publishes - everybody behind it in its component has to give up)
   const bool mute = HOOK && (sabotage & 2u) != 0u && blockIdx.x == 0u;
@@ -1502,10 +1511,10 @@ __global__ void __launch_bounds__(1024) k_fpc32_scanfix(const uint32_t* __restri
   // the chunks before mine (the second column: the first wave only)
   bool late = false;
   const uint32_t spin_max = (HOOK && (sabotage & 2u) != 0u) ? 512u : SPIN_MAX;
-  const uint32_t carry0 = look_back(agg, y, (uint32_t)arity, c, k0, late, spin_max);
+  const uint32_t carry0 = look_back(agg, nch, y, (uint32_t)arity, c, k0, last0_kept, late, spin_max);
   uint32_t carry1 = 0;
   if (two)
-    carry1 = look_back(agg, y, (uint32_t)arity, c, k1, late, spin_max);
+    carry1 = look_back(agg, nch, y, (uint32_t)arity, c, k1, last1_kept, late, spin_max);
   if (late)
     atomicOr(&nrec[c], FLAG_SCAN << 16);                   // (row 0 of the component: k_fpc32_offsets collects the flags per component)
   cin[k0] = carry0;
