@@ -1379,63 +1379,80 @@ __device__ __forceinline__ void guard_compare(int arity, uint32_t S, const uint3
 // class (LDS: `local` = the row of entries written earlier in the chunk, `cin` = what came into the chunk), the store of the result,
 // and nothing else, so a lane takes up to FIX_B records at once: their loads are issued together, then their stores.
 constexpr uint32_t FIX_B = 8;
-__device__ __forceinline__ void fixup_row_wave(const uint32_t* __restrict__ local, const uint32_t* __restrict__ cin, uint32_t H,
+struct FixRecs { u32x4 w[FIX_B]; uint32_t known[FIX_B], k2w[FIX_B]; };
+
+// records base + 64 i + lane (i < FIX_B) of a row's list: the words the sweep wrote
+__device__ __forceinline__ void fix_load(FixRecs& r, const uint32_t* __restrict__ list, uint32_t H, uint32_t base, uint32_t lane)
+  {
+#pragma unroll
+  for (uint32_t i = 0; i < FIX_B; ++i)
+    {
+    const uint32_t j = base + 64u * i + lane;
+    r.w[i] = u32x4{ 0u, 0u, 0u, 0u };
+    r.known[i] = r.k2w[i] = 0u;
+    if (j < H)
+      {
+      r.w[i] = *(const u32x4*)(list + RECW * j);
+      const u32x2 t = *(const u32x2*)(list + RECW * j + 4u);
+      r.known[i] = t[0];
+      r.k2w[i] = t[1];
+      }
+    }
+  }
+
+// ... coded from the incoming entries; returns the lane's unused bytes
+__device__ __forceinline__ uint32_t fix_code(const FixRecs& r, uint32_t* __restrict__ list, uint32_t H, uint32_t base, uint32_t lane,
+                                             const uint32_t* __restrict__ local, const uint32_t* __restrict__ cin)
+  {
+  uint32_t unused = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < FIX_B; ++i)
+    {
+    const uint32_t j = base + 64u * i + lane;
+    if (j < H)
+      {
+      const bool ft1 = (r.w[i][0] & REC_FT1) != 0u, ft2 = (r.w[i][0] & REC_FT2) != 0u;
+      uint32_t p1 = r.known[i], p2 = r.known[i];
+      // (fpsc.c:96-97: the FCM class is the predecessor's top four bits)
+      if (ft1)
+        {
+        const uint32_t k = r.w[i][3] >> 28;
+        p1 = local[k];
+        p1 = p1 == SENT ? cin[k] : p1;
+        }
+      if (ft2)
+        {
+        const uint32_t k = 16u + (r.k2w[i] >> 2);
+        p2 = local[k];
+        p2 = p2 == SENT ? cin[k] : p2;
+        }
+      const uint32_t v = r.w[i][2], a = r.w[i][3];
+      const uint32_t x1 = v ^ p1, x2 = v ^ (a + p2);
+      const uint32_t n1 = (39u - (uint32_t)__clz((int)x1)) >> 3;
+      const uint32_t n2 = (39u - (uint32_t)__clz((int)(x2 | 1u))) >> 3;
+      const bool use2 = n2 < n1;
+      const uint32_t len = use2 ? n2 : n1, x = use2 ? x2 : x1, code = use2 ? (n2 | 4u) : n1;
+      *(u32x2*)(list + RECW * j + 6u) = u32x2{ x, len | (code << 4) };
+      unused += 4u - len;
+      }
+    }
+  return unused;
+  }
+
+// the rest of a row whose first 64 * FIX_B records `first` holds, and the row's size
+__device__ __forceinline__ void fixup_row_wave(const FixRecs& first, const uint32_t* __restrict__ local, const uint32_t* __restrict__ cin, uint32_t H,
                                                uint32_t* __restrict__ segbytes, const uint32_t* __restrict__ rawbytes,
                                                uint32_t* __restrict__ recs, uint32_t S, uint32_t arity, uint32_t rowi, uint32_t lane)
   {
   if (H == 0u)
     return;
   uint32_t* list = recs + (size_t)rowi * RCAP * RECW;
-  uint32_t unused = 0;
-  for (uint32_t base = 0; base < H; base += 64u * FIX_B)
+  uint32_t unused = fix_code(first, list, H, 0u, lane, local, cin);
+  for (uint32_t base = 64u * FIX_B; base < H; base += 64u * FIX_B)
     {
-    u32x4 w[FIX_B];
-    uint32_t known[FIX_B], k2w[FIX_B];
-#pragma unroll
-    for (uint32_t i = 0; i < FIX_B; ++i)
-      {
-      const uint32_t j = base + 64u * i + lane;
-      w[i] = u32x4{ 0u, 0u, 0u, 0u };
-      known[i] = k2w[i] = 0u;
-      if (j < H)
-        {
-        w[i] = *(const u32x4*)(list + RECW * j);
-        const u32x2 t = *(const u32x2*)(list + RECW * j + 4u);
-        known[i] = t[0];
-        k2w[i] = t[1];
-        }
-      }
-#pragma unroll
-    for (uint32_t i = 0; i < FIX_B; ++i)
-      {
-      const uint32_t j = base + 64u * i + lane;
-      if (j < H)
-        {
-        const bool ft1 = (w[i][0] & REC_FT1) != 0u, ft2 = (w[i][0] & REC_FT2) != 0u;
-        uint32_t p1 = known[i], p2 = known[i];
-        // (fpsc.c:96-97: the FCM class is the predecessor's top four bits)
-        if (ft1)
-          {
-          const uint32_t k = w[i][3] >> 28;
-          p1 = local[k];
-          p1 = p1 == SENT ? cin[k] : p1;
-          }
-        if (ft2)
-          {
-          const uint32_t k = 16u + (k2w[i] >> 2);
-          p2 = local[k];
-          p2 = p2 == SENT ? cin[k] : p2;
-          }
-        const uint32_t v = w[i][2], a = w[i][3];
-        const uint32_t x1 = v ^ p1, x2 = v ^ (a + p2);
-        const uint32_t n1 = (39u - (uint32_t)__clz((int)x1)) >> 3;
-        const uint32_t n2 = (39u - (uint32_t)__clz((int)(x2 | 1u))) >> 3;
-        const bool use2 = n2 < n1;
-        const uint32_t len = use2 ? n2 : n1, x = use2 ? x2 : x1, code = use2 ? (n2 | 4u) : n1;
-        *(u32x2*)(list + RECW * j + 6u) = u32x2{ x, len | (code << 4) };
-        unused += 4u - len;
-        }
-      }
+    FixRecs more;
+    fix_load(more, list, H, base, lane);
+    unused += fix_code(more, list, H, base, lane, local, cin);
     }
   const uint32_t incl = wave_scan_incl(unused);
   if (lane == 63u)
@@ -1508,6 +1525,19 @@ __global__ void __launch_bounds__(1024) k_fpc32_scanfix(const uint32_t* __restri
   if (tid < 256u)
     for (uint32_t q = gridDim.x - 1u - blockIdx.x; q < guard_rows; q += gridDim.x)
       guard_compare(arity, S, rawbytes, nrec, recs, slots, slot_stride, segcap, gslots, grecs, gmeta, q / (uint32_t)arity, q % (uint32_t)arity, tid);
+  // (a wave's rows of the fix-up: r, r + 16.  The records of the first are asked for now - they do not depend on the look-back -, those of
+  // the second when the first is coded: a row is two memory round trips otherwise, and the noisy component's workgroup had 2 x 2 of them
+  // behind the look-back: 31.7 -> 30.2 us)
+  const uint32_t rA = tid >> 6, rB = rA + SF_THREADS / 64u;
+  static_assert((uint32_t)CH <= 2u * (SF_THREADS / 64u), "two rows per wave");
+  FixRecs recA;
+  uint32_t HA = 0;
+  if (rA < cnt)
+    {
+    const uint32_t rowi = (g0 + rA) * (uint32_t)arity + c;
+    HA = nrec[rowi] & 0xffffu;
+    fix_load(recA, recs + (size_t)rowi * RCAP * RECW, HA, 0u, tid & 63u);
+    }
   // the chunks before mine (the second column: the first wave only)
   bool late = false;
   const uint32_t spin_max = (HOOK && (sabotage & 2u) != 0u) ? 512u : SPIN_MAX;
@@ -1521,8 +1551,20 @@ __global__ void __launch_bounds__(1024) k_fpc32_scanfix(const uint32_t* __restri
   if (two)
     cin[k1] = carry1;
   __syncthreads();
-  for (uint32_t r = tid >> 6; r < cnt; r += SF_THREADS / 64u)
-    fixup_row_wave(M + r * (uint32_t)TAB, cin, Hs[r], segbytes, rawbytes, recs, S, (uint32_t)arity, (g0 + r) * (uint32_t)arity + c, tid & 63u);
+  {
+  const uint32_t lane = tid & 63u;
+  FixRecs recB;
+  uint32_t HB = 0;
+  if (rB < cnt)
+    {
+    HB = Hs[rB];
+    fix_load(recB, recs + (size_t)((g0 + rB) * (uint32_t)arity + c) * RCAP * RECW, HB, 0u, lane);
+    }
+  if (rA < cnt)
+    fixup_row_wave(recA, M + rA * (uint32_t)TAB, cin, HA, segbytes, rawbytes, recs, S, (uint32_t)arity, (g0 + rA) * (uint32_t)arity + c, lane);
+  if (rB < cnt)
+    fixup_row_wave(recB, M + rB * (uint32_t)TAB, cin, HB, segbytes, rawbytes, recs, S, (uint32_t)arity, (g0 + rB) * (uint32_t)arity + c, lane);
+  }
   }
 
 // the scan kernel's LDS is beyond the 64 KiB a kernel gets without asking: claimed once per device of the process
